@@ -1,0 +1,227 @@
+"""ctypes binding of include/cdcmdr.h (the C-ABI of the HIP hot path).
+
+The structures below mirror the header field for field; tests/test_abi.py parses the header and
+checks field order and sizes against them.
+
+There is NO fallback: if libcdcmdr.so cannot be loaded (and cannot be built), every op raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_GROUPS = 32
+MAX_TENSORS = 48
+MAX_GATES = 16
+MAX_SEL = 16
+MAX_BN_SEGS = 24
+SORT_MAX_B = 16384
+BN_ROWS_PER_BLOCK = 64
+ROWDOT_PARTS = 64
+PREC_BF16 = 0
+PREC_F32 = 1
+
+c_f = C.c_float
+c_i32 = C.c_int32
+c_i64 = C.c_int64
+c_p = C.c_void_p
+
+
+class AdamHP(C.Structure):
+    _fields_ = [("lerp_w", c_f), ("beta2", c_f), ("one_minus_beta2", c_f), ("eps", c_f),
+                ("weight_decay", c_f), ("l2_twice", c_f), ("step_scalars", c_p), ("n_scalars", c_i32)]
+
+
+class LinGroup(C.Structure):
+    _fields_ = [("x", c_p), ("ldx", c_i64), ("w", c_p), ("ldw", c_i64), ("bias", c_p),
+                ("y", c_p), ("ldy", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("act_cols", c_i32)]
+
+
+class LinFwdArgs(C.Structure):
+    _fields_ = [("n_groups", c_i32), ("relu", c_i32), ("drop_p", c_f), ("seed", C.c_uint64),
+                ("seed_offset_dev", c_p), ("row_offsets", c_p), ("g", LinGroup * MAX_GROUPS)]
+
+
+class BwdxSeg(C.Structure):
+    _fields_ = [("dz", c_p), ("lddz", c_i64), ("w", c_p), ("ldw", c_i64), ("N", c_i32), ("out", c_i32)]
+
+
+class BwdxOut(C.Structure):
+    _fields_ = [("dx", c_p), ("lddx", c_i64), ("mask_y", c_p), ("ldmask", c_i64), ("M", c_i32), ("K", c_i32),
+                ("mask_cols", c_i32), ("accumulate", c_i32)]
+
+
+class LinBwdxArgs(C.Structure):
+    _fields_ = [("n_out", c_i32), ("n_seg", c_i32), ("mask_scale", c_f), ("row_offsets", c_p),
+                ("o", BwdxOut * MAX_GROUPS), ("s", BwdxSeg * MAX_GROUPS)]
+
+
+class BwdwGroup(C.Structure):
+    _fields_ = [("dz", c_p), ("lddz", c_i64), ("x", c_p), ("ldx", c_i64), ("dw", c_p), ("lddw", c_i64),
+                ("db", c_p), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("accumulate", c_i32)]
+
+
+class LinBwdwArgs(C.Structure):
+    _fields_ = [("n_groups", c_i32), ("row_offsets", c_p), ("g", BwdwGroup * MAX_GROUPS)]
+
+
+class PoolFwdGate(C.Structure):
+    _fields_ = [("logits", c_p), ("ld_logits", c_i64), ("out", c_p), ("ld_out", c_i64), ("probs", c_p),
+                ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL)]
+
+
+class PoolFwdArgs(C.Structure):
+    _fields_ = [("n_gates", c_i32), ("n_expert", c_i32), ("H", c_i32), ("B", c_i64), ("experts", c_p),
+                ("ld_exp", c_i64), ("gate", PoolFwdGate * MAX_GATES)]
+
+
+class PoolBwdGate(C.Structure):
+    _fields_ = [("d_out", c_p), ("ld_dout", c_i64), ("probs", c_p), ("d_logits", c_p), ("ld_dlogits", c_i64),
+                ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL)]
+
+
+class PoolBwdArgs(C.Structure):
+    _fields_ = [("n_gates", c_i32), ("n_expert", c_i32), ("H", c_i32), ("B", c_i64), ("experts", c_p),
+                ("ld_exp", c_i64), ("d_experts", c_p), ("ld_dexp", c_i64), ("mask_relu", c_i32),
+                ("mask_scale", c_f), ("accumulate", c_i32), ("gate", PoolBwdGate * MAX_GATES)]
+
+
+class BnSeg(C.Structure):
+    _fields_ = [("x", c_p), ("ldx", c_i64), ("y", c_p), ("ldy", c_i64), ("gamma", c_p), ("beta", c_p),
+                ("running_mean", c_p), ("running_var", c_p), ("save_mean", c_p), ("save_invstd", c_p),
+                ("num_batches_tracked", c_p), ("C", c_i32), ("row_group", c_i32)]
+
+
+class BnFwdArgs(C.Structure):
+    _fields_ = [("n_seg", c_i32), ("training", c_i32), ("relu", c_i32), ("eps", c_f), ("momentum", c_f),
+                ("drop_p", c_f), ("seed", C.c_uint64), ("seed_offset_dev", c_p), ("M", c_i64),
+                ("row_offsets", c_p), ("workspace", c_p), ("s", BnSeg * MAX_BN_SEGS)]
+
+
+class BnBSeg(C.Structure):
+    _fields_ = [("dy", c_p), ("lddy", c_i64), ("y", c_p), ("ldy", c_i64), ("x", c_p), ("ldx", c_i64),
+                ("dx", c_p), ("lddx", c_i64), ("gamma", c_p), ("save_mean", c_p), ("save_invstd", c_p),
+                ("dgamma", c_p), ("dbeta", c_p), ("C", c_i32), ("row_group", c_i32)]
+
+
+class BnBwdArgs(C.Structure):
+    _fields_ = [("n_seg", c_i32), ("training", c_i32), ("relu", c_i32), ("eps", c_f), ("mask_scale", c_f),
+                ("M", c_i64), ("row_offsets", c_p), ("workspace", c_p), ("s", BnBSeg * MAX_BN_SEGS)]
+
+
+class RowdotGroup(C.Structure):
+    _fields_ = [("x", c_p), ("ldx", c_i64), ("w", c_p), ("bias", c_p), ("out", c_p), ("ld_out", c_i64),
+                ("logit", c_p), ("ld_logit", c_i64), ("K", c_i32)]
+
+
+class RowdotFwdArgs(C.Structure):
+    _fields_ = [("n_groups", c_i32), ("sigmoid", c_i32), ("n_addend", c_i32), ("addend", c_p * 4),
+                ("ld_addend", c_i64 * 4), ("M", c_i64), ("row_offsets", c_p), ("g", RowdotGroup * MAX_GROUPS)]
+
+
+class RowdotBGroup(C.Structure):
+    _fields_ = [("dout", c_p), ("ld_dout", c_i64), ("out", c_p), ("ld_out", c_i64), ("x", c_p), ("ldx", c_i64),
+                ("w", c_p), ("dx", c_p), ("lddx", c_i64), ("dw", c_p), ("dbias", c_p), ("dlogit", c_p),
+                ("ld_dlogit", c_i64), ("K", c_i32), ("accumulate_dx", c_i32)]
+
+
+class RowdotBwdArgs(C.Structure):
+    _fields_ = [("n_groups", c_i32), ("sigmoid", c_i32), ("M", c_i64), ("row_offsets", c_p), ("workspace", c_p),
+                ("g", RowdotBGroup * MAX_GROUPS)]
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("w", c_p), ("g", c_p), ("m", c_p), ("v", c_p), ("n", c_i64), ("l2", c_f)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("n_tensors", c_i32), ("lerp_w", c_f), ("beta2", c_f), ("one_minus_beta2", c_f), ("eps", c_f),
+                ("weight_decay", c_f), ("step_scalars", c_p), ("n_scalars", c_i32), ("grad_scale", c_f),
+                ("step_dev", c_p), ("reg_sum", c_p), ("t", AdamTensor * MAX_TENSORS)]
+
+
+# name -> (restype, argtypes); every symbol include/cdcmdr.h declares
+_SIGNATURES = {
+    "cdc_abi_version": (c_i32, []),
+    "cdc_last_error": (C.c_char_p, []),
+    "cdc_embed_gather_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
+    "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
+    "cdc_embed_adam_touched": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32, c_p]),
+    "cdc_embed_adam_dense_pass": (c_i32, [c_p, c_p, c_p, c_i64, AdamHP, c_p, c_p, c_p]),
+    "cdc_embed_adam_patch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
+    "cdc_embed_lazy_catchup": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
+    "cdc_embed_lazy_update": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
+    "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_p, c_i32, c_p]),
+    "cdc_glinear_fwd": (c_i32, [C.POINTER(LinFwdArgs), c_i32, c_p]),
+    "cdc_glinear_bwd_x": (c_i32, [C.POINTER(LinBwdxArgs), c_i32, c_p]),
+    "cdc_glinear_bwd_w": (c_i32, [C.POINTER(LinBwdwArgs), c_i32, c_p]),
+    "cdc_gate_pool_fwd": (c_i32, [C.POINTER(PoolFwdArgs), c_p]),
+    "cdc_gate_pool_bwd": (c_i32, [C.POINTER(PoolBwdArgs), c_p]),
+    "cdc_bn_fwd": (c_i32, [C.POINTER(BnFwdArgs), c_p]),
+    "cdc_bn_bwd": (c_i32, [C.POINTER(BnBwdArgs), c_p]),
+    "cdc_rowdot_fwd": (c_i32, [C.POINTER(RowdotFwdArgs), c_p]),
+    "cdc_rowdot_bwd": (c_i32, [C.POINTER(RowdotBwdArgs), c_p]),
+    "cdc_bce_fwd_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f, c_p]),
+    "cdc_cross_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i32, c_p]),
+    "cdc_cross_bwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "cdc_adam_multi": (c_i32, [C.POINTER(AdamArgs), c_p]),
+    "cdc_step_increment": (c_i32, [c_p, c_p]),
+    "cdc_fill_f32": (c_i32, [c_p, c_f, c_i64, c_p]),
+    "cdc_fill_f64": (c_i32, [c_p, C.c_double, c_i64, c_p]),
+    "cdc_add_inplace": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_p]),
+    "cdc_mul_bcast": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
+    "cdc_mul_bcast_bwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p]),
+    "cdc_group_partition": (c_i32, [c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "cdc_rows_permute": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libcdcmdr.so (building it when absent and hipcc is available). Raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise HipExtensionError(
+                f"libcdcmdr.so is missing at {path} and could not be built ({e}); "
+                "run `python __graft_entry__.py build` — there is no CPU fallback") from e
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise HipExtensionError(f"cannot load {path}: {e}; there is no CPU fallback") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipExtensionError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cdc_abi_version() != 1:
+        raise HipExtensionError(f"ABI version mismatch: library {lib.cdc_abi_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cdc_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,95 @@
+// common.h — shared host/device helpers for the gfx950 kernels behind include/cdcmdr.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "cdcmdr.h"
+
+#define CDC_WAVE 64
+
+void cdc_set_error(const char* fmt, ...);
+
+#define CDC_CHECK_ARG(cond, code, ...)            \
+    do {                                          \
+        if (!(cond)) {                            \
+            cdc_set_error(__VA_ARGS__);           \
+            return (code);                        \
+        }                                         \
+    } while (0)
+
+// call after every launch: reports launch-configuration errors without synchronising
+#define CDC_LAUNCH_CHECK(name)                                                     \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            cdc_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                       \
+        }                                                                          \
+    } while (0)
+
+static inline int64_t cdc_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Counter-based dropout stream: a 64-bit mix of (seed, element index) -> uniform in [0,1).
+// The backward pass never regenerates it: a dropped or relu-clamped unit has output exactly 0,
+// so d_in = (out > 0) ? d_out * 1/(1-p) : 0 recovers the mask from the saved output.
+__device__ __forceinline__ float cdc_uniform(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// One element of torch's CPU Adam (torch/optim/adam.py _single_tensor_adam, as run.py:720-721
+// configures it) with the L2 term of model/layer.py:96-112 folded into the gradient:
+//   g  = g_in + l2_twice*w          (autograd: grad of sum(l2*w^2))
+//   g  = g + wd*w                   (grad.add(param, alpha=wd))
+//   m  = lerp(m, g, 1-beta1)        (exp_avg.lerp_)
+//   v  = v*beta2 + (1-beta2)*g*g    (mul_ then addcmul_)
+//   w -= step_size * m / (sqrt(v)/bc2_sqrt + eps)
+struct AdamConsts {
+    float lerp_w, beta2, omb2, eps, wd, l2_twice;
+};
+__device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g_in, const AdamConsts& c,
+                                          float step_size, float bc2_sqrt) {
+    // every rounding is pinned (no compiler contraction): the dense, touched-row and lazy-replay
+    // kernels must produce identical bits for identical inputs.
+    float g = __fadd_rn(g_in, __fmul_rn(c.l2_twice, w));
+    g = fmaf(w, c.wd, g);                                   // ATen add(alpha): vec fmadd
+    m = fmaf(c.lerp_w, __fsub_rn(g, m), m);                 // ATen lerp, |weight| < 0.5: fmadd
+    v = __fmul_rn(v, c.beta2);
+    v = __fadd_rn(v, __fmul_rn(__fmul_rn(c.omb2, g), g));   // addcmul: self + (value*t1)*t2
+    float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), c.eps);
+    w = __fadd_rn(w, __fdiv_rn(__fmul_rn(-step_size, m), denom));   // addcdiv: self + (value*t1)/t2
+}
+__device__ __forceinline__ AdamConsts make_consts(const cdc_adam_hp& hp) {
+    AdamConsts c;
+    c.lerp_w = hp.lerp_w; c.beta2 = hp.beta2; c.omb2 = hp.one_minus_beta2;
+    c.eps = hp.eps; c.wd = hp.weight_decay; c.l2_twice = hp.l2_twice;
+    return c;
+}
+__device__ __forceinline__ void step_scalars_at(const float* tab, int n, int t, float& step_size, float& bc2s) {
+    int i = t < n ? t : n - 1;
+    if (i < 0) i = 0;
+    step_size = tab[2 * i];
+    bc2s = tab[2 * i + 1];
+}

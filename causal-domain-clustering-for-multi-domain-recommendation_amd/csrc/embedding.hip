@@ -1,0 +1,465 @@
+// embedding.hip — sparse id -> embedding row gather, per-field sort/dedupe, and the table optimiser
+// (exact dense-Adam semantics of the reference, in dense and lazy-exact forms).
+//
+// Reference behaviour restated here:
+//   model/layer.py:147-157  FeaturesEmbedding.forward  (offset add in int32, row lookup, flatten)
+//   model/layer.py:31,96-112 + run.py:489,720-721       whole-table L2 + dense torch.optim.Adam
+// HBM-bound byte work: no MFMA here; coalesced 16-B lanes, LDS only for the per-field sort.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// gather
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) k_gather_fwd(const int32_t* __restrict__ ids, const int32_t* __restrict__ offsets,
+                                                    const float* __restrict__ table, float* __restrict__ out,
+                                                    int32_t* __restrict__ idx_out, int32_t* __restrict__ err_flag,
+                                                    int64_t n_pos, int32_t F, int32_t D, int64_t R) {
+    const int chunks = D / VEC;                       // chunks of VEC floats per row
+    const int64_t total = n_pos * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pos = i / chunks;
+        const int c = (int)(i - pos * chunks);
+        const int f = (int)(pos % F);
+        // model/layer.py:152 — the sum is formed in x's dtype (int32): wraps like torch's int32 add
+        const int32_t row = (int32_t)((uint32_t)ids[pos] + (uint32_t)offsets[f]);
+        if (c == 0 && idx_out) idx_out[pos] = row;
+        const bool ok = row >= 0 && (int64_t)row < R;
+        if (!ok && c == 0 && err_flag) atomicMax(err_flag, (int32_t)(pos < 0x7ffffffe ? pos + 1 : 0x7fffffff));
+        if (VEC == 4) {
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) val = *reinterpret_cast<const float4*>(table + (int64_t)row * D + c * 4);
+            *reinterpret_cast<float4*>(out + pos * D + c * 4) = val;
+        } else {
+            out[pos * D + c] = ok ? table[(int64_t)row * D + c] : 0.f;
+        }
+    }
+}
+
+extern "C" int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, const float* table, float* out,
+                                    int32_t* idx_out, int32_t* err_flag, int64_t B, int32_t F, int32_t D, int64_t R,
+                                    void* stream) {
+    CDC_CHECK_ARG(ids && offsets && table && out, CDC_E_BADARG, "embed_gather_fwd: null pointer");
+    CDC_CHECK_ARG(B >= 0 && F > 0 && D > 0 && R > 0, CDC_E_BADARG, "embed_gather_fwd: bad sizes B=%ld F=%d D=%d R=%ld",
+                  (long)B, F, D, (long)R);
+    if (B == 0) return 0;
+    const int64_t n_pos = B * F;
+    const bool vec = (D % 4 == 0) && (((uintptr_t)table | (uintptr_t)out) % 16 == 0);
+    const int64_t total = n_pos * (vec ? D / 4 : D);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    if (vec)
+        hipLaunchKernelGGL(k_gather_fwd<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, table, out,
+                           idx_out, err_flag, n_pos, F, D, R);
+    else
+        hipLaunchKernelGGL(k_gather_fwd<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, table, out,
+                           idx_out, err_flag, n_pos, F, D, R);
+    CDC_LAUNCH_CHECK("embed_gather_fwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-field sort + dedupe: one workgroup per field, bitonic sort of (row<<32 | b) in LDS
+// ------------------------------------------------------------------------------------------------
+#define SORT_THREADS 1024
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __restrict__ idx, int32_t* __restrict__ uniq_row,
+                                                              int32_t* __restrict__ seg_start, int32_t* __restrict__ perm,
+                                                              int32_t* __restrict__ uniq_cnt, int32_t B, int32_t F,
+                                                              int32_t n_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);              // n_pad entries
+    int32_t* scan = reinterpret_cast<int32_t*>(keys + n_pad);            // SORT_THREADS entries
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < n_pad; i += SORT_THREADS) {
+        uint64_t k = ~0ull;                                               // padding sorts last
+        if (i < B) k = ((uint64_t)(uint32_t)idx[(int64_t)i * F + f] << 32) | (uint32_t)i;
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n_pad >> 1); t += SORT_THREADS) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // index with bit j cleared
+                const int hi = lo | j;
+                const bool up = (lo & k) == 0;
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // head flags + block-wide exclusive scan; each thread owns a contiguous chunk
+    const int per = n_pad / SORT_THREADS > 0 ? n_pad / SORT_THREADS : 1;
+    const int begin = tid * per;
+    int local = 0;
+    for (int i = begin; i < begin + per && i < B; ++i) {
+        const bool head = (i == 0) || ((keys[i] >> 32) != (keys[i - 1] >> 32));
+        local += head ? 1 : 0;
+    }
+    scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+        int v = (tid >= off) ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    int u = scan[tid] - local;                                           // exclusive prefix
+    const int total = scan[SORT_THREADS - 1];
+    int32_t* urow = uniq_row + (int64_t)f * B;
+    int32_t* sst = seg_start + (int64_t)f * (B + 1);
+    int32_t* prm = perm + (int64_t)f * B;
+    for (int i = begin; i < begin + per && i < B; ++i) {
+        const uint64_t k = keys[i];
+        const bool head = (i == 0) || ((k >> 32) != (keys[i - 1] >> 32));
+        if (head) {
+            urow[u] = (int32_t)(uint32_t)(k >> 32);
+            sst[u] = i;
+            ++u;
+        }
+        prm[i] = (int32_t)(uint32_t)k;
+    }
+    if (tid == 0) {
+        sst[total] = B;
+        uniq_cnt[f] = total;
+    }
+}
+
+extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
+                                     int32_t* uniq_cnt, int64_t B, int32_t F, void* stream) {
+    CDC_CHECK_ARG(idx && uniq_row && seg_start && perm && uniq_cnt, CDC_E_BADARG, "embed_sort_dedupe: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0, CDC_E_BADARG, "embed_sort_dedupe: bad sizes");
+    CDC_CHECK_ARG(B <= CDC_SORT_MAX_B, CDC_E_TOOBIG, "embed_sort_dedupe: B=%ld exceeds %d", (long)B, CDC_SORT_MAX_B);
+    int n_pad = SORT_THREADS;   // at least one key per thread keeps the chunking simple
+    while (n_pad < B) n_pad <<= 1;
+    const size_t lds = (size_t)n_pad * 8 + SORT_THREADS * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_sort_dedupe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { cdc_set_error("embed_sort_dedupe: cannot raise LDS limit: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_sort_dedupe, dim3(F), dim3(SORT_THREADS), lds, (hipStream_t)stream, idx, uniq_row, seg_start, perm,
+                       uniq_cnt, (int32_t)B, F, n_pad);
+    CDC_LAUNCH_CHECK("embed_sort_dedupe");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense gradient (drop-in path: feeds torch.optim.Adam like aten::embedding_dense_backward)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_grad_dense(const float* __restrict__ d_out, const int32_t* __restrict__ uniq_row,
+                                                    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ perm,
+                                                    const int32_t* __restrict__ uniq_cnt, float* __restrict__ grad,
+                                                    int32_t B, int32_t F, int32_t D, int64_t R) {
+    const int64_t total = (int64_t)F * B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t slot = i / D;
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        const int32_t row = uniq_row[(int64_t)f * B + j];
+        if (row < 0 || (int64_t)row >= R) continue;
+        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+        const int32_t* prm = perm + (int64_t)f * B;
+        float acc = 0.f;
+        for (int k = sst[j]; k < sst[j + 1]; ++k) acc += d_out[((int64_t)prm[k] * F + f) * D + d];
+        grad[(int64_t)row * D + d] += acc;
+    }
+}
+
+extern "C" int cdc_embed_grad_dense(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
+                                    const int32_t* perm, const int32_t* uniq_cnt, float* grad, int64_t B, int32_t F,
+                                    int32_t D, int64_t R, void* stream) {
+    CDC_CHECK_ARG(d_out && uniq_row && seg_start && perm && uniq_cnt && grad, CDC_E_BADARG, "embed_grad_dense: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_B, CDC_E_BADARG, "embed_grad_dense: bad sizes");
+    const int64_t total = (int64_t)F * B * D;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_grad_dense, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, uniq_row, seg_start, perm,
+                       uniq_cnt, grad, (int32_t)B, F, D, R);
+    CDC_LAUNCH_CHECK("embed_grad_dense");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// table optimiser, dense form
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_adam_touched(const float* __restrict__ d_out, const int32_t* __restrict__ uniq_row,
+                                                      const int32_t* __restrict__ seg_start, const int32_t* __restrict__ perm,
+                                                      const int32_t* __restrict__ uniq_cnt, const float* __restrict__ w,
+                                                      const float* __restrict__ m, const float* __restrict__ v,
+                                                      float* __restrict__ side, cdc_adam_hp hp,
+                                                      const int32_t* __restrict__ step_dev, int32_t B, int32_t F, int32_t D) {
+    const AdamConsts c = make_consts(hp);
+    float step_size, bc2s;
+    step_scalars_at(hp.step_scalars, hp.n_scalars, *step_dev, step_size, bc2s);
+    const int64_t total = (int64_t)F * B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t slot = i / D;
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        const int64_t row = uniq_row[(int64_t)f * B + j];
+        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+        const int32_t* prm = perm + (int64_t)f * B;
+        float g = 0.f;
+        for (int k = sst[j]; k < sst[j + 1]; ++k) g = __fadd_rn(g, d_out[((int64_t)prm[k] * F + f) * D + d]);
+        float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
+        adam_elem(wv, mv, vv, g, c, step_size, bc2s);
+        float* s = side + slot * 3 * D;
+        s[d] = wv; s[D + d] = mv; s[2 * D + d] = vv;
+    }
+}
+
+extern "C" int cdc_embed_adam_touched(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
+                                      const int32_t* perm, const int32_t* uniq_cnt, const float* w, const float* m,
+                                      const float* v, float* side, cdc_adam_hp hp, const int32_t* step_dev, int64_t B,
+                                      int32_t F, int32_t D, void* stream) {
+    CDC_CHECK_ARG(d_out && uniq_row && seg_start && perm && uniq_cnt && w && m && v && side && step_dev && hp.step_scalars,
+                  CDC_E_BADARG, "embed_adam_touched: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_B && hp.n_scalars > 0, CDC_E_BADARG, "embed_adam_touched: bad sizes");
+    const int64_t total = (int64_t)F * B * D;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_adam_touched, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, uniq_row, seg_start, perm,
+                       uniq_cnt, w, m, v, side, hp, step_dev, (int32_t)B, F, D);
+    CDC_LAUNCH_CHECK("embed_adam_touched");
+    return 0;
+}
+
+// One streaming pass over the whole table: 12 B read + 12 B written per element.
+__global__ void __launch_bounds__(256) k_adam_dense_pass(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                         int64_t n_vec4, int64_t n_elems, cdc_adam_hp hp,
+                                                         const int32_t* __restrict__ step_dev, double* __restrict__ reg_sum) {
+    const AdamConsts c = make_consts(hp);
+    float step_size, bc2s;
+    step_scalars_at(hp.step_scalars, hp.n_scalars, *step_dev, step_size, bc2s);
+    double sq = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec4; i += stride) {
+        float4 wv = reinterpret_cast<float4*>(w)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        sq += (double)(wv.x * wv.x + wv.y * wv.y) + (double)(wv.z * wv.z + wv.w * wv.w);
+        adam_elem(wv.x, mv.x, vv.x, 0.f, c, step_size, bc2s);
+        adam_elem(wv.y, mv.y, vv.y, 0.f, c, step_size, bc2s);
+        adam_elem(wv.z, mv.z, vv.z, 0.f, c, step_size, bc2s);
+        adam_elem(wv.w, mv.w, vv.w, 0.f, c, step_size, bc2s);
+        reinterpret_cast<float4*>(w)[i] = wv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // scalar tail (n_elems not a multiple of 4)
+    for (int64_t i = n_vec4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_elems; i += stride) {
+        float wv = w[i], mv = m[i], vv = v[i];
+        sq += (double)(wv * wv);
+        adam_elem(wv, mv, vv, 0.f, c, step_size, bc2s);
+        w[i] = wv; m[i] = mv; v[i] = vv;
+    }
+    if (reg_sum) {
+        __shared__ double part[4];
+        sq = wave_sum_d(sq);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(reg_sum, part[0] + part[1] + part[2] + part[3]);
+    }
+}
+
+extern "C" int cdc_embed_adam_dense_pass(float* w, float* m, float* v, int64_t n_elems, cdc_adam_hp hp,
+                                         const int32_t* step_dev, double* reg_sum, void* stream) {
+    CDC_CHECK_ARG(w && m && v && step_dev && hp.step_scalars && hp.n_scalars > 0, CDC_E_BADARG, "embed_adam_dense_pass: null pointer");
+    CDC_CHECK_ARG(n_elems > 0, CDC_E_BADARG, "embed_adam_dense_pass: bad size");
+    CDC_CHECK_ARG((((uintptr_t)w | (uintptr_t)m | (uintptr_t)v) % 16) == 0, CDC_E_ALIGN, "embed_adam_dense_pass: buffers must be 16-byte aligned");
+    const int64_t n_vec4 = n_elems / 4;
+    int blocks = (int)std::min<int64_t>(std::max<int64_t>(cdc_ceil_div(n_vec4, 256), 1), 256 * 8);
+    hipLaunchKernelGGL(k_adam_dense_pass, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, n_vec4, n_elems, hp,
+                       step_dev, reg_sum);
+    CDC_LAUNCH_CHECK("embed_adam_dense_pass");
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) k_adam_patch(const float* __restrict__ side, const int32_t* __restrict__ uniq_row,
+                                                    const int32_t* __restrict__ uniq_cnt, float* __restrict__ w,
+                                                    float* __restrict__ m, float* __restrict__ v, int32_t B, int32_t F,
+                                                    int32_t D) {
+    const int64_t total = (int64_t)F * B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t slot = i / D;
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        const int64_t row = uniq_row[(int64_t)f * B + j];
+        const float* s = side + slot * 3 * D;
+        w[row * D + d] = s[d];
+        m[row * D + d] = s[D + d];
+        v[row * D + d] = s[2 * D + d];
+    }
+}
+
+extern "C" int cdc_embed_adam_patch(const float* side, const int32_t* uniq_row, const int32_t* uniq_cnt, float* w,
+                                    float* m, float* v, int64_t B, int32_t F, int32_t D, void* stream) {
+    CDC_CHECK_ARG(side && uniq_row && uniq_cnt && w && m && v, CDC_E_BADARG, "embed_adam_patch: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0, CDC_E_BADARG, "embed_adam_patch: bad sizes");
+    const int64_t total = (int64_t)F * B * D;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_adam_patch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, side, uniq_row, uniq_cnt, w, m, v,
+                       (int32_t)B, F, D);
+    CDC_LAUNCH_CHECK("embed_adam_patch");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// table optimiser, lazy-exact form: a row's (w,m,v) are valid for step last[row]; the untouched-row
+// recurrence (g = 2*l2*w + wd*w) is replayed on demand.  Every element-step is computed exactly once
+// with the same adam_elem as the dense pass, so both forms give identical bits.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
+                                                      float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                      int32_t* __restrict__ last, cdc_adam_hp hp,
+                                                      const int32_t* __restrict__ step_dev, int32_t B, int32_t F, int32_t D) {
+    const AdamConsts c = make_consts(hp);
+    const int target = *step_dev - 1;
+    const int64_t total = (int64_t)F * B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t slot = i / D;
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        const int64_t row = uniq_row[(int64_t)f * B + j];
+        const int from = last[row];
+        if (from >= target) continue;
+        float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
+        for (int s = from + 1; s <= target; ++s) {
+            float ss, bc;
+            step_scalars_at(hp.step_scalars, hp.n_scalars, s, ss, bc);
+            adam_elem(wv, mv, vv, 0.f, c, ss, bc);
+        }
+        w[row * D + d] = wv; m[row * D + d] = mv; v[row * D + d] = vv;
+        // last[row] is advanced by k_lazy_mark afterwards: every lane of the row reads it here
+    }
+}
+__global__ void __launch_bounds__(256) k_lazy_mark(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
+                                                   int32_t* __restrict__ last, const int32_t* __restrict__ step_dev, int32_t B,
+                                                   int32_t F) {
+    const int target = *step_dev - 1;
+    const int64_t total = (int64_t)F * B;
+    for (int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < total; slot += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        const int64_t row = uniq_row[slot];
+        if (last[row] < target) last[row] = target;
+    }
+}
+
+extern "C" int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* uniq_cnt, float* w, float* m, float* v,
+                                      int32_t* last, cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring,
+                                      int32_t ring_len, int64_t B, int32_t F, int32_t D, void* stream) {
+    (void)reg_ring; (void)ring_len;
+    CDC_CHECK_ARG(uniq_row && uniq_cnt && w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0, CDC_E_BADARG,
+                  "embed_lazy_catchup: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0, CDC_E_BADARG, "embed_lazy_catchup: bad sizes");
+    const int64_t total = (int64_t)F * B * D;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_lazy_catchup, dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, w, m, v, last, hp,
+                       step_dev, (int32_t)B, F, D);
+    CDC_LAUNCH_CHECK("embed_lazy_catchup");
+    int blocks2 = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 256 * 16);
+    hipLaunchKernelGGL(k_lazy_mark, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, last, step_dev,
+                       (int32_t)B, F);
+    CDC_LAUNCH_CHECK("embed_lazy_mark");
+    return 0;
+}
+
+// step t for the batch's rows: rows are at t-1 after catchup (last[] still holds the older value,
+// which is ignored here); writes last[row] = t.
+__global__ void __launch_bounds__(256) k_lazy_update(const float* __restrict__ d_out, const int32_t* __restrict__ uniq_row,
+                                                     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ perm,
+                                                     const int32_t* __restrict__ uniq_cnt, float* __restrict__ w,
+                                                     float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ last,
+                                                     cdc_adam_hp hp, const int32_t* __restrict__ step_dev, int32_t B,
+                                                     int32_t F, int32_t D) {
+    const AdamConsts c = make_consts(hp);
+    const int t = *step_dev;
+    float step_size, bc2s;
+    step_scalars_at(hp.step_scalars, hp.n_scalars, t, step_size, bc2s);
+    const int64_t total = (int64_t)F * B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t slot = i / D;
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        const int64_t row = uniq_row[(int64_t)f * B + j];
+        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+        const int32_t* prm = perm + (int64_t)f * B;
+        float g = 0.f;
+        for (int k = sst[j]; k < sst[j + 1]; ++k) g = __fadd_rn(g, d_out[((int64_t)prm[k] * F + f) * D + d]);
+        float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
+        adam_elem(wv, mv, vv, g, c, step_size, bc2s);
+        w[row * D + d] = wv; m[row * D + d] = mv; v[row * D + d] = vv;
+        if (d == 0) last[row] = t;
+    }
+}
+
+extern "C" int cdc_embed_lazy_update(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
+                                     const int32_t* perm, const int32_t* uniq_cnt, float* w, float* m, float* v,
+                                     int32_t* last, cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring,
+                                     int32_t ring_len, int64_t B, int32_t F, int32_t D, void* stream) {
+    (void)reg_ring; (void)ring_len;
+    CDC_CHECK_ARG(d_out && uniq_row && seg_start && perm && uniq_cnt && w && m && v && last && step_dev && hp.step_scalars &&
+                      hp.n_scalars > 0, CDC_E_BADARG, "embed_lazy_update: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0, CDC_E_BADARG, "embed_lazy_update: bad sizes");
+    const int64_t total = (int64_t)F * B * D;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    hipLaunchKernelGGL(k_lazy_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, uniq_row, seg_start, perm,
+                       uniq_cnt, w, m, v, last, hp, step_dev, (int32_t)B, F, D);
+    CDC_LAUNCH_CHECK("embed_lazy_update");
+    return 0;
+}
+
+// all rows -> step (*step_dev + step_bias)
+__global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                    int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
+                                                    const int32_t* __restrict__ step_dev, int32_t step_bias) {
+    const AdamConsts c = make_consts(hp);
+    const int target = *step_dev + step_bias;
+    const int64_t total = R * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / D;
+        const int from = last[row];
+        if (from >= target) continue;
+        float wv = w[i], mv = m[i], vv = v[i];
+        for (int s = from + 1; s <= target; ++s) {
+            float ss, bc;
+            step_scalars_at(hp.step_scalars, hp.n_scalars, s, ss, bc);
+            adam_elem(wv, mv, vv, 0.f, c, ss, bc);
+        }
+        w[i] = wv; m[i] = mv; v[i] = vv;
+    }
+}
+__global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ last, int64_t R, const int32_t* __restrict__ step_dev,
+                                                       int32_t step_bias) {
+    const int target = *step_dev + step_bias;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x)
+        if (last[i] < target) last[i] = target;
+}
+
+extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D, cdc_adam_hp hp,
+                                    const int32_t* step_dev, int32_t step_bias, double* reg_ring, int32_t ring_len,
+                                    void* stream) {
+    (void)reg_ring; (void)ring_len;
+    CDC_CHECK_ARG(w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0, CDC_E_BADARG, "embed_lazy_flush: null pointer");
+    CDC_CHECK_ARG(R > 0 && D > 0, CDC_E_BADARG, "embed_lazy_flush: bad sizes");
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(R * D, 256), 256 * 16);
+    hipLaunchKernelGGL(k_lazy_flush, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, last, R, D, hp, step_dev, step_bias);
+    CDC_LAUNCH_CHECK("embed_lazy_flush");
+    int blocks2 = (int)std::min<int64_t>(cdc_ceil_div(R, 256), 256 * 16);
+    hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias);
+    CDC_LAUNCH_CHECK("embed_lazy_set_last");
+    return 0;
+}

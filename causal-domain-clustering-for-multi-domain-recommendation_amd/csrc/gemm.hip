@@ -1,0 +1,441 @@
+// gemm.hip — grouped linear layers on the gfx950 matrix cores.
+//
+// Stands in for every nn.Linear / F.linear on the reference's training path
+// (model/layer.py:185,193,275; model/ple.py:83-94; model/mmoe.py:35-40; model/star.py:90-102)
+// and for the three ATen addmm calls autograd issues for each of them (forward, grad-input,
+// grad-weight).  Storage is fp32; the contraction runs either on bf16 MFMA with fp32
+// accumulation (v_mfma_f32_16x16x32_bf16, operands rounded while staging into LDS) or on the
+// exact fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// One 256-thread workgroup (4 waves, 2x2) owns a BM x BN output tile of one group; all groups of
+// a layer go out in ONE launch (descriptors travel as kernel arguments).  Global -> register ->
+// LDS staging with the next K-slab's loads in flight under the current slab's MFMAs.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define GEMM_THREADS 256
+#define BK 32
+// LDS row strides chosen so the 16 lanes of a ds_read_b128 group land on disjoint bank quads
+#define LDS_STRIDE_BF16 40   // elements: 80 bytes
+#define LDS_STRIDE_F32 33    // elements
+
+template <bool BF16> struct LdsElem;
+template <> struct LdsElem<true> { typedef __bf16 type; static constexpr int stride = LDS_STRIDE_BF16; };
+template <> struct LdsElem<false> { typedef float type; static constexpr int stride = LDS_STRIDE_F32; };
+
+// A tile operand: element (i, r) lives at p[i*s_i + r*s_r]; i in [0,I) (tile rows), r in [0,Rn) (reduction).
+struct Operand {
+    const float* p;
+    int64_t s_i, s_r;
+    int I, Rn;      // valid extents
+};
+
+// ---- staging: global -> registers (fp32) -------------------------------------------------------
+// RC = true : reduction index contiguous in memory (s_r == 1): thread loads 4 consecutive r
+// RC = false: tile-row index contiguous (s_i == 1): thread loads 4 consecutive i at one r
+template <int ROWS, bool RC>
+struct Stage {
+    static constexpr int PER = ROWS * BK / 4 / GEMM_THREADS;   // float4 loads per thread
+    f32x4_t v[PER];
+
+    __device__ __forceinline__ void load(const Operand& op, int i0, int r0, int tid) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int i, r;
+            if (RC) { r = (tid % (BK / 4)) * 4; i = tid / (BK / 4) + p * (GEMM_THREADS / (BK / 4)); }
+            else    { i = (tid % (ROWS / 4)) * 4; r = tid / (ROWS / 4) + p * (GEMM_THREADS / (ROWS / 4)); }
+            const int gi = i0 + i, gr = r0 + r;
+            f32x4_t val = {0.f, 0.f, 0.f, 0.f};
+            if (RC) {
+                if (gi < op.I) {
+                    const float* src = op.p + (int64_t)gi * op.s_i + gr;
+                    if (gr + 3 < op.Rn && (((uintptr_t)src) & 15) == 0) val = *reinterpret_cast<const f32x4_t*>(src);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (gr + q < op.Rn) val[q] = src[q];
+                    }
+                }
+            } else {
+                if (gr < op.Rn) {
+                    const float* src = op.p + (int64_t)gr * op.s_r + gi;
+                    if (gi + 3 < op.I && (((uintptr_t)src) & 15) == 0) val = *reinterpret_cast<const f32x4_t*>(src);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (gi + q < op.I) val[q] = src[q];
+                    }
+                }
+            }
+            v[p] = val;
+        }
+    }
+
+    template <typename T>
+    __device__ __forceinline__ void store(T* lds, int stride, int tid) const {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int i, r;
+            if (RC) { r = (tid % (BK / 4)) * 4; i = tid / (BK / 4) + p * (GEMM_THREADS / (BK / 4)); }
+            else    { i = (tid % (ROWS / 4)) * 4; r = tid / (ROWS / 4) + p * (GEMM_THREADS / (ROWS / 4)); }
+            if (RC) {
+                if constexpr (sizeof(T) == 2) {
+                    bf16x4_t b = __builtin_convertvector(v[p], bf16x4_t);
+                    *reinterpret_cast<bf16x4_t*>(lds + i * stride + r) = b;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) lds[i * stride + r + q] = v[p][q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lds[(i + q) * stride + r] = (T)v[p][q];
+            }
+        }
+    }
+};
+
+// ---- one K-slab of MFMAs for this wave ------------------------------------------------------------
+template <bool BF16, int MT, int NT>
+__device__ __forceinline__ void mma_slab(const typename LdsElem<BF16>::type* As, const typename LdsElem<BF16>::type* Bs,
+                                         int wm, int wn, int lane, f32x4_t (&acc)[MT][NT]) {
+    constexpr int S = LdsElem<BF16>::stride;
+    const int lr = lane & 15, lk = lane >> 4;
+    if constexpr (BF16) {
+        bf16x8_t a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8_t*>(As + (wm + mt * 16 + lr) * S + lk * 8);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn + nt * 16 + lr) * S + lk * 8);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = As[(wm + mt * 16 + lr) * S + kk * 4 + lk];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = Bs[(wn + nt * 16 + lr) * S + kk * 4 + lk];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+}
+
+// ---- accumulate A(i,r)·B(j,r) over r for one (A,B) operand pair into acc ---------------------------
+template <bool BF16, int BM, int BN, bool A_RC, bool B_RC, bool COLSUM>
+__device__ __forceinline__ void gemm_accumulate(const Operand& A, const Operand& B, int i0, int j0, unsigned char* smem,
+                                                f32x4_t (&acc)[BM / 32][BN / 32], f32x4_t* colsum) {
+    typedef typename LdsElem<BF16>::type T;
+    constexpr int S = LdsElem<BF16>::stride;
+    T* As = reinterpret_cast<T*>(smem);
+    T* Bs = As + BM * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int nk = (A.Rn + BK - 1) / BK;
+    Stage<BM, A_RC> sa;
+    Stage<BN, B_RC> sb;
+    if (nk > 0) { sa.load(A, i0, 0, tid); sb.load(B, j0, 0, tid); }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (COLSUM) {
+            // bias gradient: column sums of the A operand (dZ) in fp32, taken before the bf16 rounding
+#pragma unroll
+            for (int p = 0; p < Stage<BM, A_RC>::PER; ++p) colsum[0] += sa.v[p];
+        }
+        sa.store(As, S, tid);
+        sb.store(Bs, S, tid);
+        __syncthreads();
+        if (kt + 1 < nk) { sa.load(A, i0, (kt + 1) * BK, tid); sb.load(B, j0, (kt + 1) * BK, tid); }
+        mma_slab<BF16, BM / 32, BN / 32>(As, Bs, wm, wn, lane, acc);
+        __syncthreads();
+    }
+}
+
+// XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) get a contiguous run of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk / 8, r = nblk % 8, x = bid % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+}
+
+// =================================================================================================
+// forward: y = act(x · wᵀ + bias)
+// =================================================================================================
+template <bool BF16, int BM, int BN>
+__global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int g = 0, tn_cnt = 1;
+    for (; g < a.n_groups; ++g) {
+        tn_cnt = (a.g[g].N + BN - 1) / BN;
+        const int t = ((a.g[g].M + BM - 1) / BM) * tn_cnt;
+        if (tile < t) break;
+        tile -= t;
+    }
+    if (g >= a.n_groups) return;
+    const cdc_lin_group& G = a.g[g];
+    int row_lo = 0, M = G.M;
+    if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
+    const int i0 = (tile / tn_cnt) * BM, j0 = (tile % tn_cnt) * BN;
+    if (i0 >= M) return;
+
+    Operand A{G.x + (int64_t)row_lo * G.ldx, G.ldx, 1, M, G.K};
+    Operand B{G.w, G.ldw, 1, G.N, G.K};
+    f32x4_t acc[BM / 32][BN / 32];
+#pragma unroll
+    for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < BN / 32; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    gemm_accumulate<BF16, BM, BN, true, true, false>(A, B, i0, j0, smem, acc, nullptr);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    uint64_t seed = a.seed;
+    if (a.drop_p > 0.f && a.seed_offset_dev) seed += (uint64_t)(uint32_t)(*a.seed_offset_dev) * 0xD1342543DE82EF95ull;
+    float* y = G.y + (int64_t)row_lo * G.ldy;
+#pragma unroll
+    for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < BN / 32; ++nt) {
+            const int col = j0 + wn + nt * 16 + (lane & 15);
+            if (col >= G.N) continue;
+            const float bv = G.bias ? G.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
+                if (row >= M) continue;
+                float val = acc[mt][nt][r] + bv;
+                if (col < G.act_cols) {
+                    if (a.relu) val = fmaxf(val, 0.f);
+                    if (a.drop_p > 0.f) {
+                        const uint64_t e = ((uint64_t)g << 56) ^ ((uint64_t)(row_lo + row) * (uint64_t)G.N + (uint64_t)col);
+                        val = cdc_uniform(seed, e) < a.drop_p ? 0.f : val * keep_scale;
+                    }
+                }
+                y[(int64_t)row * G.ldy + col] = val;
+            }
+        }
+}
+
+// =================================================================================================
+// grad-input: dX_o = sum_s dZ_s · W_s  (+ activation mask of the producing layer)
+// =================================================================================================
+template <bool BF16, int BM, int BN>
+__global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bwdx_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int o = 0, tn_cnt = 1;
+    for (; o < a.n_out; ++o) {
+        tn_cnt = (a.o[o].K + BN - 1) / BN;
+        const int t = ((a.o[o].M + BM - 1) / BM) * tn_cnt;
+        if (tile < t) break;
+        tile -= t;
+    }
+    if (o >= a.n_out) return;
+    const cdc_bwdx_out& O = a.o[o];
+    int row_lo = 0, M = O.M;
+    if (a.row_offsets) { row_lo = a.row_offsets[o]; M = a.row_offsets[o + 1] - row_lo; }
+    const int i0 = (tile / tn_cnt) * BM, j0 = (tile % tn_cnt) * BN;
+    if (i0 >= M) return;
+
+    f32x4_t acc[BM / 32][BN / 32];
+#pragma unroll
+    for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < BN / 32; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < a.n_seg; ++s) {
+        if (a.s[s].out != o) continue;
+        const cdc_bwdx_seg& S = a.s[s];
+        Operand A{S.dz + (int64_t)row_lo * S.lddz, S.lddz, 1, M, S.N};   // (i=row, r=n)  r contiguous
+        Operand B{S.w, 1, S.ldw, O.K, S.N};                               // (j=k,  r=n)  j contiguous
+        gemm_accumulate<BF16, BM, BN, true, false, false>(A, B, i0, j0, smem, acc, nullptr);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    float* dx = O.dx + (int64_t)row_lo * O.lddx;
+    const float* mk = O.mask_y ? O.mask_y + (int64_t)row_lo * O.ldmask : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < BN / 32; ++nt) {
+            const int col = j0 + wn + nt * 16 + (lane & 15);
+            if (col >= O.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
+                if (row >= M) continue;
+                float val = acc[mt][nt][r];
+                if (mk && col < O.mask_cols) val = mk[(int64_t)row * O.ldmask + col] > 0.f ? val * a.mask_scale : 0.f;
+                float* dst = dx + (int64_t)row * O.lddx + col;
+                *dst = O.accumulate ? *dst + val : val;
+            }
+        }
+}
+
+// =================================================================================================
+// grad-weight: dW_g = dZ_gᵀ · X_g ; db_g = colsum(dZ_g)
+// =================================================================================================
+template <bool BF16, int BM, int BN>
+__global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bwdw_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    int g = 0, tn_cnt = 1;
+    for (; g < a.n_groups; ++g) {
+        tn_cnt = (a.g[g].K + BN - 1) / BN;
+        const int t = ((a.g[g].N + BM - 1) / BM) * tn_cnt;
+        if (tile < t) break;
+        tile -= t;
+    }
+    if (g >= a.n_groups) return;
+    const cdc_bwdw_group& G = a.g[g];
+    int row_lo = 0, M = G.M;
+    if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
+    const int i0 = (tile / tn_cnt) * BM, j0 = (tile % tn_cnt) * BN;   // i over N (dW rows), j over K (dW cols)
+
+    Operand A{G.dz + (int64_t)row_lo * G.lddz, 1, G.lddz, G.N, M};     // (i=n, r=b)  i contiguous
+    Operand B{G.x + (int64_t)row_lo * G.ldx, 1, G.ldx, G.K, M};        // (j=k, r=b)  j contiguous
+    f32x4_t acc[BM / 32][BN / 32];
+#pragma unroll
+    for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < BN / 32; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};
+    const bool want_db = (G.db != nullptr) && (j0 == 0);
+    if (want_db) gemm_accumulate<BF16, BM, BN, false, false, true>(A, B, i0, j0, smem, acc, &colsum);
+    else         gemm_accumulate<BF16, BM, BN, false, false, false>(A, B, i0, j0, smem, acc, nullptr);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (want_db) {
+        // threads tid % (BM/4) share the same 4 columns; fixed-order reduction through LDS
+        float* red = reinterpret_cast<float*>(smem);                       // GEMM_THREADS * 4 floats
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[tid * 4 + q] = colsum[q];
+        __syncthreads();
+        if (tid < BM) {
+            const int c4 = tid / 4, q = tid % 4;
+            float s = 0.f;
+            for (int t = c4; t < GEMM_THREADS; t += BM / 4) s += red[t * 4 + q];
+            const int n = i0 + tid;
+            if (n < G.N) G.db[n] = G.accumulate ? G.db[n] + s : s;
+        }
+    }
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+#pragma unroll
+    for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < BN / 32; ++nt) {
+            const int col = j0 + wn + nt * 16 + (lane & 15);
+            if (col >= G.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
+                if (row >= G.N) continue;
+                float* dst = G.dw + (int64_t)row * G.lddw + col;
+                const float val = acc[mt][nt][r];
+                *dst = G.accumulate ? *dst + val : val;
+            }
+        }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+template <bool BF16, int BM, int BN>
+static constexpr size_t lds_bytes() {
+    size_t tiles = (size_t)(BM + BN) * LdsElem<BF16>::stride * sizeof(typename LdsElem<BF16>::type);
+    size_t red = (size_t)GEMM_THREADS * 4 * sizeof(float);
+    return tiles > red ? tiles : red;
+}
+
+static bool pick_big_tiles(int64_t tiles64) {
+    // 128x128 tiles quarter the L2 traffic per flop; use them once they still give every CU >= 2 workgroups
+    return tiles64 / 4 >= 512;
+}
+
+extern "C" int cdc_glinear_fwd(const cdc_lin_fwd_args* a, int32_t prec, void* stream) {
+    CDC_CHECK_ARG(a && a->n_groups > 0 && a->n_groups <= CDC_MAX_GROUPS, CDC_E_BADARG, "glinear_fwd: bad group count");
+    CDC_CHECK_ARG(prec == CDC_PREC_BF16 || prec == CDC_PREC_F32, CDC_E_BADARG, "glinear_fwd: bad precision");
+    CDC_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f, CDC_E_BADARG, "glinear_fwd: dropout p out of range");
+    int64_t t64 = 0, t128 = 0;
+    for (int g = 0; g < a->n_groups; ++g) {
+        const cdc_lin_group& G = a->g[g];
+        CDC_CHECK_ARG(G.x && G.w && G.y && G.M >= 0 && G.N > 0 && G.K > 0 && G.ldx >= G.K && G.ldw >= G.K && G.ldy >= G.N,
+                      CDC_E_BADARG, "glinear_fwd: group %d malformed (M=%d N=%d K=%d)", g, G.M, G.N, G.K);
+        t64 += cdc_ceil_div(G.M, 64) * cdc_ceil_div(G.N, 64);
+        t128 += cdc_ceil_div(G.M, 128) * cdc_ceil_div(G.N, 128);
+    }
+    if (t64 == 0) return 0;
+    const bool big = pick_big_tiles(t64);
+    const int64_t grid = big ? t128 : t64;
+    CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "glinear_fwd: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == CDC_PREC_BF16) {
+        if (big) hipLaunchKernelGGL((k_glinear_fwd<true, 128, 128>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_fwd<true, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
+    } else {
+        if (big) hipLaunchKernelGGL((k_glinear_fwd<false, 128, 128>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_fwd<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
+    }
+    CDC_LAUNCH_CHECK("glinear_fwd");
+    return 0;
+}
+
+extern "C" int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void* stream) {
+    CDC_CHECK_ARG(a && a->n_out > 0 && a->n_out <= CDC_MAX_GROUPS && a->n_seg > 0 && a->n_seg <= CDC_MAX_GROUPS, CDC_E_BADARG,
+                  "glinear_bwd_x: bad counts");
+    CDC_CHECK_ARG(prec == CDC_PREC_BF16 || prec == CDC_PREC_F32, CDC_E_BADARG, "glinear_bwd_x: bad precision");
+    int64_t t64 = 0, t128 = 0;
+    for (int o = 0; o < a->n_out; ++o) {
+        const cdc_bwdx_out& O = a->o[o];
+        CDC_CHECK_ARG(O.dx && O.M >= 0 && O.K > 0 && O.lddx >= O.K, CDC_E_BADARG, "glinear_bwd_x: output %d malformed", o);
+        t64 += cdc_ceil_div(O.M, 64) * cdc_ceil_div(O.K, 64);
+        t128 += cdc_ceil_div(O.M, 128) * cdc_ceil_div(O.K, 128);
+    }
+    for (int s = 0; s < a->n_seg; ++s) {
+        const cdc_bwdx_seg& S = a->s[s];
+        CDC_CHECK_ARG(S.dz && S.w && S.N > 0 && S.out >= 0 && S.out < a->n_out && S.lddz >= S.N && S.ldw >= a->o[S.out].K,
+                      CDC_E_BADARG, "glinear_bwd_x: segment %d malformed", s);
+    }
+    if (t64 == 0) return 0;
+    const bool big = pick_big_tiles(t64);
+    const int64_t grid = big ? t128 : t64;
+    CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "glinear_bwd_x: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == CDC_PREC_BF16) {
+        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<true, 128, 128>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_bwd_x<true, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
+    } else {
+        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<false, 128, 128>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_bwd_x<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
+    }
+    CDC_LAUNCH_CHECK("glinear_bwd_x");
+    return 0;
+}
+
+extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void* stream) {
+    CDC_CHECK_ARG(a && a->n_groups > 0 && a->n_groups <= CDC_MAX_GROUPS, CDC_E_BADARG, "glinear_bwd_w: bad group count");
+    CDC_CHECK_ARG(prec == CDC_PREC_BF16 || prec == CDC_PREC_F32, CDC_E_BADARG, "glinear_bwd_w: bad precision");
+    int64_t t64 = 0;
+    for (int g = 0; g < a->n_groups; ++g) {
+        const cdc_bwdw_group& G = a->g[g];
+        CDC_CHECK_ARG(G.dz && G.x && G.dw && G.M >= 0 && G.N > 0 && G.K > 0 && G.lddz >= G.N && G.ldx >= G.K && G.lddw >= G.K,
+                      CDC_E_BADARG, "glinear_bwd_w: group %d malformed", g);
+        t64 += cdc_ceil_div(G.N, 64) * cdc_ceil_div(G.K, 64);
+    }
+    CDC_CHECK_ARG(t64 < (1ll << 31), CDC_E_TOOBIG, "glinear_bwd_w: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (prec == CDC_PREC_BF16)
+        hipLaunchKernelGGL((k_glinear_bwd_w<true, 64, 64>), dim3(t64), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
+    else
+        hipLaunchKernelGGL((k_glinear_bwd_w<false, 64, 64>), dim3(t64), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
+    CDC_LAUNCH_CHECK("glinear_bwd_w");
+    return 0;
+}

@@ -1,0 +1,641 @@
+// rowops.hip — the row-wise (HBM / L2 bound) operators between the MFMA contractions:
+// gate softmax + expert pooling, BatchNorm(+ReLU+dropout), row dot products (+sigmoid),
+// BCE loss, the DCN-v1 cross layer.  One wave (64 lanes) per batch row wherever a row-wise
+// reduction is needed; reductions across rows go through order-fixed partial sums (no float atomics).
+#include "common.h"
+
+#define ROW_THREADS 256
+#define WAVES_PER_BLOCK (ROW_THREADS / 64)
+
+// =================================================================================================
+// gate softmax + pooling   (model/ple.py:89-94,105-123 ; model/mmoe.py:37-40,58-60)
+// =================================================================================================
+__global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_fwd(const cdc_pool_fwd_args a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= a.B) return;
+    const float* ex = a.experts + row * a.ld_exp;
+    for (int g = 0; g < a.n_gates; ++g) {
+        const auto& G = a.gate[g];
+        const float* lg = G.logits + row * G.ld_logits;
+        // softmax over n_sel <= 16 logits, every lane redundantly (torch.softmax: max-subtract, exp, normalise)
+        float p[CDC_MAX_SEL];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) {
+            p[j] = j < G.n_sel ? lg[j] : -INFINITY;
+            mx = fmaxf(mx, p[j]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) {
+            p[j] = j < G.n_sel ? expf(p[j] - mx) : 0.f;
+            sum += p[j];
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] *= inv;
+        if (lane < G.n_sel && G.probs) {
+            float pv = 0.f;
+#pragma unroll
+            for (int j = 0; j < CDC_MAX_SEL; ++j) if (j == lane) pv = p[j];
+            G.probs[row * G.n_sel + lane] = pv;
+        }
+        for (int h = lane; h < a.H; h += 64) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < CDC_MAX_SEL; ++j)
+                if (j < G.n_sel) acc += p[j] * ex[(int64_t)G.sel[j] * a.H + h];   // same order as torch.sum(dim=1)
+            G.out[row * G.ld_out + h] = acc;
+        }
+    }
+}
+
+extern "C" int cdc_gate_pool_fwd(const cdc_pool_fwd_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n_gates > 0 && a->n_gates <= CDC_MAX_GATES && a->n_expert > 0 && a->H > 0 && a->B >= 0 && a->experts,
+                  CDC_E_BADARG, "gate_pool_fwd: bad argument");
+    for (int g = 0; g < a->n_gates; ++g) {
+        CDC_CHECK_ARG(a->gate[g].logits && a->gate[g].out && a->gate[g].n_sel > 0 && a->gate[g].n_sel <= CDC_MAX_SEL, CDC_E_BADARG,
+                      "gate_pool_fwd: gate %d malformed", g);
+        for (int j = 0; j < a->gate[g].n_sel; ++j)
+            CDC_CHECK_ARG(a->gate[g].sel[j] >= 0 && a->gate[g].sel[j] < a->n_expert, CDC_E_BADARG, "gate_pool_fwd: gate %d selects expert out of range", g);
+    }
+    if (a->B == 0) return 0;
+    hipLaunchKernelGGL(k_gate_pool_fwd, dim3(cdc_ceil_div(a->B, WAVES_PER_BLOCK)), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("gate_pool_fwd");
+    return 0;
+}
+
+__global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd(const cdc_pool_bwd_args a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= a.B) return;
+    const float* ex = a.experts + row * a.ld_exp;
+    float* dex = a.d_experts + row * a.ld_dexp;
+    // (1) gate gradients: dp_j = <d_out, expert_sel[j]> ; d_logit_j = p_j * (dp_j - sum_k p_k dp_k)
+    for (int g = 0; g < a.n_gates; ++g) {
+        const auto& G = a.gate[g];
+        const float* dout = G.d_out + row * G.ld_dout;
+        float dp[CDC_MAX_SEL];
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) dp[j] = 0.f;
+        for (int h = lane; h < a.H; h += 64) {
+            const float d = dout[h];
+#pragma unroll
+            for (int j = 0; j < CDC_MAX_SEL; ++j)
+                if (j < G.n_sel) dp[j] += d * ex[(int64_t)G.sel[j] * a.H + h];
+        }
+        float dot = 0.f;
+        float pj_lane = 0.f, dpj_lane = 0.f;
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) {
+            if (j < G.n_sel) {
+                dp[j] = wave_sum(dp[j]);
+                const float pj = G.probs[row * G.n_sel + j];
+                dot += pj * dp[j];
+                if (j == lane) { pj_lane = pj; dpj_lane = dp[j]; }
+            }
+        }
+        if (lane < G.n_sel) G.d_logits[row * G.ld_dlogits + lane] = pj_lane * (dpj_lane - dot);
+    }
+    // (2) expert gradients: d_expert_e = sum over gates that select e of p * d_out  (then the expert's relu/dropout mask)
+    for (int e = 0; e < a.n_expert; ++e) {
+        for (int h = lane; h < a.H; h += 64) {
+            float acc = 0.f;
+            for (int g = 0; g < a.n_gates; ++g) {
+                const auto& G = a.gate[g];
+                for (int j = 0; j < G.n_sel; ++j)
+                    if (G.sel[j] == e) acc += G.probs[row * G.n_sel + j] * G.d_out[row * G.ld_dout + h];
+            }
+            if (a.mask_relu) acc = ex[(int64_t)e * a.H + h] > 0.f ? acc * a.mask_scale : 0.f;
+            float* dst = dex + (int64_t)e * a.H + h;
+            *dst = a.accumulate ? *dst + acc : acc;
+        }
+    }
+}
+
+extern "C" int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n_gates > 0 && a->n_gates <= CDC_MAX_GATES && a->n_expert > 0 && a->H > 0 && a->B >= 0 && a->experts &&
+                      a->d_experts, CDC_E_BADARG, "gate_pool_bwd: bad argument");
+    for (int g = 0; g < a->n_gates; ++g)
+        CDC_CHECK_ARG(a->gate[g].d_out && a->gate[g].probs && a->gate[g].d_logits && a->gate[g].n_sel > 0 &&
+                          a->gate[g].n_sel <= CDC_MAX_SEL, CDC_E_BADARG, "gate_pool_bwd: gate %d malformed", g);
+    if (a->B == 0) return 0;
+    hipLaunchKernelGGL(k_gate_pool_bwd, dim3(cdc_ceil_div(a->B, WAVES_PER_BLOCK)), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("gate_pool_bwd");
+    return 0;
+}
+
+// =================================================================================================
+// BatchNorm1d (+ReLU +dropout)  (model/layer.py:187,199-205 ; model/star.py:117-181)
+// block = 64 columns x 64 rows: lane = column, wave w takes rows w, w+4, ...
+// =================================================================================================
+struct BnTile { int seg, c0, row_lo, M, chunk, col_base; };
+
+template <typename Args>
+__device__ __forceinline__ bool bn_locate(const Args& a, int n_chunks, BnTile& t) {
+    // blockIdx.x -> (segment, 64-column tile, row chunk)
+    int tile = blockIdx.x / n_chunks;
+    t.chunk = blockIdx.x % n_chunks;
+    int s = 0, col_base = 0;
+    for (; s < a.n_seg; ++s) {
+        const int ct = (a.s[s].C + 63) / 64;
+        if (tile < ct) break;
+        tile -= ct;
+        col_base += a.s[s].C;
+    }
+    if (s >= a.n_seg) return false;
+    t.seg = s; t.c0 = tile * 64; t.col_base = col_base;
+    t.row_lo = 0; t.M = (int)a.M;
+    if (a.row_offsets) { const int rg = a.s[s].row_group; t.row_lo = a.row_offsets[rg]; t.M = a.row_offsets[rg + 1] - t.row_lo; }
+    return true;
+}
+
+// pass 1: per (row chunk, column) partial sum and sum of squares in double
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_stats(const cdc_bn_fwd_args a, int n_chunks, int total_c) {
+    BnTile t;
+    if (!bn_locate(a, n_chunks, t)) return;
+    const cdc_bn_seg& S = a.s[t.seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = t.c0 + lane;
+    double s1 = 0.0, s2 = 0.0;
+    const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
+    const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
+    if (c < S.C)
+        for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
+            const double x = (double)S.x[(int64_t)(t.row_lo + r) * S.ldx + c];
+            s1 += x; s2 += x * x;
+        }
+    __shared__ double sh[2][WAVES_PER_BLOCK][64];
+    sh[0][wave][lane] = s1; sh[1][wave][lane] = s2;
+    __syncthreads();
+    if (wave == 0 && c < S.C) {
+        s1 = sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane];
+        s2 = sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane];
+        double* ws = a.workspace + ((int64_t)t.chunk * total_c + t.col_base + c) * 2;
+        ws[0] = s1; ws[1] = s2;
+    }
+}
+
+// pass 2: finalise stats for the tile's columns (every block redundantly, fixed order), normalise its rows
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args a, int n_chunks, int total_c) {
+    BnTile t;
+    if (!bn_locate(a, n_chunks, t)) return;
+    const cdc_bn_seg& S = a.s[t.seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = t.c0 + lane;
+    const bool skip_norm = (t.M == 1);           // reference skips BN when the (group's) batch has one row
+    float mean = 0.f, invstd = 1.f;
+    if (c < S.C && !skip_norm) {
+        if (a.training) {
+            double s1 = 0.0, s2 = 0.0;
+            const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
+            for (int k = 0; k < used; ++k) {
+                const double* ws = a.workspace + ((int64_t)k * total_c + t.col_base + c) * 2;
+                s1 += ws[0]; s2 += ws[1];
+            }
+            const double mu = t.M > 0 ? s1 / t.M : 0.0;
+            double var = t.M > 0 ? s2 / t.M - mu * mu : 0.0;
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            if (t.chunk == 0 && wave == 0) {
+                if (S.save_mean) S.save_mean[c] = mean;
+                if (S.save_invstd) S.save_invstd[c] = invstd;
+                if (S.running_mean && t.M > 0) {
+                    const double unbiased = t.M > 1 ? var * ((double)t.M / (double)(t.M - 1)) : var;
+                    S.running_mean[c] = (1.f - a.momentum) * S.running_mean[c] + a.momentum * mean;
+                    S.running_var[c] = (1.f - a.momentum) * S.running_var[c] + a.momentum * (float)unbiased;
+                }
+            }
+        } else {
+            mean = S.running_mean[c];
+            invstd = 1.f / sqrtf(S.running_var[c] + a.eps);
+        }
+    }
+    if (a.training && !skip_norm && t.chunk == 0 && t.c0 == 0 && threadIdx.x == 0 && S.num_batches_tracked) *S.num_batches_tracked += 1;
+    if (c >= S.C) return;
+    const float gam = (skip_norm || !S.gamma) ? 1.f : S.gamma[c];
+    const float bet = (skip_norm || !S.beta) ? 0.f : S.beta[c];
+    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    uint64_t seed = a.seed;
+    if (a.drop_p > 0.f && a.seed_offset_dev) seed += (uint64_t)(uint32_t)(*a.seed_offset_dev) * 0xD1342543DE82EF95ull;
+    const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
+    const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
+    for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
+        const int64_t gr = t.row_lo + r;
+        float v = S.x[gr * S.ldx + c];
+        if (!skip_norm) v = (v - mean) * invstd * gam + bet;
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.drop_p > 0.f) {
+            const uint64_t e = ((uint64_t)(t.seg + 64) << 56) ^ ((uint64_t)gr * (uint64_t)S.C + (uint64_t)c);
+            v = cdc_uniform(seed, e) < a.drop_p ? 0.f : v * keep_scale;
+        }
+        S.y[gr * S.ldy + c] = v;
+    }
+}
+
+extern "C" int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n_seg > 0 && a->n_seg <= CDC_MAX_BN_SEGS && a->M >= 0, CDC_E_BADARG, "bn_fwd: bad argument");
+    CDC_CHECK_ARG(!a->training || a->workspace, CDC_E_BADARG, "bn_fwd: training needs a workspace");
+    int total_c = 0, col_tiles = 0;
+    for (int s = 0; s < a->n_seg; ++s) {
+        const cdc_bn_seg& S = a->s[s];
+        CDC_CHECK_ARG(S.x && S.y && S.C > 0 && S.ldx >= S.C && S.ldy >= S.C, CDC_E_BADARG, "bn_fwd: segment %d malformed", s);
+        CDC_CHECK_ARG(a->training || (S.running_mean && S.running_var), CDC_E_BADARG, "bn_fwd: eval needs running stats");
+        total_c += S.C;
+        col_tiles += (S.C + 63) / 64;
+    }
+    if (a->M == 0) return 0;
+    const int n_chunks = (int)cdc_ceil_div(a->M, CDC_BN_ROWS_PER_BLOCK);
+    const int64_t grid = (int64_t)col_tiles * n_chunks;
+    CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "bn_fwd: grid too large");
+    if (a->training) {
+        hipLaunchKernelGGL(k_bn_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+        CDC_LAUNCH_CHECK("bn_stats");
+    }
+    hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+    CDC_LAUNCH_CHECK("bn_apply");
+    return 0;
+}
+
+// backward pass 1: partial sums of dz (-> dbeta) and dz * xhat (-> dgamma), dz = activation-masked dy
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_stats(const cdc_bn_bwd_args a, int n_chunks, int total_c) {
+    BnTile t;
+    if (!bn_locate(a, n_chunks, t)) return;
+    const cdc_bn_bseg& S = a.s[t.seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = t.c0 + lane;
+    double s1 = 0.0, s2 = 0.0;
+    const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
+    const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
+    if (c < S.C && t.M != 1) {
+        const float mean = S.save_mean[c], invstd = S.save_invstd[c];
+        for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
+            const int64_t gr = t.row_lo + r;
+            float dz = S.dy[gr * S.lddy + c];
+            if (a.relu || a.mask_scale != 1.f) dz = S.y[gr * S.ldy + c] > 0.f ? dz * a.mask_scale : 0.f;
+            const float xhat = (S.x[gr * S.ldx + c] - mean) * invstd;
+            s1 += (double)dz; s2 += (double)dz * (double)xhat;
+        }
+    }
+    __shared__ double sh[2][WAVES_PER_BLOCK][64];
+    sh[0][wave][lane] = s1; sh[1][wave][lane] = s2;
+    __syncthreads();
+    if (wave == 0 && c < S.C) {
+        s1 = sh[0][0][lane] + sh[0][1][lane] + sh[0][2][lane] + sh[0][3][lane];
+        s2 = sh[1][0][lane] + sh[1][1][lane] + sh[1][2][lane] + sh[1][3][lane];
+        double* ws = a.workspace + ((int64_t)t.chunk * total_c + t.col_base + c) * 2;
+        ws[0] = s1; ws[1] = s2;
+    }
+}
+
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_args a, int n_chunks, int total_c) {
+    BnTile t;
+    if (!bn_locate(a, n_chunks, t)) return;
+    const cdc_bn_bseg& S = a.s[t.seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = t.c0 + lane;
+    if (c >= S.C) return;
+    const bool skip_norm = (t.M == 1);
+    double s1 = 0.0, s2 = 0.0;
+    if (!skip_norm) {
+        const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
+        for (int k = 0; k < used; ++k) {
+            const double* ws = a.workspace + ((int64_t)k * total_c + t.col_base + c) * 2;
+            s1 += ws[0]; s2 += ws[1];
+        }
+    }
+    if (t.chunk == 0 && wave == 0) {
+        if (S.dbeta) S.dbeta[c] = (float)s1;
+        if (S.dgamma) S.dgamma[c] = (float)s2;
+    }
+    const float gam = (skip_norm || !S.gamma) ? 1.f : S.gamma[c];
+    const float mean = skip_norm ? 0.f : S.save_mean[c];
+    const float invstd = skip_norm ? 1.f : S.save_invstd[c];
+    const float invM = t.M > 0 ? 1.f / (float)t.M : 0.f;
+    const float db = (float)s1, dg = (float)s2;
+    const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
+    const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
+    for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
+        const int64_t gr = t.row_lo + r;
+        float dz = S.dy[gr * S.lddy + c];
+        if (a.relu || a.mask_scale != 1.f) dz = S.y[gr * S.ldy + c] > 0.f ? dz * a.mask_scale : 0.f;
+        float dx;
+        if (skip_norm) dx = dz;
+        else if (a.training) {
+            const float xhat = (S.x[gr * S.ldx + c] - mean) * invstd;
+            dx = gam * invstd * (dz - invM * (db + xhat * dg));
+        } else dx = gam * invstd * dz;
+        S.dx[gr * S.lddx + c] = dx;
+    }
+}
+
+extern "C" int cdc_bn_bwd(const cdc_bn_bwd_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n_seg > 0 && a->n_seg <= CDC_MAX_BN_SEGS && a->M >= 0 && a->workspace, CDC_E_BADARG, "bn_bwd: bad argument");
+    int total_c = 0, col_tiles = 0;
+    for (int s = 0; s < a->n_seg; ++s) {
+        const cdc_bn_bseg& S = a->s[s];
+        CDC_CHECK_ARG(S.dy && S.y && S.x && S.dx && S.save_mean && S.save_invstd && S.C > 0, CDC_E_BADARG, "bn_bwd: segment %d malformed", s);
+        total_c += S.C;
+        col_tiles += (S.C + 63) / 64;
+    }
+    if (a->M == 0) return 0;
+    const int n_chunks = (int)cdc_ceil_div(a->M, CDC_BN_ROWS_PER_BLOCK);
+    const int64_t grid = (int64_t)col_tiles * n_chunks;
+    CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "bn_bwd: grid too large");
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+    CDC_LAUNCH_CHECK("bn_bwd_stats");
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+    CDC_LAUNCH_CHECK("bn_bwd_apply");
+    return 0;
+}
+
+// =================================================================================================
+// row dot products (+addends, +sigmoid)  (model/layer.py:122-126, :193 + :50-55, dcn.py:42)
+// =================================================================================================
+__global__ void __launch_bounds__(ROW_THREADS) k_rowdot_fwd(const cdc_rowdot_fwd_args a) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.y;
+    const cdc_rowdot_group& G = a.g[g];
+    int row_lo = 0, M = (int)a.M;
+    if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
+    const int64_t r = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int64_t gr = row_lo + r;
+    const float* x = G.x + gr * G.ldx;
+    float acc = 0.f;
+    for (int k = lane; k < G.K; k += 64) acc += x[k] * G.w[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (G.bias) acc += G.bias[0];
+        for (int i = 0; i < a.n_addend; ++i) acc += a.addend[i][gr * a.ld_addend[i]];
+        if (G.logit) G.logit[gr * G.ld_logit] = acc;
+        if (a.sigmoid) acc = 1.f / (1.f + expf(-acc));
+        G.out[gr * G.ld_out] = acc;
+    }
+}
+
+extern "C" int cdc_rowdot_fwd(const cdc_rowdot_fwd_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n_groups > 0 && a->n_groups <= CDC_MAX_GROUPS && a->M >= 0 && a->n_addend >= 0 && a->n_addend <= 4,
+                  CDC_E_BADARG, "rowdot_fwd: bad argument");
+    for (int g = 0; g < a->n_groups; ++g)
+        CDC_CHECK_ARG(a->g[g].x && a->g[g].w && a->g[g].out && a->g[g].K > 0, CDC_E_BADARG, "rowdot_fwd: group %d malformed", g);
+    if (a->M == 0) return 0;
+    hipLaunchKernelGGL(k_rowdot_fwd, dim3(cdc_ceil_div(a->M, WAVES_PER_BLOCK), a->n_groups), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("rowdot_fwd");
+    return 0;
+}
+
+// backward: rows are split into CDC_ROWDOT_PARTS contiguous parts; each part's block writes its partial
+// (dw[K], dbias) to the workspace; a second launch adds the parts in order.
+__global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd(const cdc_rowdot_bwd_args a, int kmax) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.y, part = blockIdx.x;
+    const cdc_rowdot_bgroup& G = a.g[g];
+    int row_lo = 0, M = (int)a.M;
+    if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
+    const int per = (M + CDC_ROWDOT_PARTS - 1) / CDC_ROWDOT_PARTS;
+    const int r_begin = part * per, r_end = min(r_begin + per, M);
+    extern __shared__ float sh[];      // [WAVES_PER_BLOCK][kmax + 1]
+    float* mine = sh + wave * (kmax + 1);
+    for (int k = lane; k <= kmax; k += 64) mine[k] = 0.f;
+    float db = 0.f;
+    for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
+        const int64_t gr = row_lo + r;
+        float d = G.dout[gr * G.ld_dout];
+        if (a.sigmoid) { const float o = G.out[gr * G.ld_out]; d = d * o * (1.f - o); }
+        if (lane == 0 && G.dlogit) G.dlogit[gr * G.ld_dlogit] = d;
+        db += d;
+        const float* x = G.x + gr * G.ldx;
+        for (int k = lane; k < G.K; k += 64) {
+            mine[k] += d * x[k];
+            if (G.dx) {
+                float* dst = G.dx + gr * G.lddx + k;
+                const float v = d * G.w[k];
+                *dst = G.accumulate_dx ? *dst + v : v;
+            }
+        }
+    }
+    if (lane == 0) mine[kmax] = db;
+    __syncthreads();
+    float* ws = a.workspace + ((int64_t)g * CDC_ROWDOT_PARTS + part) * (kmax + 1);
+    for (int k = threadIdx.x; k <= kmax; k += ROW_THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) s += sh[w * (kmax + 1) + k];
+        ws[k] = s;
+    }
+}
+__global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd_final(const cdc_rowdot_bwd_args a, int kmax) {
+    const int g = blockIdx.y;
+    const cdc_rowdot_bgroup& G = a.g[g];
+    const int k = blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (k > kmax) return;
+    const float* ws = a.workspace + (int64_t)g * CDC_ROWDOT_PARTS * (kmax + 1);
+    float s = 0.f;
+    for (int p = 0; p < CDC_ROWDOT_PARTS; ++p) s += ws[(int64_t)p * (kmax + 1) + k];
+    if (k < G.K) { if (G.dw) G.dw[k] = s; }
+    else if (k == kmax && G.dbias) G.dbias[0] = s;
+}
+
+extern "C" int cdc_rowdot_bwd(const cdc_rowdot_bwd_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n_groups > 0 && a->n_groups <= CDC_MAX_GROUPS && a->M >= 0 && a->workspace, CDC_E_BADARG, "rowdot_bwd: bad argument");
+    int kmax = 0;
+    for (int g = 0; g < a->n_groups; ++g) {
+        CDC_CHECK_ARG(a->g[g].dout && a->g[g].x && a->g[g].w && a->g[g].K > 0 && (!a->sigmoid || a->g[g].out), CDC_E_BADARG,
+                      "rowdot_bwd: group %d malformed", g);
+        kmax = std::max(kmax, a->g[g].K);
+    }
+    CDC_CHECK_ARG((size_t)WAVES_PER_BLOCK * (kmax + 1) * 4 <= 64 * 1024, CDC_E_TOOBIG, "rowdot_bwd: K too large");
+    hipLaunchKernelGGL(k_rowdot_bwd, dim3(CDC_ROWDOT_PARTS, a->n_groups), dim3(ROW_THREADS), WAVES_PER_BLOCK * (kmax + 1) * sizeof(float),
+                       (hipStream_t)stream, *a, kmax);
+    CDC_LAUNCH_CHECK("rowdot_bwd");
+    hipLaunchKernelGGL(k_rowdot_bwd_final, dim3(cdc_ceil_div(kmax + 1, ROW_THREADS), a->n_groups), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, *a, kmax);
+    CDC_LAUNCH_CHECK("rowdot_bwd_final");
+    return 0;
+}
+
+// =================================================================================================
+// BCE on probabilities, mean reduction, + its gradient  (run.py:484,723; aten binary_cross_entropy)
+// =================================================================================================
+__global__ void __launch_bounds__(1024) k_bce(const float* __restrict__ p, int64_t ldp, const int64_t* __restrict__ group,
+                                              const int16_t* __restrict__ y_i16, const float* __restrict__ y_f32,
+                                              float* __restrict__ loss, float* __restrict__ dp, int64_t lddp, int64_t B,
+                                              int32_t n_col, float inv_count) {
+    double acc = 0.0;
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        int64_t col = group ? group[b] : 0;
+        if (col < 0 || col >= n_col) col = 0;
+        const float x = p[b * ldp + col];
+        const float t = y_i16 ? (float)y_i16[b] : y_f32[b];
+        const float l = (t - 1.f) * fmaxf(log1pf(-x), -100.f) - t * fmaxf(logf(x), -100.f);
+        acc += (double)l;
+        if (dp) {
+            for (int c = 0; c < n_col; ++c) dp[b * lddp + c] = 0.f;
+            dp[b * lddp + col] = inv_count * (x - t) / fmaxf((1.f - x) * x, 1e-12f);
+        }
+    }
+    __shared__ double sh[16];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+        *loss = (float)(s * (double)inv_count);
+    }
+}
+
+extern "C" int cdc_bce_fwd_bwd(const float* p, int64_t ldp, const int64_t* group, const int16_t* y_i16, const float* y_f32,
+                               float* loss, float* dp, int64_t lddp, int64_t B, int32_t n_col, float inv_count, void* stream) {
+    CDC_CHECK_ARG(p && loss && (y_i16 || y_f32) && B > 0 && n_col > 0 && ldp >= n_col && (!dp || lddp >= n_col), CDC_E_BADARG,
+                  "bce_fwd_bwd: bad argument");
+    hipLaunchKernelGGL(k_bce, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, ldp, group, y_i16, y_f32, loss, dp, lddp, B, n_col, inv_count);
+    CDC_LAUNCH_CHECK("bce_fwd_bwd");
+    return 0;
+}
+
+// =================================================================================================
+// DCN-v1 cross layer  (model/layer.py:321-329):  out = x0 * (xl . w) + b + xl
+// =================================================================================================
+__global__ void __launch_bounds__(ROW_THREADS) k_cross_fwd(const float* __restrict__ x0, int64_t ld0, const float* __restrict__ xl,
+                                                           int64_t ldl, const float* __restrict__ w, const float* __restrict__ b,
+                                                           float* __restrict__ out, int64_t ldo, float* __restrict__ xw_save,
+                                                           int64_t B, int32_t E) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* xr = xl + row * ldl;
+    float s = 0.f;
+    for (int k = lane; k < E; k += 64) s += xr[k] * w[k];
+    s = wave_sum(s);
+    if (lane == 0 && xw_save) xw_save[row] = s;
+    const float* x0r = x0 + row * ld0;
+    for (int k = lane; k < E; k += 64) out[row * ldo + k] = x0r[k] * s + b[k] + xr[k];
+}
+
+extern "C" int cdc_cross_fwd(const float* x0, int64_t ld0, const float* xl, int64_t ldl, const float* w, const float* b,
+                             float* out, int64_t ldo, float* xw_save, int64_t B, int32_t E, void* stream) {
+    CDC_CHECK_ARG(x0 && xl && w && b && out && B >= 0 && E > 0 && ld0 >= E && ldl >= E && ldo >= E, CDC_E_BADARG, "cross_fwd: bad argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_cross_fwd, dim3(cdc_ceil_div(B, WAVES_PER_BLOCK)), dim3(ROW_THREADS), 0, (hipStream_t)stream, x0, ld0, xl, ldl,
+                       w, b, out, ldo, xw_save, B, E);
+    CDC_LAUNCH_CHECK("cross_fwd");
+    return 0;
+}
+
+// d_s = <d_out, x0>; d_x0 += d_out*s; d_xl = d_out + d_s*w; dw = sum_b d_s*xl; db = sum_b d_out
+__global__ void __launch_bounds__(ROW_THREADS) k_cross_bwd(const float* __restrict__ d_out, int64_t ldo, const float* __restrict__ x0,
+                                                           int64_t ld0, const float* __restrict__ xl, int64_t ldl,
+                                                           const float* __restrict__ w, const float* __restrict__ xw_save,
+                                                           float* __restrict__ d_x0_acc, int64_t ld_dx0, float* __restrict__ d_xl,
+                                                           int64_t ld_dxl, float* __restrict__ workspace, int64_t B, int32_t E) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = blockIdx.x;
+    const int64_t per = (B + CDC_ROWDOT_PARTS - 1) / CDC_ROWDOT_PARTS;
+    const int64_t r_begin = part * per, r_end = min(r_begin + per, B);
+    extern __shared__ float sh[];      // [WAVES][2E]
+    float* mine = sh + wave * 2 * E;
+    for (int k = lane; k < 2 * E; k += 64) mine[k] = 0.f;
+    for (int64_t r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
+        const float* dor = d_out + r * ldo;
+        const float* x0r = x0 + r * ld0;
+        const float* xlr = xl + r * ldl;
+        float ds = 0.f;
+        for (int k = lane; k < E; k += 64) ds += dor[k] * x0r[k];
+        ds = wave_sum(ds);
+        const float s = xw_save[r];
+        for (int k = lane; k < E; k += 64) {
+            const float d = dor[k];
+            d_x0_acc[r * ld_dx0 + k] += d * s;
+            d_xl[r * ld_dxl + k] = d + ds * w[k];
+            mine[k] += ds * xlr[k];
+            mine[E + k] += d;
+        }
+    }
+    __syncthreads();
+    float* ws = workspace + (int64_t)part * 2 * E;
+    for (int k = threadIdx.x; k < 2 * E; k += ROW_THREADS) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < WAVES_PER_BLOCK; ++wv) s += sh[wv * 2 * E + k];
+        ws[k] = s;
+    }
+}
+__global__ void __launch_bounds__(ROW_THREADS) k_cross_bwd_final(const float* __restrict__ workspace, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int32_t E) {
+    const int k = blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (k >= 2 * E) return;
+    float s = 0.f;
+    for (int p = 0; p < CDC_ROWDOT_PARTS; ++p) s += workspace[(int64_t)p * 2 * E + k];
+    if (k < E) dw[k] = s; else db[k - E] = s;
+}
+
+extern "C" int cdc_cross_bwd(const float* d_out, int64_t ldo, const float* x0, int64_t ld0, const float* xl, int64_t ldl,
+                             const float* w, const float* xw_save, float* d_x0_acc, int64_t ld_dx0, float* d_xl, int64_t ld_dxl,
+                             float* dw, float* db, float* workspace, int64_t B, int32_t E, void* stream) {
+    CDC_CHECK_ARG(d_out && x0 && xl && w && xw_save && d_x0_acc && d_xl && dw && db && workspace && B > 0 && E > 0, CDC_E_BADARG,
+                  "cross_bwd: bad argument");
+    CDC_CHECK_ARG((size_t)WAVES_PER_BLOCK * 2 * E * 4 <= 64 * 1024, CDC_E_TOOBIG, "cross_bwd: E too large");
+    hipLaunchKernelGGL(k_cross_bwd, dim3(CDC_ROWDOT_PARTS), dim3(ROW_THREADS), WAVES_PER_BLOCK * 2 * E * sizeof(float), (hipStream_t)stream,
+                       d_out, ldo, x0, ld0, xl, ldl, w, xw_save, d_x0_acc, ld_dx0, d_xl, ld_dxl, workspace, B, E);
+    CDC_LAUNCH_CHECK("cross_bwd");
+    hipLaunchKernelGGL(k_cross_bwd_final, dim3(cdc_ceil_div(2 * E, ROW_THREADS)), dim3(ROW_THREADS), 0, (hipStream_t)stream, workspace, dw, db, E);
+    CDC_LAUNCH_CHECK("cross_bwd_final");
+    return 0;
+}
+
+// =================================================================================================
+// dense-parameter Adam, multi-tensor (run.py:720-721 + the L2 term of model/layer.py:96-112)
+// =================================================================================================
+#define ADAM_CHUNK 4096
+__global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args a) {
+    int chunk = blockIdx.x, ti = 0;
+    for (; ti < a.n_tensors; ++ti) {
+        const int nc = (int)((a.t[ti].n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+        if (chunk < nc) break;
+        chunk -= nc;
+    }
+    if (ti >= a.n_tensors) return;
+    const cdc_adam_tensor& T = a.t[ti];
+    AdamConsts c;
+    c.lerp_w = a.lerp_w; c.beta2 = a.beta2; c.omb2 = a.one_minus_beta2; c.eps = a.eps; c.wd = a.weight_decay;
+    c.l2_twice = 2.f * T.l2;
+    float step_size, bc2s;
+    step_scalars_at(a.step_scalars, a.n_scalars, *a.step_dev, step_size, bc2s);
+    const int64_t begin = (int64_t)chunk * ADAM_CHUNK;
+    const int64_t end = min(begin + ADAM_CHUNK, T.n);
+    double sq = 0.0;
+    for (int64_t i = begin + threadIdx.x; i < end; i += ROW_THREADS) {
+        float w = T.w[i], m = T.m[i], v = T.v[i];
+        float g = T.g ? T.g[i] : 0.f;
+        if (a.grad_scale != 1.f) g *= a.grad_scale;
+        sq += (double)(w * w);
+        adam_elem(w, m, v, g, c, step_size, bc2s);
+        T.w[i] = w; T.m[i] = m; T.v[i] = v;
+    }
+    if (a.reg_sum && T.l2 != 0.f) {
+        __shared__ double part[WAVES_PER_BLOCK];
+        sq = wave_sum_d(sq);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(a.reg_sum, (double)T.l2 * (part[0] + part[1] + part[2] + part[3]));
+    }
+}
+
+extern "C" int cdc_adam_multi(const cdc_adam_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n_tensors > 0 && a->n_tensors <= CDC_MAX_TENSORS && a->step_dev && a->step_scalars && a->n_scalars > 0,
+                  CDC_E_BADARG, "adam_multi: bad argument");
+    int64_t chunks = 0;
+    for (int i = 0; i < a->n_tensors; ++i) {
+        CDC_CHECK_ARG(a->t[i].w && a->t[i].m && a->t[i].v && a->t[i].n > 0, CDC_E_BADARG, "adam_multi: tensor %d malformed", i);
+        chunks += cdc_ceil_div(a->t[i].n, ADAM_CHUNK);
+    }
+    CDC_CHECK_ARG(chunks < (1ll << 31), CDC_E_TOOBIG, "adam_multi: too many chunks");
+    hipLaunchKernelGGL(k_adam_multi, dim3(chunks), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("adam_multi");
+    return 0;
+}

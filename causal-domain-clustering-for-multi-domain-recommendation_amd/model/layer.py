@@ -1,0 +1,384 @@
+"""Layer library of the multi-domain CTR models, MI355X-native.
+
+Same class names, constructor arguments, parameter names (state_dict keys) and forward() conventions
+as the reference's model/layer.py, but no ATen compute: every forward() describes its dataflow to a
+static launch plan (plan.py) whose steps are the hand-written gfx950 kernels behind include/cdcmdr.h.
+
+Reference citations (file:line under the reference repository):
+  BaseModel                model/layer.py:10-112
+  FeaturesLinear           model/layer.py:115-126
+  FeaturesEmbedding        model/layer.py:129-157
+  MultiLayerPerceptron     model/layer.py:178-206
+  DNN                      model/layer.py:209-300
+  CrossNetwork             model/layer.py:303-329
+  CrossNetV2 / CrossNetMix model/layer.py:332-407
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import plan as P
+from ..functional import PlanCache, PlanHolder
+
+
+class HipModule(nn.Module):
+    """Common plumbing: arithmetic precision of the MFMA contractions and the plan cache."""
+
+    precision = "bf16"      # "bf16": bf16 MFMA operands / fp32 accumulate;  "f32": exact fp32 MFMA
+
+    def _cache(self):
+        c = self.__dict__.get("_plan_cache")
+        if c is None:
+            c = PlanCache()
+            self.__dict__["_plan_cache"] = c
+        return c
+
+    def set_precision(self, precision):
+        assert precision in ("bf16", "f32")
+        for m in self.modules():
+            if isinstance(m, HipModule):
+                m.precision = precision
+                m._cache().clear()
+        return self
+
+    def _new_plan(self, B, device, seed=0):
+        return P.Plan(device, B, precision=self.precision, training=self.training,
+                      dropout=float(getattr(self, "dropout_p", 0.0)), seed=seed)
+
+
+# --------------------------------------------------------------------------------------------------
+# embedding + wide term
+# --------------------------------------------------------------------------------------------------
+class FeaturesEmbedding(HipModule):
+    """One flat table for all fields; forward adds the per-field offsets in x's dtype (int32) and gathers.
+    Reference: model/layer.py:129-157."""
+
+    def __init__(self, field_dims, embed_dim):
+        super().__init__()
+        self.field_num = len(field_dims)
+        self.output_dim0 = self.field_num
+        self.embed_dim = embed_dim
+        total = int(np.sum(np.asarray(field_dims, dtype=np.int64)))
+        self.embedding_dict = nn.Embedding(total, embed_dim)          # N(0,1) init, as the reference
+        self.offsets = np.array((0, *np.cumsum(np.asarray(field_dims, dtype=np.int64))[:-1]), dtype=np.longlong)
+
+    def offsets_device(self, device):
+        cached = self.__dict__.get("_offsets_dev")
+        if cached is None or cached.device != torch.device(device):
+            # x.new_tensor(offsets) in the reference takes x's dtype: int32 (wrapping on overflow)
+            cached = torch.from_numpy(self.offsets.astype(np.int64)).to(torch.int32).to(device)
+            self.__dict__["_offsets_dev"] = cached
+        return cached
+
+    def describe(self, plan):
+        table = self.embedding_dict.weight
+        return P.EmbedGather(plan, table, self.offsets_device(table.device), self.field_num, self.embed_dim)
+
+    def forward(self, x, squeeze_dim=False):
+        B = x.shape[0]
+        dev = self.embedding_dict.weight.device
+
+        def build():
+            plan = self._new_plan(B, dev)
+            op = self.describe(plan)
+            plan.finalize([op.out])
+            return PlanHolder(plan, [op.ids], [op.out], emb_op=op)
+
+        holder = self._cache().get(self, "emb", B, build)
+        out = holder.run(x.to(torch.int32))
+        return out if squeeze_dim else out.view(B, self.field_num, self.embed_dim)
+
+
+class FeaturesLinear(HipModule):
+    """Wide term: one output unit over the flattened embeddings. Reference: model/layer.py:115-126."""
+
+    def __init__(self, field_dims, output_dim=1, sigmoid=False):
+        super().__init__()
+        if output_dim != 1:
+            raise NotImplementedError("the reference only ever builds FeaturesLinear with output_dim=1")
+        self.fc = nn.Linear(field_dims, output_dim, bias=True)
+        self.sigmoid = sigmoid
+
+    def describe(self, plan, x, out=None, addends=()):
+        op = P.RowDot(plan, [{"x": x, "w": self.fc.weight, "b": self.fc.bias, "out": out}], addends=addends,
+                      sigmoid=self.sigmoid)
+        return op.outs[0]
+
+    def forward(self, x):
+        return _run_float_module(self, "lin", x, lambda plan, xb: [self.describe(plan, xb)])
+
+
+def _run_float_module(mod, tag, x, describe):
+    """Standalone forward of a layer module on a float input [B, K]."""
+    B, K = x.shape
+    dev = x.device
+
+    def build():
+        plan = mod._new_plan(B, dev)
+        xb = plan.new(K)
+        outs = describe(plan, xb)
+        plan.finalize(outs)
+        return PlanHolder(plan, [xb], outs)
+
+    holder = mod._cache().get(mod, (tag, K), B, build)
+    return holder.run(x.contiguous().float())
+
+
+# --------------------------------------------------------------------------------------------------
+# MLPs
+# --------------------------------------------------------------------------------------------------
+class MultiLayerPerceptron(HipModule):
+    """[Linear, (BatchNorm1d), ReLU, Dropout] x n (+ Linear -> 1). BatchNorm is skipped for a batch of one row.
+    Reference: model/layer.py:178-206 (module order inside `layers` fixes the state_dict indices)."""
+
+    def __init__(self, input_dim, layer_dims, dropout, output_layer=True, bn=True):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        self.use_bn = bn
+        self.dropout_p = float(dropout)
+        self.hidden = []                   # (linear, bn or None) per hidden layer
+        for layer_dim in layer_dims:
+            lin = nn.Linear(input_dim, layer_dim)
+            self.layers.append(lin)
+            norm = None
+            if bn:
+                norm = nn.BatchNorm1d(layer_dim)
+                self.layers.append(norm)
+            self.layers.append(nn.ReLU())
+            self.layers.append(nn.Dropout(p=dropout))
+            self.hidden.append((lin, norm))
+            input_dim = layer_dim
+        self.out_linear = None
+        if output_layer:
+            lin = nn.Linear(input_dim, 1)
+            self.layers.append(lin)
+            self.__dict__["out_linear"] = lin     # alias only: parameters are registered under `layers`
+
+    def describe(self, plan, x):
+        outs, _ = mlp_stack(plan, [self], [x])
+        return outs[0]
+
+    def forward(self, x):
+        return _run_float_module(self, "mlp", x, lambda plan, xb: [self.describe(plan, xb)])
+
+
+def _bn_seg(x, norm, out=None, row_group=0):
+    return {"x": x, "out": out, "gamma": norm.weight, "beta": norm.bias, "gamma_param": norm.weight,
+            "beta_param": norm.bias, "running_mean": norm.running_mean, "running_var": norm.running_var,
+            "num_batches_tracked": norm.num_batches_tracked, "row_group": row_group}
+
+
+def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmoid=False, final_outs=None):
+    """Runs structurally identical MultiLayerPerceptrons side by side: one grouped-linear launch (and one
+    BatchNorm launch) per layer depth for all of them.
+
+    extra_groups: extra linear groups (dicts x/w/b/out) riding in the first launch (gates).
+    Returns (outputs per mlp, outputs of the extra groups)."""
+    n = len(mlps)
+    cur = list(inputs)
+    extra_outs = []
+    depth = len(mlps[0].hidden)
+    if depth == 0 and extra_groups:
+        op = P.GLinear(plan, [dict(g) for g in extra_groups])
+        extra_outs = op.outs
+    for j in range(depth):
+        width = mlps[0].hidden[j][0].out_features
+        use_bn = mlps[0].use_bn
+        pre = plan.new(n * width)
+        groups = []
+        for i, m in enumerate(mlps):
+            lin = m.hidden[j][0]
+            groups.append({"x": cur[i], "w": lin.weight, "b": lin.bias, "out": pre.slice(i * width, (i + 1) * width)})
+        n_extra = 0
+        if j == 0 and extra_groups:
+            for g in extra_groups:
+                g = dict(g)
+                g["act_cols"] = 0
+                groups.append(g)
+                n_extra += 1
+        if use_bn:
+            op = P.GLinear(plan, groups, relu=False, dropout=False)
+            post = plan.new(n * width)
+            segs = [_bn_seg(pre.slice(i * width, (i + 1) * width), m.hidden[j][1], out=post.slice(i * width, (i + 1) * width))
+                    for i, m in enumerate(mlps)]
+            P.BatchNorm(plan, segs, relu=True, dropout=True)
+            cur = [post.slice(i * width, (i + 1) * width) for i in range(n)]
+        else:
+            op = P.GLinear(plan, groups, relu=True, dropout=True)
+            cur = [op.outs[i] for i in range(n)]
+        if n_extra:
+            extra_outs = op.outs[n:]
+    if mlps[0].out_linear is not None:
+        groups = []
+        for i, m in enumerate(mlps):
+            lin = m.out_linear
+            groups.append({"x": cur[i], "w": lin.weight, "b": lin.bias,
+                           "out": None if final_outs is None else final_outs[i]})
+        op = P.RowDot(plan, groups, addends=final_addends, sigmoid=final_sigmoid)
+        cur = op.outs
+    return cur, extra_outs
+
+
+def activation_layer(act_name):
+    """Reference: model/layer.py:209-238 (DeepCTR-style activation factory)."""
+    if isinstance(act_name, str):
+        name = act_name.lower()
+        if name == "sigmoid":
+            return nn.Sigmoid()
+        if name == "linear":
+            return nn.Identity()
+        if name == "relu":
+            return nn.ReLU(inplace=True)
+        if name == "prelu":
+            return nn.PReLU()
+        raise NotImplementedError(act_name)
+    if isinstance(act_name, type) and issubclass(act_name, nn.Module):
+        return act_name()
+    raise NotImplementedError
+
+
+class DNN(HipModule):
+    """DeepCTR-style MLP with separate `linears` / `bn` / `activation_layers` lists (used by STAR).
+    Reference: model/layer.py:241-300."""
+
+    def __init__(self, inputs_dim, hidden_units, activation="relu", dropout_rate=0, use_bn=True):
+        super().__init__()
+        if len(hidden_units) == 0:
+            raise ValueError("hidden_units is empty!!")
+        if str(activation).lower() != "relu":
+            raise NotImplementedError("the HIP path implements the relu DNN the reference models use")
+        self.dropout_rate = dropout_rate
+        self.dropout_p = float(dropout_rate)
+        self.dropout = nn.Dropout(dropout_rate)
+        self.use_bn = use_bn
+        dims = [inputs_dim] + list(hidden_units)
+        self.linears = nn.ModuleList([nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)])
+        if self.use_bn:
+            self.bn = nn.ModuleList([nn.BatchNorm1d(dims[i + 1]) for i in range(len(dims) - 1)])
+        self.activation_layers = nn.ModuleList([activation_layer(activation) for _ in range(len(dims) - 1)])
+
+    def describe(self, plan, x):
+        cur = x
+        for i, lin in enumerate(self.linears):
+            if self.use_bn:
+                op = P.GLinear(plan, [{"x": cur, "w": lin.weight, "b": lin.bias}])
+                bn = P.BatchNorm(plan, [_bn_seg(op.outs[0], self.bn[i])], relu=True, dropout=True)
+                cur = bn.outs[0]
+            else:
+                op = P.GLinear(plan, [{"x": cur, "w": lin.weight, "b": lin.bias}], relu=True, dropout=True)
+                cur = op.outs[0]
+        return cur
+
+    def forward(self, inputs):
+        return _run_float_module(self, "dnn", inputs, lambda plan, xb: [self.describe(plan, xb)])
+
+
+# --------------------------------------------------------------------------------------------------
+# cross networks
+# --------------------------------------------------------------------------------------------------
+class CrossNetwork(HipModule):
+    """DCN-v1: x_{l+1} = x0 * (x_l . w_l) + b_l + x_l.  Reference: model/layer.py:303-329."""
+
+    def __init__(self, input_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        self.w = nn.ModuleList([nn.Linear(input_dim, 1, bias=False) for _ in range(num_layers)])
+        self.b = nn.ParameterList([nn.Parameter(torch.zeros((input_dim,))) for _ in range(num_layers)])
+
+    def describe(self, plan, x0, out=None):
+        cur = x0
+        for i in range(self.num_layers):
+            last = i == self.num_layers - 1
+            dst = out if (last and out is not None) else None
+            op = P.CrossLayer(plan, x0, cur, self.w[i].weight, self.b[i], out=dst)
+            cur = op.out
+        return cur
+
+    def forward(self, x):
+        return _run_float_module(self, "cross", x, lambda plan, xb: [self.describe(plan, xb)])
+
+
+# --------------------------------------------------------------------------------------------------
+# BaseModel
+# --------------------------------------------------------------------------------------------------
+class BaseModel(HipModule):
+    """Embedding + wide term + regularisation registry + tower helpers shared by every model.
+    Reference: model/layer.py:10-112."""
+
+    def __init__(self, feature_dims, embed_dim, l2_reg_embedding=1e-5, l2_reg_linear=1e-5):
+        super().__init__()
+        self.feature_dims = feature_dims
+        self.embedding = FeaturesEmbedding(feature_dims, embed_dim)
+        self.embed_output_dim = self.embedding.output_dim0 * embed_dim
+        self.embed_dim = embed_dim
+        self.field_num = self.embedding.field_num
+        self.linear = FeaturesLinear(self.embed_output_dim)
+        self.is_concat_linear_cn = None
+        self.reg_loss = torch.zeros((1,))
+        self.regularization_weight = []
+        self.add_regularization_weight(self.embedding.embedding_dict.parameters(), l2=l2_reg_embedding)
+        self.add_regularization_weight(_reg_filter(self.linear), l2=l2_reg_linear)
+
+    # ---- regularisation (model/layer.py:86-112) ----------------------------------------------------
+    def add_regularization_weight(self, weight_list, l1=0.0, l2=0.0):
+        if isinstance(weight_list, torch.nn.parameter.Parameter):
+            weight_list = [weight_list]
+        else:
+            weight_list = list(weight_list)
+        self.regularization_weight.append((weight_list, l1, l2))
+
+    def regularized_parameters(self):
+        """[(parameter, l1, l2)] over the registry, (name, parameter) tuples unwrapped."""
+        out = []
+        for weight_list, l1, l2 in self.regularization_weight:
+            for w in weight_list:
+                out.append((w[1] if isinstance(w, tuple) else w, l1, l2))
+        return out
+
+    def get_regularization_loss(self, device):
+        """sum over the registry of l1*|w| + l2*w^2, shape (1,), differentiable (run.py:489 adds it to the loss).
+        Drop-in path only: the fused trainer folds the same term into its optimiser kernels."""
+        total = torch.zeros((1,), device=device)
+        for p, l1, l2 in self.regularized_parameters():
+            if l1 > 0:
+                total = total + torch.sum(l1 * torch.abs(p))
+            if l2 > 0:
+                total = total + torch.sum(l2 * torch.square(p))
+        return total
+
+    # ---- towers (model/layer.py:35-56) ---------------------------------------------------------------
+    def build_tower_output(self, n_tower, tower_input_dim, tower_dims, dropout):
+        towers = nn.ModuleList(
+            MultiLayerPerceptron(tower_input_dim, tower_dims, dropout, output_layer=True) for _ in range(self.n_tower))
+        output_layers = nn.ModuleList([nn.Sigmoid() for _ in range(n_tower)])
+        return towers, None, output_layers
+
+    def describe_towers(self, plan, tower_inputs, other_outs, out):
+        """tower MLP -> `+= other` for every other logit -> sigmoid -> column i of `out` [B, n_tower]."""
+        finals = [out.slice(i, i + 1) for i in range(len(self.towers))]
+        mlp_stack(plan, list(self.towers), tower_inputs, final_addends=other_outs, final_sigmoid=True, final_outs=finals)
+        return out
+
+    def build_atten(self, config, dropout):
+        raise NotImplementedError("the attention branch (use_atten=True, model/layer.py:58-84) is not on the HIP path yet; "
+                                  "construct the model with config.use_atten = False")
+
+    # ---- plan plumbing for whole models ----------------------------------------------------------------
+    def plan_holder(self, B, tag="fwd", **kw):
+        """The (cached) plan of this model at batch size B in its current train/eval mode."""
+        dev = self.embedding.embedding_dict.weight.device
+
+        def build():
+            plan = self._new_plan(B, dev, seed=int(getattr(self, "seed", 0)))
+            emb = self.embedding.describe(plan)
+            outs, ins, extra = self.describe(plan, emb, **kw)
+            plan.finalize(outs)
+            return PlanHolder(plan, [emb.ids] + ins, outs, emb_op=emb, extra_outputs=extra)
+
+        return self._cache().get(self, (tag, tuple(sorted(kw.items()))), B, build)
+
+
+def _reg_filter(module):
+    """named parameters whose name has 'weight' and not 'bn' — the reference's filter (e.g. model/ple.py:42-45).
+    BatchNorm gammas inside MultiLayerPerceptron are named layers.N.weight and therefore ARE regularised."""
+    return [(n, p) for n, p in module.named_parameters() if "weight" in n and "bn" not in n]

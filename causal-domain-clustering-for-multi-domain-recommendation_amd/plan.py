@@ -1,0 +1,688 @@
+"""Static launch plans: the forward and backward kernel sequences of one model at one batch size.
+
+A plan owns every activation / gradient buffer (allocated once through torch's caching allocator) and
+every pre-filled C-ABI argument block, so running it is nothing but a fixed list of asynchronous
+launches on the current HIP stream — the whole step is hipGraph-capturable and costs no Python work
+per element.  The model classes in model/ describe their dataflow with the small builder below; the
+reference does the same work through eager ATen ops and autograd (model/layer.py, ple.py, mmoe.py, ...).
+
+Gradient conventions
+  * `Buf.grad` of a buffer produced by a linear layer with a fused activation (relu / dropout) holds
+    the gradient w.r.t. the PRE-activation value: consumers apply the producer's mask while writing
+    (glinear_bwd_x / gate_pool_bwd epilogues), so no separate mask pass exists.
+  * a BatchNorm output's grad is w.r.t. its post-activation value (bn_bwd applies its own mask).
+  * several consumers of one buffer accumulate: the first writer (in backward order) stores, later
+    ones add; the builder works the flags out when the plan is finalised.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Buf:
+    """fp32 2-D view [rows, cols] with row stride `ld` (elements) inside a root tensor."""
+
+    def __init__(self, root, rows, cols, ld=None, col0=0, plan=None):
+        self.root = root                  # torch tensor [rows, ld_root]
+        self.rows = rows
+        self.cols = cols
+        self.ld = ld if ld is not None else root.stride(0)
+        self.col0 = col0
+        self.plan = plan
+        self.mask = None                  # (scale, n_cols): relu/dropout fused into the producer covers cols [0,n_cols)
+        self.is_param_like = False
+
+    @property
+    def ptr(self):
+        return self.root.data_ptr() + 4 * self.col0
+
+    def cptr(self):
+        return C.c_void_p(self.ptr)
+
+    def slice(self, c0, c1):
+        b = Buf(self.root, self.rows, c1 - c0, self.ld, self.col0 + c0, self.plan)
+        if self.mask is not None:
+            scale, act_cols = self.mask
+            if c0 < act_cols:
+                b.mask = (scale, min(act_cols, c1) - c0)
+        return b
+
+    def tensor(self):
+        return self.root[:, self.col0:self.col0 + self.cols]
+
+    # ---- gradient view (same geometry inside the root's gradient tensor) ----
+    @property
+    def grad(self):
+        g = self.plan._root_grad(self.root)
+        return Buf(g, self.rows, self.cols, g.stride(0), self.col0, self.plan)
+
+
+class _GradState:
+    """Tracks which column intervals of a root gradient tensor the backward sequence has initialised."""
+
+    def __init__(self):
+        self.done = {}      # id(root) -> list of (c0, c1)
+
+    def claim(self, buf):
+        """Returns True if `buf`'s gradient region is already initialised (=> accumulate), else marks it."""
+        key = id(buf.root)
+        iv = self.done.setdefault(key, [])
+        c0, c1 = buf.col0, buf.col0 + buf.cols
+        for a, b in iv:
+            if a <= c0 and c1 <= b:
+                return True
+        for a, b in iv:
+            if not (c1 <= a or b <= c0):
+                raise RuntimeError(f"partial gradient overlap on a buffer: [{c0},{c1}) vs [{a},{b})")
+        iv.append((c0, c1))
+        return False
+
+    def is_set(self, buf):
+        c0, c1 = buf.col0, buf.col0 + buf.cols
+        return any(a <= c0 and c1 <= b for a, b in self.done.get(id(buf.root), []))
+
+
+class Plan:
+    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0):
+        assert precision in ("bf16", "f32")
+        self.lib = L.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.HipExtensionError("the HIP hot path needs a GPU device (got %s); there is no CPU fallback" % device)
+        self.B = B
+        self.prec = L.PREC_BF16 if precision == "bf16" else L.PREC_F32
+        self.training = training
+        self.dropout = float(dropout) if training else 0.0
+        self.keep_scale = 1.0 / (1.0 - self.dropout) if self.dropout > 0 else 1.0
+        self.seed = seed
+        self.ops = []
+        self.fwd_steps = []
+        self.bwd_steps = []
+        self._grads = {}                  # id(root) -> grad tensor
+        self._roots = {}
+        self.param_grads = {}             # id(param) -> grad tensor
+        self._param_refs = {}
+        self._param_grad_set = set()
+        self._op_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # dropout stream offset
+        self._bn_ws = None
+        self._bn_ws_need = 0
+        self._rowdot_ws = None
+        self._rowdot_ws_need = 0
+        self.finalized = False
+        self.loss_inputs = None
+
+    # ---------------------------------------------------------------- buffers
+    def new(self, cols, rows=None, dtype=torch.float32):
+        rows = self.B if rows is None else rows
+        t = torch.empty((rows, cols), dtype=dtype, device=self.device)
+        self._roots[id(t)] = t
+        return Buf(t, rows, cols, plan=self)
+
+    def _root_grad(self, root):
+        g = self._grads.get(id(root))
+        if g is None:
+            g = torch.zeros_like(root)
+            self._grads[id(root)] = g
+            self._roots[id(root)] = root
+        return g
+
+    def param_grad(self, p):
+        g = self.param_grads.get(id(p))
+        if g is None:
+            g = torch.zeros_like(p.data)
+            self.param_grads[id(p)] = g
+            self._param_refs[id(p)] = p
+        return g
+
+    def ensure_grad(self, buf, gs):
+        """Make sure buf.grad is initialised in the backward sequence (zero it if nobody wrote it)."""
+        if not gs.is_set(buf):
+            t = buf.grad.tensor()
+            self.bwd_steps.append(lambda s, t=t: t.zero_())
+            gs.claim(buf)
+
+    def _claim_param(self, p):
+        if id(p) in self._param_grad_set:
+            return True
+        self._param_grad_set.add(id(p))
+        return False
+
+    def _next_seed(self):
+        self._op_count += 1
+        return (self.seed * 1000003 + self._op_count * 7919) & 0xFFFFFFFFFFFFFFFF
+
+    def need_bn_ws(self, rows, total_c):
+        self._bn_ws_need = max(self._bn_ws_need, 2 * math.ceil(rows / L.BN_ROWS_PER_BLOCK) * total_c)
+
+    def need_rowdot_ws(self, n):
+        self._rowdot_ws_need = max(self._rowdot_ws_need, n)
+
+    # ---------------------------------------------------------------- ops
+    def add(self, op):
+        self.ops.append(op)
+        return op
+
+    def finalize(self, outputs):
+        """outputs: list of Bufs whose .grad the caller seeds before backward()."""
+        self._bn_ws = torch.empty(max(self._bn_ws_need, 1), dtype=torch.float64, device=self.device)
+        self._rowdot_ws = torch.empty(max(self._rowdot_ws_need, 1), dtype=torch.float32, device=self.device)
+        gs = _GradState()
+        for o in outputs:
+            gs.claim(o)
+            _ = o.grad
+        self.outputs = outputs
+        for op in self.ops:
+            op.build_fwd(self)
+        for op in reversed(self.ops):
+            op.build_bwd(self, gs)
+        self.finalized = True
+
+    def forward(self):
+        s = _stream()
+        for fn in self.fwd_steps:
+            fn(s)
+
+    def backward(self):
+        s = _stream()
+        for fn in self.bwd_steps:
+            fn(s)
+
+    def call(self, fn_name, *args, what=None):
+        fn = getattr(self.lib, fn_name)
+        what = what or fn_name
+
+        def run(stream):
+            rc = fn(*args, stream)
+            if rc != 0:
+                L.check(rc, what)
+        return run
+
+
+# ======================================================================================================
+# ops
+# ======================================================================================================
+class EmbedGather:
+    """model/layer.py:147-157 FeaturesEmbedding.forward(squeeze_dim=True)."""
+
+    def __init__(self, plan, table, offsets_i32, n_fields, dim):
+        self.table = table                  # Parameter [R, D]
+        self.offsets = offsets_i32          # device int32 [F]
+        self.F, self.D = n_fields, dim
+        self.ids = torch.zeros((plan.B, n_fields), dtype=torch.int32, device=plan.device)
+        self.idx = torch.empty((plan.B, n_fields), dtype=torch.int32, device=plan.device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=plan.device)
+        self.out = plan.new(n_fields * dim)
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        R = self.table.shape[0]
+        plan.fwd_steps.append(plan.call("cdc_embed_gather_fwd", _p(self.ids), _p(self.offsets), _p(self.table.data),
+                                        self.out.cptr(), _p(self.idx), _p(self.err), C.c_int64(plan.B), self.F, self.D,
+                                        C.c_int64(R)))
+
+    def build_bwd(self, plan, gs):
+        # the gradient w.r.t. the gathered rows stays in self.out.grad; the table optimiser (optim.py) or the
+        # drop-in dense-gradient path (functional.py) consumes it together with self.idx.
+        if not gs.is_set(self.out):
+            g = self.out.grad
+            plan.bwd_steps.append(plan.call("cdc_fill_f32", g.cptr(), C.c_float(0.0), C.c_int64(g.rows * g.ld)))
+
+
+class GLinear:
+    """Several nn.Linear layers (optionally + ReLU + dropout) in one launch.
+
+    groups: list of dicts {x: Buf, w: Parameter [N,K], b: Parameter [N] or None, act_cols: int or None}.
+    Outputs are carved out of `out` buffers given per group (Buf [B, N]) or freshly allocated.
+    """
+
+    def __init__(self, plan, groups, relu=False, dropout=False, row_offsets=None, M=None):
+        self.groups = groups
+        self.relu = relu
+        self.drop_p = plan.dropout if dropout else 0.0
+        self.row_offsets = row_offsets
+        self.M = plan.B if M is None else M
+        self.seed = plan._next_seed()
+        self.outs = []
+        for g in groups:
+            N, K = g["w"].shape
+            assert g["x"].cols == K, f"linear input has {g['x'].cols} columns, weight expects {K}"
+            y = g.get("out")
+            if y is None:
+                y = plan.new(N, rows=g["x"].rows)
+            assert y.cols == N
+            act_cols = g.get("act_cols")
+            act_cols = N if act_cols is None else act_cols
+            g["act_cols"] = act_cols if (relu or self.drop_p > 0) else 0
+            if g["act_cols"] > 0:
+                y.mask = (plan.keep_scale if self.drop_p > 0 else 1.0, g["act_cols"])
+            g["y"] = y
+            self.outs.append(y)
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        for c0 in range(0, len(self.groups), L.MAX_GROUPS):
+            chunk = self.groups[c0:c0 + L.MAX_GROUPS]
+            a = L.LinFwdArgs()
+            a.n_groups = len(chunk)
+            a.relu = 1 if self.relu else 0
+            a.drop_p = self.drop_p
+            a.seed = (self.seed + c0) & 0xFFFFFFFFFFFFFFFF
+            a.seed_offset_dev = plan.step_dev.data_ptr()
+            a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr() + 4 * c0
+            for i, g in enumerate(chunk):
+                G = a.g[i]
+                N, K = g["w"].shape
+                G.x, G.ldx = g["x"].ptr, g["x"].ld
+                G.w, G.ldw = g["w"].data_ptr(), K
+                G.bias = None if g.get("b") is None else g["b"].data_ptr()
+                G.y, G.ldy = g["y"].ptr, g["y"].ld
+                G.M, G.N, G.K = self.M, N, K
+                G.act_cols = g["act_cols"]
+            self._keep = getattr(self, "_keep", []) + [a]
+            plan.fwd_steps.append(plan.call("cdc_glinear_fwd", C.byref(a), plan.prec))
+
+    def build_bwd(self, plan, gs):
+        # dZ of every group lives in y.grad (pre-activation gradient, see module docstring)
+        for g in self.groups:
+            plan.ensure_grad(g["y"], gs)
+        # ---- grad-weight / grad-bias
+        for c0 in range(0, len(self.groups), L.MAX_GROUPS):
+            chunk = self.groups[c0:c0 + L.MAX_GROUPS]
+            a = L.LinBwdwArgs()
+            a.n_groups = len(chunk)
+            a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr() + 4 * c0
+            for i, g in enumerate(chunk):
+                G = a.g[i]
+                N, K = g["w"].shape
+                dz = g["y"].grad
+                G.dz, G.lddz = dz.ptr, dz.ld
+                G.x, G.ldx = g["x"].ptr, g["x"].ld
+                gw = plan.param_grad(g["w"])
+                acc_w = plan._claim_param(g["w"])
+                G.dw, G.lddw = gw.data_ptr(), K
+                if g.get("b") is not None:
+                    gb = plan.param_grad(g["b"])
+                    acc_b = plan._claim_param(g["b"])
+                    assert acc_b == acc_w
+                    G.db = gb.data_ptr()
+                else:
+                    G.db = None
+                G.M, G.N, G.K = self.M, N, K
+                G.accumulate = 1 if acc_w else 0
+            self._keep.append(a)
+            plan.bwd_steps.append(plan.call("cdc_glinear_bwd_w", C.byref(a), plan.prec))
+        # ---- grad-input: groups reading the same x reduce into one output
+        outs = []      # list of (x Buf, [group indices])
+        for gi, g in enumerate(self.groups):
+            if g.get("no_dx"):
+                continue
+            x = g["x"]
+            for o in outs:
+                if o[0].root is x.root and o[0].col0 == x.col0 and o[0].cols == x.cols:
+                    o[1].append(gi)
+                    break
+            else:
+                outs.append((x, [gi]))
+        # pack outputs into launches of <= MAX_GROUPS outputs / segments
+        launches, cur_o, cur_s = [], [], 0
+        for o in outs:
+            if len(o[1]) > L.MAX_GROUPS:
+                raise RuntimeError("more than %d linear groups share one input" % L.MAX_GROUPS)
+            if cur_o and (len(cur_o) + 1 > L.MAX_GROUPS or cur_s + len(o[1]) > L.MAX_GROUPS):
+                launches.append(cur_o)
+                cur_o, cur_s = [], 0
+            cur_o.append(o)
+            cur_s += len(o[1])
+        if cur_o:
+            launches.append(cur_o)
+        if self.row_offsets is not None:
+            # ragged rows: outputs must line up one-to-one with the row groups
+            assert all(len(o[1]) == 1 for o in outs), "ragged linear groups cannot share an input"
+        for la in launches:
+            # all outputs of one launch share the mask scale (one plan-wide dropout rate)
+            a = L.LinBwdxArgs()
+            a.n_out = len(la)
+            a.mask_scale = 1.0
+            si = 0
+            first_group = la[0][1][0]
+            a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr() + 4 * first_group
+            for oi, (x, gis) in enumerate(la):
+                O = a.o[oi]
+                xg = x.grad
+                O.dx, O.lddx = xg.ptr, xg.ld
+                if x.mask is not None:
+                    O.mask_y, O.ldmask = x.ptr, x.ld
+                    O.mask_cols = min(x.mask[1], x.cols)
+                    a.mask_scale = x.mask[0]
+                else:
+                    O.mask_y = None
+                    O.mask_cols = 0
+                O.M, O.K = self.M, x.cols
+                O.accumulate = 1 if gs.claim(x) else 0
+                for gi in gis:
+                    g = self.groups[gi]
+                    S = a.s[si]
+                    dz = g["y"].grad
+                    S.dz, S.lddz = dz.ptr, dz.ld
+                    S.w, S.ldw = g["w"].data_ptr(), g["w"].shape[1]
+                    S.N = g["w"].shape[0]
+                    S.out = oi
+                    si += 1
+            a.n_seg = si
+            self._keep.append(a)
+            plan.bwd_steps.append(plan.call("cdc_glinear_bwd_x", C.byref(a), plan.prec))
+
+
+class GatePool:
+    """softmax gates + weighted expert pooling (model/ple.py:105-123, model/mmoe.py:58-60).
+
+    experts: Buf [B, n_expert*H]; gates: list of (logits Buf [B, n_sel], sel list[int]).
+    """
+
+    def __init__(self, plan, experts, n_expert, H, gates, outs=None):
+        assert experts.cols == n_expert * H
+        self.experts, self.n_expert, self.H = experts, n_expert, H
+        self.gates = gates
+        self.outs = outs if outs is not None else [plan.new(H) for _ in gates]
+        self.probs = [torch.empty((plan.B, len(sel)), dtype=torch.float32, device=plan.device) for _, sel in gates]
+        for _, sel in gates:
+            if len(sel) > L.MAX_SEL:
+                raise RuntimeError(f"a gate mixes {len(sel)} experts; the pooling kernel supports {L.MAX_SEL}")
+        self._keep = []
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        for c0 in range(0, len(self.gates), L.MAX_GATES):
+            a = L.PoolFwdArgs()
+            chunk = self.gates[c0:c0 + L.MAX_GATES]
+            a.n_gates, a.n_expert, a.H, a.B = len(chunk), self.n_expert, self.H, plan.B
+            a.experts, a.ld_exp = self.experts.ptr, self.experts.ld
+            for i, (lg, sel) in enumerate(chunk):
+                G = a.gate[i]
+                G.logits, G.ld_logits = lg.ptr, lg.ld
+                G.out, G.ld_out = self.outs[c0 + i].ptr, self.outs[c0 + i].ld
+                G.probs = self.probs[c0 + i].data_ptr()
+                G.n_sel = len(sel)
+                for j, e in enumerate(sel):
+                    G.sel[j] = e
+            self._keep.append(a)
+            plan.fwd_steps.append(plan.call("cdc_gate_pool_fwd", C.byref(a)))
+
+    def build_bwd(self, plan, gs):
+        acc = gs.claim(self.experts)
+        for c0 in range(0, len(self.gates), L.MAX_GATES):
+            a = L.PoolBwdArgs()
+            chunk = self.gates[c0:c0 + L.MAX_GATES]
+            a.n_gates, a.n_expert, a.H, a.B = len(chunk), self.n_expert, self.H, plan.B
+            a.experts, a.ld_exp = self.experts.ptr, self.experts.ld
+            eg = self.experts.grad
+            a.d_experts, a.ld_dexp = eg.ptr, eg.ld
+            if self.experts.mask is not None:
+                assert self.experts.mask[1] >= self.experts.cols, "expert buffer is only partly activation-masked"
+                a.mask_relu, a.mask_scale = 1, self.experts.mask[0]
+            else:
+                a.mask_relu, a.mask_scale = 0, 1.0
+            a.accumulate = 1 if (acc or c0 > 0) else 0
+            for i, (lg, sel) in enumerate(chunk):
+                G = a.gate[i]
+                plan.ensure_grad(self.outs[c0 + i], gs)
+                og = self.outs[c0 + i].grad
+                G.d_out, G.ld_dout = og.ptr, og.ld
+                G.probs = self.probs[c0 + i].data_ptr()
+                lgg = lg.grad
+                if gs.claim(lg):
+                    raise RuntimeError("gate logits feed more than one consumer")
+                G.d_logits, G.ld_dlogits = lgg.ptr, lgg.ld
+                G.n_sel = len(sel)
+                for j, e in enumerate(sel):
+                    G.sel[j] = e
+            self._keep.append(a)
+            plan.bwd_steps.append(plan.call("cdc_gate_pool_bwd", C.byref(a)))
+
+
+class BatchNorm:
+    """BatchNorm1d (+ReLU, +dropout) over column segments sharing one launch.
+
+    segs: list of dicts {x: Buf, bn: module-like with weight/bias/running_mean/running_var/num_batches_tracked
+          (or explicit tensors gamma/beta), out: Buf or None, row_group: int}
+    """
+
+    def __init__(self, plan, segs, relu=True, dropout=True, eps=1e-5, momentum=0.1, row_offsets=None, M=None):
+        self.segs = segs
+        self.relu = relu
+        self.drop_p = plan.dropout if dropout else 0.0
+        self.eps, self.momentum = eps, momentum
+        self.row_offsets = row_offsets
+        self.M = plan.B if M is None else M
+        self.seed = plan._next_seed()
+        self.outs = []
+        total_c = 0
+        for s in segs:
+            Cn = s["x"].cols
+            y = s.get("out")
+            if y is None:
+                y = plan.new(Cn, rows=s["x"].rows)
+            s["y"] = y
+            s["save_mean"] = torch.zeros(Cn, dtype=torch.float32, device=plan.device)
+            s["save_invstd"] = torch.ones(Cn, dtype=torch.float32, device=plan.device)
+            self.outs.append(y)
+            total_c += Cn
+        self._keep = []
+        for c0 in range(0, len(segs), L.MAX_BN_SEGS):
+            plan.need_bn_ws(self.M, sum(s["x"].cols for s in segs[c0:c0 + L.MAX_BN_SEGS]))
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        for c0 in range(0, len(self.segs), L.MAX_BN_SEGS):
+            chunk = self.segs[c0:c0 + L.MAX_BN_SEGS]
+            a = L.BnFwdArgs()
+            a.n_seg, a.training, a.relu = len(chunk), 1 if plan.training else 0, 1 if self.relu else 0
+            a.eps, a.momentum, a.drop_p = self.eps, self.momentum, self.drop_p
+            a.seed, a.seed_offset_dev = (self.seed + c0) & 0xFFFFFFFFFFFFFFFF, plan.step_dev.data_ptr()
+            a.M = self.M
+            a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr()
+            a.workspace = plan._bn_ws.data_ptr()
+            for i, s in enumerate(chunk):
+                S = a.s[i]
+                S.x, S.ldx = s["x"].ptr, s["x"].ld
+                S.y, S.ldy = s["y"].ptr, s["y"].ld
+                S.gamma, S.beta = s["gamma"].data_ptr(), s["beta"].data_ptr()
+                S.running_mean, S.running_var = s["running_mean"].data_ptr(), s["running_var"].data_ptr()
+                S.save_mean, S.save_invstd = s["save_mean"].data_ptr(), s["save_invstd"].data_ptr()
+                nbt = s.get("num_batches_tracked")
+                S.num_batches_tracked = None if nbt is None else nbt.data_ptr()
+                S.C = s["x"].cols
+                S.row_group = s.get("row_group", 0)
+            self._keep.append(a)
+            plan.fwd_steps.append(plan.call("cdc_bn_fwd", C.byref(a)))
+
+    def build_bwd(self, plan, gs):
+        for c0 in range(0, len(self.segs), L.MAX_BN_SEGS):
+            chunk = self.segs[c0:c0 + L.MAX_BN_SEGS]
+            a = L.BnBwdArgs()
+            a.n_seg, a.training, a.relu = len(chunk), 1 if plan.training else 0, 1 if self.relu else 0
+            a.eps = self.eps
+            a.mask_scale = plan.keep_scale if self.drop_p > 0 else 1.0
+            a.M = self.M
+            a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr()
+            a.workspace = plan._bn_ws.data_ptr()
+            pre = []
+            for i, s in enumerate(chunk):
+                S = a.s[i]
+                plan.ensure_grad(s["y"], gs)
+                yg = s["y"].grad
+                S.dy, S.lddy = yg.ptr, yg.ld
+                S.y, S.ldy = s["y"].ptr, s["y"].ld
+                S.x, S.ldx = s["x"].ptr, s["x"].ld
+                xg = s["x"].grad
+                if gs.claim(s["x"]):
+                    raise RuntimeError("a BatchNorm input feeds more than one consumer")
+                S.dx, S.lddx = xg.ptr, xg.ld
+                S.gamma = s["gamma"].data_ptr()
+                if plan.training:
+                    S.save_mean, S.save_invstd = s["save_mean"].data_ptr(), s["save_invstd"].data_ptr()
+                else:
+                    inv = s["save_invstd"]
+                    rm, rv = s["running_mean"], s["running_var"]
+                    pre.append(lambda st, inv=inv, rv=rv, eps=self.eps: inv.copy_(torch.rsqrt(rv + eps)))
+                    S.save_mean, S.save_invstd = rm.data_ptr(), inv.data_ptr()
+                if s.get("gamma_param") is not None:
+                    gg, gb = plan.param_grad(s["gamma_param"]), plan.param_grad(s["beta_param"])
+                    if plan._claim_param(s["gamma_param"]) or plan._claim_param(s["beta_param"]):
+                        raise RuntimeError("BatchNorm parameters used twice in one plan")
+                    S.dgamma, S.dbeta = gg.data_ptr(), gb.data_ptr()
+                else:
+                    S.dgamma = None if s.get("dgamma") is None else s["dgamma"].data_ptr()
+                    S.dbeta = None if s.get("dbeta") is None else s["dbeta"].data_ptr()
+                S.C = s["x"].cols
+                S.row_group = s.get("row_group", 0)
+            self._keep.append(a)
+            plan.bwd_steps.extend(pre)
+            plan.bwd_steps.append(plan.call("cdc_bn_bwd", C.byref(a)))
+
+
+class RowDot:
+    """out[b] = sigmoid?(x[b,:]·w + bias + sum addends[b])  for several groups (towers) in one launch.
+
+    groups: list of dicts {x: Buf, w: Parameter [1,K] or [K], b: Parameter [1] or None, out: Buf [B,1]}
+    addends: list of Buf [B,1] added to every group's logit (model/layer.py:53-54 `y_logits += other`).
+    """
+
+    def __init__(self, plan, groups, addends=(), sigmoid=False, row_offsets=None, M=None):
+        self.groups, self.addends, self.sigmoid = groups, list(addends), sigmoid
+        self.row_offsets = row_offsets
+        self.M = plan.B if M is None else M
+        assert len(groups) <= L.MAX_GROUPS and len(self.addends) <= 4
+        kmax = 0
+        for g in groups:
+            K = g["w"].numel()
+            assert g["x"].cols == K
+            if g.get("out") is None:
+                g["out"] = plan.new(1, rows=g["x"].rows)
+            kmax = max(kmax, K)
+        self.kmax = kmax
+        self.outs = [g["out"] for g in groups]
+        plan.need_rowdot_ws(len(groups) * L.ROWDOT_PARTS * (kmax + 1))
+        if self.addends:
+            self.dlogit = [plan.new(1) for _ in groups]
+        self._keep = []
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        a = L.RowdotFwdArgs()
+        a.n_groups, a.sigmoid, a.n_addend, a.M = len(self.groups), 1 if self.sigmoid else 0, len(self.addends), self.M
+        a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr()
+        for i, ad in enumerate(self.addends):
+            a.addend[i], a.ld_addend[i] = ad.ptr, ad.ld
+        for i, g in enumerate(self.groups):
+            G = a.g[i]
+            G.x, G.ldx = g["x"].ptr, g["x"].ld
+            G.w = g["w"].data_ptr()
+            G.bias = None if g.get("b") is None else g["b"].data_ptr()
+            G.out, G.ld_out = g["out"].ptr, g["out"].ld
+            G.logit = None
+            G.K = g["w"].numel()
+        self._keep.append(a)
+        plan.fwd_steps.append(plan.call("cdc_rowdot_fwd", C.byref(a)))
+
+    def build_bwd(self, plan, gs):
+        a = L.RowdotBwdArgs()
+        a.n_groups, a.sigmoid, a.M = len(self.groups), 1 if self.sigmoid else 0, self.M
+        a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr()
+        a.workspace = plan._rowdot_ws.data_ptr()
+        post = []
+        for i, g in enumerate(self.groups):
+            G = a.g[i]
+            plan.ensure_grad(g["out"], gs)
+            og = g["out"].grad
+            G.dout, G.ld_dout = og.ptr, og.ld
+            G.out, G.ld_out = g["out"].ptr, g["out"].ld
+            G.x, G.ldx = g["x"].ptr, g["x"].ld
+            G.w = g["w"].data_ptr()
+            if g.get("no_dx"):
+                G.dx = None
+            else:
+                if g["x"].mask is not None:
+                    raise RuntimeError("rowdot cannot consume an activation-fused linear output")
+                xg = g["x"].grad
+                G.dx, G.lddx = xg.ptr, xg.ld
+                G.accumulate_dx = 1 if gs.claim(g["x"]) else 0
+            gw = plan.param_grad(g["w"])
+            if plan._claim_param(g["w"]):
+                raise RuntimeError("rowdot weight used twice in one plan")
+            G.dw = gw.data_ptr()
+            if g.get("b") is not None:
+                gb = plan.param_grad(g["b"])
+                plan._claim_param(g["b"])
+                G.dbias = gb.data_ptr()
+            else:
+                G.dbias = None
+            if self.addends:
+                G.dlogit, G.ld_dlogit = self.dlogit[i].ptr, self.dlogit[i].ld
+                for ad in self.addends:
+                    adg = ad.grad
+                    if gs.claim(ad):
+                        post.append(plan.call("cdc_add_inplace", adg.cptr(), C.c_int64(adg.ld), self.dlogit[i].cptr(),
+                                              C.c_int64(self.dlogit[i].ld), C.c_int64(self.M), 1))
+                    else:
+                        t_dst, t_src = adg.tensor(), self.dlogit[i].tensor()
+                        post.append(lambda st, d=t_dst, s_=t_src: d.copy_(s_))
+            else:
+                G.dlogit = None
+            G.K = g["w"].numel()
+        self._keep.append(a)
+        plan.bwd_steps.append(plan.call("cdc_rowdot_bwd", C.byref(a)))
+        plan.bwd_steps.extend(post)
+
+
+class CrossLayer:
+    """DCN-v1 cross layer (model/layer.py:321-329): out = x0 * (xl·w) + b + xl."""
+
+    def __init__(self, plan, x0, xl, w, b, out=None):
+        self.x0, self.xl, self.w, self.b = x0, xl, w, b
+        self.out = out if out is not None else plan.new(x0.cols)
+        self.xw = torch.empty(plan.B, dtype=torch.float32, device=plan.device)
+        self.ws = torch.empty(L.ROWDOT_PARTS * 2 * x0.cols, dtype=torch.float32, device=plan.device)
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        plan.fwd_steps.append(plan.call("cdc_cross_fwd", self.x0.cptr(), C.c_int64(self.x0.ld), self.xl.cptr(),
+                                        C.c_int64(self.xl.ld), _p(self.w.data), _p(self.b.data), self.out.cptr(),
+                                        C.c_int64(self.out.ld), _p(self.xw), C.c_int64(plan.B), self.x0.cols))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        og = self.out.grad
+        if self.x0.mask is not None or self.xl.mask is not None:
+            raise RuntimeError("a cross layer cannot consume an activation-fused linear output")
+        # d_x0 accumulates inside the kernel: its gradient region must exist first
+        plan.ensure_grad(self.x0, gs)
+        x0g = self.x0.grad
+        same = (self.xl.root is self.x0.root and self.xl.col0 == self.x0.col0)
+        if same:
+            dxl = plan.new(self.x0.cols)
+        else:
+            if gs.claim(self.xl):
+                raise RuntimeError("a cross layer input (x_l) feeds more than one consumer")
+            dxl = self.xl.grad
+        gw, gb = plan.param_grad(self.w), plan.param_grad(self.b)
+        plan._claim_param(self.w), plan._claim_param(self.b)
+        plan.bwd_steps.append(plan.call("cdc_cross_bwd", og.cptr(), C.c_int64(og.ld), self.x0.cptr(), C.c_int64(self.x0.ld),
+                                        self.xl.cptr(), C.c_int64(self.xl.ld), _p(self.w.data), _p(self.xw), x0g.cptr(),
+                                        C.c_int64(x0g.ld), dxl.cptr(), C.c_int64(dxl.ld), _p(gw), _p(gb), _p(self.ws),
+                                        C.c_int64(plan.B), self.x0.cols))
+        if same:
+            plan.bwd_steps.append(plan.call("cdc_add_inplace", x0g.cptr(), C.c_int64(x0g.ld), dxl.cptr(), C.c_int64(dxl.ld),
+                                            C.c_int64(plan.B), self.x0.cols))

@@ -1,0 +1,402 @@
+/*
+ * cdcmdr.h — C-ABI of the MI355X (gfx950) multi-domain CTR training hot path.
+ *
+ * The reference (Chrissie-Law/Causal-Domain-Clustering-for-Multi-Domain-Recommendation,
+ * 100 % eager PyTorch) has no FFI of its own; the seam it offers is the nn.Module
+ * surface of model/<name>.py.  Every entry point below replaces the ATen work done by one
+ * reference function on that path; the reference file:line it stands in for is cited
+ * per function.  The host-side mirror of the nn.Module surface (Python) binds these
+ * with ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - raw device pointers + explicit sizes; no torch types cross this boundary;
+ *   - the caller owns and pre-allocates every buffer; nothing here allocates, frees
+ *     or keeps state between calls;
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*);
+ *     no call synchronises the device, so every call is hipGraph-capturable;
+ *   - return value: 0 = ok, <0 = bad argument (CDC_E_*), >0 = hipError_t;
+ *     cdc_last_error() gives a thread-local message for the last non-zero return;
+ *   - all floating point storage is fp32.  `prec` selects the arithmetic of the
+ *     dense contractions: CDC_PREC_BF16 = bf16 MFMA operands / fp32 accumulate,
+ *     CDC_PREC_F32 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ */
+#ifndef CDCMDR_H
+#define CDCMDR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDC_ABI_VERSION 1
+
+#define CDC_E_BADARG   (-1)
+#define CDC_E_TOOBIG   (-2)
+#define CDC_E_ALIGN    (-3)
+
+#define CDC_PREC_BF16 0
+#define CDC_PREC_F32  1
+
+#define CDC_MAX_GROUPS 32   /* groups / segments per launch (descriptors travel as kernel arguments) */
+#define CDC_MAX_TENSORS 48  /* tensors per multi-tensor Adam launch */
+
+int cdc_abi_version(void);
+const char* cdc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding (reference: model/layer.py:129-157 FeaturesEmbedding; dense nn.Embedding grad +
+ * whole-table L2 + dense torch.optim.Adam: model/layer.py:31,96-112, run.py:489,720-721)
+ * ---------------------------------------------------------------------------------------- */
+
+/* model/layer.py:152-155 — idx = x + offsets computed in x's dtype (int32, wrapping),
+ * out[b, f*D:(f+1)*D] = table[idx[b,f], :].   ids [B,F] int32 row-major, offsets [F] int32.
+ * An idx outside [0,R) sets *err_flag (device int32, may be NULL) to 1+flat position and
+ * yields a zero row (the CPU reference raises IndexError).  idx_out (may be NULL) receives
+ * the int32 row indices. */
+int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, const float* table,
+                         float* out, int32_t* idx_out, int32_t* err_flag,
+                         int64_t B, int32_t F, int32_t D, int64_t R, void* stream);
+
+/* Per-field sort + dedupe of the row indices of one batch (rows of different fields never
+ * collide, so each field is sorted on its own in LDS).  B <= CDC_SORT_MAX_B.
+ *   idx       [B,F] int32 row indices (from cdc_embed_gather_fwd)
+ *   uniq_row  [F,B] int32 — field f's unique rows, ascending, first uniq_cnt[f] entries valid
+ *   seg_start [F,B+1] int32 — uniq j of field f owns sorted positions [seg_start[f][j], seg_start[f][j+1])
+ *   perm      [F,B] int32 — batch row b of each sorted position (ascending b inside a segment)
+ *   uniq_cnt  [F]   int32
+ */
+#define CDC_SORT_MAX_B 16384
+int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
+                          int32_t* uniq_cnt, int64_t B, int32_t F, void* stream);
+
+/* Dense gradient of the table, as aten::embedding_dense_backward produces it for the
+ * reference (model/layer.py:140,153): grad[row,:] += sum over the row's segment of
+ * d_out[b, f*D:(f+1)*D], summed in ascending b (the CPU reference's order). */
+int cdc_embed_grad_dense(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
+                         const int32_t* perm, const int32_t* uniq_cnt, float* grad,
+                         int64_t B, int32_t F, int32_t D, int64_t R, void* stream);
+
+/* Adam hyper-parameters of run.py:720-721 (+ the L2 coefficient of model/layer.py:31), already
+ * rounded to fp32 the way torch's CPU Adam rounds its Python-double scalars:
+ *   lerp_w = float(1-beta1), beta2 = float(beta2), one_minus_beta2 = float(1-beta2),
+ *   l2_twice = 2*float(l2)  (d/dw sum(l2*w^2) as autograd forms it).
+ * step_scalars: device table [n_scalars][2] of {step_size_t = lr/(1-beta1^t), sqrt(1-beta2^t)},
+ * computed by the host in double and rounded to fp32 (index t, clamped to n_scalars-1 where both
+ * have converged).  step_dev points at a device int32 holding the 1-based step t of THIS update. */
+typedef struct {
+    float lerp_w, beta2, one_minus_beta2, eps, weight_decay, l2_twice;
+    const float* step_scalars;
+    int32_t n_scalars;
+} cdc_adam_hp;
+
+/* Exact dense-Adam semantics for the whole table, in three launches:
+ *  (1) touched: for every unique row of the batch: g = segsum(d_out) + 2*l2*w + wd*w, Adam
+ *      step t, result written to side[f,j,{w,m,v},D] (the table itself is not modified);
+ *  (2) dense_pass: every row updated as an untouched row (g = 2*l2*w + wd*w) in one streaming
+ *      pass; reg_sum (device double, may be NULL) += sum(w_old^2) (caller multiplies by l2);
+ *  (3) patch: side rows copied over the rows touched by the batch. */
+int cdc_embed_adam_touched(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
+                           const int32_t* perm, const int32_t* uniq_cnt,
+                           const float* w, const float* m, const float* v, float* side,
+                           cdc_adam_hp hp, const int32_t* step_dev,
+                           int64_t B, int32_t F, int32_t D, void* stream);
+int cdc_embed_adam_dense_pass(float* w, float* m, float* v, int64_t n_elems,
+                              cdc_adam_hp hp, const int32_t* step_dev, double* reg_sum, void* stream);
+int cdc_embed_adam_patch(const float* side, const int32_t* uniq_row, const int32_t* uniq_cnt,
+                         float* w, float* m, float* v, int64_t B, int32_t F, int32_t D, void* stream);
+
+/* Lazy-exact form of the same update: rows carry last[row] = the step their
+ * (w,m,v) are valid for.  catchup replays the untouched-row recurrence for the batch's unique rows
+ * up to step t-1 (run BEFORE the gather of step t); update applies step t with the batch gradient;
+ * flush brings every row to step t_now (dense pass; before state_dict / eval / reg-loss report).
+ * reg_ring [ring_len] device doubles: reg_ring[s % ring_len] += sum(w_{s-1}^2) over replayed rows. */
+int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* uniq_cnt,
+                           float* w, float* m, float* v, int32_t* last,
+                           cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring, int32_t ring_len,
+                           int64_t B, int32_t F, int32_t D, void* stream);
+int cdc_embed_lazy_update(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
+                          const int32_t* perm, const int32_t* uniq_cnt,
+                          float* w, float* m, float* v, int32_t* last,
+                          cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring, int32_t ring_len,
+                          int64_t B, int32_t F, int32_t D, void* stream);
+/* brings all R rows to step *step_dev (+ step_bias): rows with last < target are replayed. */
+int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D,
+                         cdc_adam_hp hp, const int32_t* step_dev, int32_t step_bias,
+                         double* reg_ring, int32_t ring_len, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped linear layers on MFMA (reference: every nn.Linear on the path —
+ * model/layer.py:185,193 MultiLayerPerceptron; :275 DNN; model/ple.py:83-94 CGC experts+gates;
+ * model/mmoe.py:35-40; model/star.py:90-102 F.linear with W_d*W_s)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x;  int64_t ldx;    /* [M,K] activations, row stride ldx */
+    const float* w;  int64_t ldw;    /* [N,K] nn.Linear weight layout */
+    const float* bias;               /* [N] or NULL */
+    float* y;        int64_t ldy;    /* [M,N] */
+    int32_t M, N, K;
+    int32_t act_cols;                /* columns [0,act_cols) get relu (+dropout) in the epilogue */
+} cdc_lin_group;
+
+typedef struct {
+    int32_t n_groups;
+    int32_t relu;                    /* 1: relu on act columns */
+    float   drop_p;                  /* dropout probability on act columns (0 = off) */
+    uint64_t seed;                   /* dropout stream: element (group,row,col) keyed by seed */
+    const int32_t* seed_offset_dev;  /* device int32 added to the seed stream per step (may be NULL) */
+    const int32_t* row_offsets;      /* device [n_groups+1] or NULL: ragged rows — group g uses rows
+                                        [row_offsets[g], row_offsets[g+1]) of its x / y; M = upper bound */
+    cdc_lin_group g[CDC_MAX_GROUPS];
+} cdc_lin_fwd_args;
+
+/* y_g = act(x_g · w_gᵀ + bias_g) for every group in one launch. */
+int cdc_glinear_fwd(const cdc_lin_fwd_args* a, int32_t prec, void* stream);
+
+/* dX_o = sum over the output's segments s of dZ_s · W_s   (several groups that read the same x
+ * reduce into one dX without atomics), then the optional activation mask of the PRODUCING layer:
+ * dX = (mask_y > 0) ? dX * mask_scale : 0. */
+typedef struct {
+    const float* dz; int64_t lddz;   /* [M,N] */
+    const float* w;  int64_t ldw;    /* [N,K] */
+    int32_t N;
+    int32_t out;                     /* index of the output this segment reduces into */
+} cdc_bwdx_seg;
+typedef struct {
+    float* dx; int64_t lddx;         /* [M,K] */
+    const float* mask_y; int64_t ldmask; /* post-activation output of the layer that produced x, or NULL */
+    int32_t M, K;
+    int32_t mask_cols;               /* mask applies to columns [0,mask_cols) */
+    int32_t accumulate;              /* 1: dx += result */
+} cdc_bwdx_out;
+typedef struct {
+    int32_t n_out, n_seg;
+    float mask_scale;
+    const int32_t* row_offsets;      /* ragged rows per OUTPUT (device [n_out+1]) or NULL */
+    cdc_bwdx_out o[CDC_MAX_GROUPS];
+    cdc_bwdx_seg s[CDC_MAX_GROUPS];
+} cdc_lin_bwdx_args;
+int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void* stream);
+
+/* dW_g[N,K] = dZ_gᵀ · X_g ; db_g[N] = column sums of dZ_g (fp32, exact order-fixed reduction). */
+typedef struct {
+    const float* dz; int64_t lddz;   /* [M,N] */
+    const float* x;  int64_t ldx;    /* [M,K] */
+    float* dw; int64_t lddw;         /* [N,K] */
+    float* db;                       /* [N] or NULL */
+    int32_t M, N, K;
+    int32_t accumulate;              /* 1: dw += , db += */
+} cdc_bwdw_group;
+typedef struct {
+    int32_t n_groups;
+    const int32_t* row_offsets;      /* ragged rows (device [n_groups+1]) or NULL */
+    cdc_bwdw_group g[CDC_MAX_GROUPS];
+} cdc_lin_bwdw_args;
+int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gate softmax + expert pooling (reference: model/ple.py:89-94,105-123; model/mmoe.py:37-40,58-60)
+ *   p[b,g,:] = softmax(logits[b, gate g's columns]) ; out[g][b,:] = sum_j p[b,g,j] * experts[b, sel[g][j], :]
+ * experts [B, n_expert, H] with row stride ld_exp (expert e at column e*H).
+ * ---------------------------------------------------------------------------------------- */
+#define CDC_MAX_GATES 16
+#define CDC_MAX_SEL   16
+typedef struct {
+    int32_t n_gates, n_expert, H;
+    int64_t B;
+    const float* experts; int64_t ld_exp;
+    struct {
+        const float* logits; int64_t ld_logits;   /* [B, n_sel] */
+        float* out; int64_t ld_out;               /* [B, H] */
+        float* probs;                             /* [B, n_sel] contiguous (saved for backward) */
+        int32_t n_sel;
+        int32_t sel[CDC_MAX_SEL];
+    } gate[CDC_MAX_GATES];
+} cdc_pool_fwd_args;
+int cdc_gate_pool_fwd(const cdc_pool_fwd_args* a, void* stream);
+
+typedef struct {
+    int32_t n_gates, n_expert, H;
+    int64_t B;
+    const float* experts; int64_t ld_exp;     /* forward expert outputs (post-activation) */
+    float* d_experts; int64_t ld_dexp;        /* [B, n_expert, H]: every expert column written */
+    int32_t mask_relu;                        /* 1: d_experts = (experts > 0) ? d * mask_scale : 0 */
+    float mask_scale;
+    int32_t accumulate;                       /* 1: d_experts += (a second launch for more than CDC_MAX_GATES gates) */
+    struct {
+        const float* d_out; int64_t ld_dout;  /* [B,H] */
+        const float* probs;                   /* [B,n_sel] */
+        float* d_logits; int64_t ld_dlogits;  /* [B,n_sel] */
+        int32_t n_sel;
+        int32_t sel[CDC_MAX_SEL];
+    } gate[CDC_MAX_GATES];
+} cdc_pool_bwd_args;
+int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm1d (+ReLU, +dropout) over column segments (reference: model/layer.py:187,199-205 with the
+ * batch==1 skip; model/star.py:117-181 MDR_BatchNorm with gamma_d*gamma_s / beta_d+beta_s — the caller
+ * passes the combined gamma/beta).  Training: batch mean / biased variance, running stats updated with
+ * momentum and the unbiased variance (torch semantics).  Eval: running stats.
+ * One segment = C columns sharing one parameter set and one row range.
+ * ---------------------------------------------------------------------------------------- */
+#define CDC_MAX_BN_SEGS 24
+#define CDC_BN_ROWS_PER_BLOCK 64      /* rows per partial-sum block: workspace holds ceil(M/64) partials */
+typedef struct {
+    const float* x; int64_t ldx;      /* [M,C] pre-norm */
+    float* y; int64_t ldy;            /* [M,C] output */
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;  /* updated in training */
+    float* save_mean; float* save_invstd;     /* [C] saved for backward (training) */
+    int64_t* num_batches_tracked;     /* incremented in training when the segment is normalised (may be NULL) */
+    int32_t C;
+    int32_t row_group;                /* index into row_offsets (ragged rows) */
+} cdc_bn_seg;
+typedef struct {
+    int32_t n_seg;
+    int32_t training;
+    int32_t relu;
+    float eps, momentum;
+    float drop_p; uint64_t seed; const int32_t* seed_offset_dev;
+    int64_t M;                        /* rows (upper bound when ragged) */
+    const int32_t* row_offsets;       /* device, or NULL: every segment covers rows [0,M) */
+    double* workspace;                /* >= 2 * ceil(M/64) * sum(C) doubles (training) */
+    cdc_bn_seg s[CDC_MAX_BN_SEGS];
+} cdc_bn_fwd_args;
+int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream);
+
+typedef struct {
+    const float* dy; int64_t lddy;    /* grad w.r.t. the post-activation output */
+    const float* y;  int64_t ldy;     /* post-activation output (relu/dropout mask) */
+    const float* x;  int64_t ldx;     /* pre-norm input */
+    float* dx; int64_t lddx;
+    const float* gamma;
+    const float* save_mean; const float* save_invstd;      /* training: batch stats; eval: the running
+                                                              mean and 1/sqrt(running_var+eps) */
+    float* dgamma; float* dbeta;
+    int32_t C;
+    int32_t row_group;
+} cdc_bn_bseg;
+typedef struct {
+    int32_t n_seg;
+    int32_t training;
+    int32_t relu;
+    float eps;
+    float mask_scale;                 /* 1/(1-p) when dropout was on */
+    int64_t M;
+    const int32_t* row_offsets;
+    double* workspace;                /* >= 2 * ceil(M/64) * sum(C) doubles */
+    cdc_bn_bseg s[CDC_MAX_BN_SEGS];
+} cdc_bn_bwd_args;
+int cdc_bn_bwd(const cdc_bn_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row dot products: out[b] = sigmoid?( x[b,:]·w + bias + sum_i addend_i[b] )
+ * (reference: model/layer.py:122-126 FeaturesLinear, :193 tower output Linear(→1) followed by
+ *  `y_logits += other` and Sigmoid model/layer.py:50-55, :318,326 CrossNetwork.w, dcn.py:42)
+ * grouped over towers: group g reads x_g, writes out + g*out_gstride.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x; int64_t ldx;
+    const float* w; const float* bias;    /* bias: device pointer to 1 float or NULL */
+    float* out; int64_t ld_out;           /* out[b*ld_out] */
+    float* logit; int64_t ld_logit;       /* optional pre-sigmoid copy (NULL = skip) */
+    int32_t K;
+} cdc_rowdot_group;
+typedef struct {
+    int32_t n_groups;
+    int32_t sigmoid;
+    int32_t n_addend;
+    const float* addend[4]; int64_t ld_addend[4];
+    int64_t M;
+    const int32_t* row_offsets;       /* ragged: group g covers rows [ro[g],ro[g+1]) of x/out/addend */
+    cdc_rowdot_group g[CDC_MAX_GROUPS];
+} cdc_rowdot_fwd_args;
+int cdc_rowdot_fwd(const cdc_rowdot_fwd_args* a, void* stream);
+
+typedef struct {
+    const float* dout; int64_t ld_dout;   /* grad w.r.t. out (post-sigmoid if sigmoid) */
+    const float* out;  int64_t ld_out;    /* forward output (for sigmoid') */
+    const float* x; int64_t ldx;
+    const float* w;
+    float* dx; int64_t lddx;              /* may be NULL */
+    float* dw; float* dbias;              /* [K], [1]; partial sums reduced deterministically */
+    float* dlogit; int64_t ld_dlogit;     /* optional: grad w.r.t. the logit (for addends), may be NULL */
+    int32_t K;
+    int32_t accumulate_dx;
+} cdc_rowdot_bgroup;
+typedef struct {
+    int32_t n_groups;
+    int32_t sigmoid;
+    int64_t M;
+    const int32_t* row_offsets;
+    float* workspace;                     /* >= n_groups * CDC_ROWDOT_PARTS * (Kmax+1) floats */
+    cdc_rowdot_bgroup g[CDC_MAX_GROUPS];
+} cdc_rowdot_bwd_args;
+#define CDC_ROWDOT_PARTS 64
+int cdc_rowdot_bwd(const cdc_rowdot_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss (reference: run.py:484,723 — BCELoss(mean) on probabilities gathered by group column,
+ * log clamped at -100; backward as aten::binary_cross_entropy_backward with eps 1e-12)
+ *   p [B, n_col]; group [B] int64 column per row (NULL => column 0); y int16/float labels.
+ *   loss (device float) = mean_b bce(p[b,group[b]], y[b]) * loss_scale
+ *   dp [B, n_col] = d loss / d p (zeros elsewhere); inv_count = 1/global_batch.
+ * ---------------------------------------------------------------------------------------- */
+int cdc_bce_fwd_bwd(const float* p, int64_t ldp, const int64_t* group, const int16_t* y_i16,
+                    const float* y_f32, float* loss, float* dp, int64_t lddp,
+                    int64_t B, int32_t n_col, float inv_count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CrossNetwork (DCN v1) layer (reference: model/layer.py:321-329): out = x0 * (xl·w) + b + xl
+ * ---------------------------------------------------------------------------------------- */
+int cdc_cross_fwd(const float* x0, int64_t ld0, const float* xl, int64_t ldl, const float* w, const float* b,
+                  float* out, int64_t ldo, float* xw_save, int64_t B, int32_t E, void* stream);
+/* d_x0 += , d_xl = , dw = , db =  (workspace >= CDC_ROWDOT_PARTS*2*E floats) */
+int cdc_cross_bwd(const float* d_out, int64_t ldo, const float* x0, int64_t ld0, const float* xl, int64_t ldl,
+                  const float* w, const float* xw_save, float* d_x0_acc, int64_t ld_dx0, float* d_xl, int64_t ld_dxl,
+                  float* dw, float* db, float* workspace, int64_t B, int32_t E, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense-parameter Adam, multi-tensor (reference: run.py:720-721 torch.optim.Adam(lr, betas=(0.9,0.99),
+ * eps=1e-8, weight_decay=wd) + the L2 term of model/layer.py:96-112 whose gradient is 2*l2*w):
+ *   g = grad + 2*l2_i*w + wd*w ; Adam step t ; reg_sum += l2_i * sum(w_old^2) (device double).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    float* w; const float* g; float* m; float* v;
+    int64_t n;
+    float l2;
+} cdc_adam_tensor;
+typedef struct {
+    int32_t n_tensors;
+    float lerp_w, beta2, one_minus_beta2, eps, weight_decay;   /* as in cdc_adam_hp */
+    const float* step_scalars; int32_t n_scalars;
+    float grad_scale;                 /* g is multiplied by this first (1/world_size after a sum all-reduce) */
+    const int32_t* step_dev;
+    double* reg_sum;                  /* may be NULL */
+    cdc_adam_tensor t[CDC_MAX_TENSORS];
+} cdc_adam_args;
+int cdc_adam_multi(const cdc_adam_args* a, void* stream);
+
+/* small utilities used by the step driver */
+int cdc_step_increment(int32_t* step_dev, void* stream);                 /* ++*step_dev */
+int cdc_fill_f32(float* p, float value, int64_t n, void* stream);
+int cdc_fill_f64(double* p, double value, int64_t n, void* stream);
+/* dst[r*ld_dst + c] += src[r*ld_src + c]  (gradient fan-in where a kernel cannot accumulate itself) */
+int cdc_add_inplace(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t rows, int32_t cols, void* stream);
+/* out[i] = a[i] * b[i % nb]  (STAR: W_d ⊙ W_s, model/star.py:90) ; and its two gradients */
+int cdc_mul_bcast(const float* a, const float* b, float* out, int64_t na, int64_t nb, void* stream);
+int cdc_mul_bcast_bwd(const float* d_out, const float* a, const float* b, float* da, float* db,
+                      int64_t na, int64_t nb, void* stream);
+/* stable partition of batch rows by group id (reference: model/star.py:84-86,113-114):
+ *   counts[g], row_offsets[g] (exclusive scan, n_group+1 entries), order[pos] = source row. */
+int cdc_group_partition(const int64_t* group, int32_t* row_offsets, int32_t* order,
+                        int64_t B, int32_t n_group, void* stream);
+/* out[pos,:] = in[order[pos],:]  and the inverse scatter out[order[pos],:] = in[pos,:] */
+int cdc_rows_permute(const float* in, int64_t ld_in, const int32_t* order, float* out, int64_t ld_out,
+                     int64_t B, int32_t C, int32_t inverse, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDCMDR_H */

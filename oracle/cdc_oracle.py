@@ -1,0 +1,421 @@
+"""CPU oracle of the multi-domain CTR training hot path — TEST INFRASTRUCTURE ONLY.
+
+A from-scratch functional restatement (numpy for the integer index math, plain torch fp32 CPU ops for
+the floating-point math, torch.autograd for derivatives) of what the reference computes on this path.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the product path
+(the package's HIP kernels) never does.
+
+Parity pin: tests/test_oracle_golden.py checks every function here against the golden vectors in
+tests/golden/*.npz, which tools/make_golden.py captured by importing the reference's own model/
+package in the build container (the reference has no tests or fixtures of its own: SURVEY.md §4).
+
+Every function takes the model's parameters as a flat dict keyed by the reference's state_dict names,
+so reference checkpoints and the HIP modules' state_dict() are interchangeable inputs.
+Reference citations are file:line under the reference repository.
+"""
+import math
+import re
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# --------------------------------------------------------------------------------------------------
+# embedding  (model/layer.py:129-157)
+# --------------------------------------------------------------------------------------------------
+def field_offsets(field_dims):
+    """model/layer.py:141-144: offsets[f] = sum of the cardinalities of the fields before f."""
+    fd = np.asarray(field_dims, dtype=np.int64)
+    return np.concatenate([[0], np.cumsum(fd)[:-1]]).astype(np.int64)
+
+
+def gather_index(x_i32, field_dims):
+    """model/layer.py:152: x + x.new_tensor(offsets): the sum is formed in x's dtype, int32, and wraps."""
+    x = np.asarray(x_i32, dtype=np.int32)
+    off = field_offsets(field_dims).astype(np.int32)           # new_tensor -> int32 (wraps like torch)
+    with np.errstate(over="ignore"):
+        return (x.astype(np.int32) + off[None, :]).astype(np.int32)
+
+
+def embed(table, x_i32, field_dims):
+    """model/layer.py:153-155: row lookup then flatten to [B, F*D]."""
+    idx = gather_index(x_i32, field_dims)
+    if idx.min() < 0 or idx.max() >= table.shape[0]:
+        raise IndexError("index out of range in self")
+    rows = table[torch.from_numpy(idx.astype(np.int64))]       # [B, F, D]
+    return rows.flatten(1)
+
+
+# --------------------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------------------
+def _lin(x, sd, prefix):
+    b = sd.get(prefix + ".bias")
+    y = x @ sd[prefix + ".weight"].t()
+    return y if b is None else y + b
+
+
+def _bn(x, sd, prefix, training, stats_out, gamma=None, beta=None):
+    """nn.BatchNorm1d / F.batch_norm: batch mean and biased variance in training, running stats in eval;
+    running stats updated with momentum 0.1 and the unbiased variance (functional: new stats go to stats_out)."""
+    g = sd[prefix + ".weight"] if gamma is None else gamma
+    b = sd[prefix + ".bias"] if beta is None else beta
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if training:
+        n = x.shape[0]
+        mean = x.mean(0)
+        var = x.var(0, unbiased=False)
+        if stats_out is not None:
+            unb = var * (n / (n - 1)) if n > 1 else var
+            stats_out[prefix + ".running_mean"] = ((1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean).detach()
+            stats_out[prefix + ".running_var"] = ((1 - BN_MOMENTUM) * rv + BN_MOMENTUM * unb).detach()
+            stats_out[prefix + ".num_batches_tracked"] = sd[prefix + ".num_batches_tracked"] + 1
+    else:
+        mean, var = rm, rv
+    return (x - mean) / torch.sqrt(var + BN_EPS) * g + b
+
+
+def _mlp_layer_ids(sd, prefix):
+    """indices N of `prefix.layers.N.weight` entries, with whether each is a Linear (2-D) or a BatchNorm (1-D)."""
+    pat = re.compile(re.escape(prefix) + r"\.layers\.(\d+)\.weight$")
+    ids = sorted(int(m.group(1)) for k in sd for m in [pat.match(k)] if m)
+    return [(i, sd[f"{prefix}.layers.{i}.weight"].dim()) for i in ids]
+
+
+def mlp(x, sd, prefix, training, stats_out=None, output_layer=False):
+    """MultiLayerPerceptron.forward (model/layer.py:197-206) with dropout p = 0: Linear -> (BN unless the batch
+    has one row) -> ReLU per hidden layer; with output_layer the trailing Linear -> 1 has no activation."""
+    layers = _mlp_layer_ids(sd, prefix)
+    lin_pos = [k for k, (_, dim) in enumerate(layers) if dim == 2]
+    for n, k in enumerate(lin_pos):
+        idx = layers[k][0]
+        y = _lin(x, sd, f"{prefix}.layers.{idx}")
+        if output_layer and n == len(lin_pos) - 1:
+            return y
+        if k + 1 < len(layers) and layers[k + 1][1] == 1 and x.shape[0] != 1:
+            y = _bn(y, sd, f"{prefix}.layers.{layers[k + 1][0]}", training, stats_out)
+        x = torch.relu(y)
+    return x
+
+
+def wide_logit(e, sd):
+    """FeaturesLinear (model/layer.py:122-126)."""
+    return _lin(e, sd, "linear.fc")
+
+
+def towers(tower_inputs, other_outs, sd, training, stats_out, prefix="towers"):
+    """BaseModel.tower_forward (model/layer.py:48-56)."""
+    ys = []
+    for i, t_in in enumerate(tower_inputs):
+        logit = mlp(t_in, sd, f"{prefix}.{i}", training, stats_out, output_layer=True)
+        for o in other_outs:
+            logit = logit + o
+        ys.append(torch.sigmoid(logit))
+    return torch.cat(ys, dim=1)
+
+
+def _count(sd, pattern):
+    pat = re.compile(pattern)
+    return len({m.group(1) for k in sd for m in [pat.match(k)] if m})
+
+
+# --------------------------------------------------------------------------------------------------
+# PLE  (model/ple.py:50-70, 96-125)
+# --------------------------------------------------------------------------------------------------
+def cgc(x_list, sd, prefix, n_task, training):
+    n_spec_total = _count(sd, re.escape(prefix) + r"\.experts_specific\.(\d+)\.")
+    n_shared = _count(sd, re.escape(prefix) + r"\.experts_shared\.(\d+)\.")
+    ns = n_spec_total // n_task
+    spec = [mlp(x_list[i // ns], sd, f"{prefix}.experts_specific.{i}", training) for i in range(n_spec_total)]
+    shared = [mlp(x_list[-1], sd, f"{prefix}.experts_shared.{k}", training) for k in range(n_shared)]
+    outs = []
+    for i in range(n_task):
+        gate = torch.softmax(_lin(x_list[i], sd, f"{prefix}.gates_specific.{i}.0"), dim=1)
+        cat = torch.stack(spec[i * ns:(i + 1) * ns] + shared, dim=1)        # [B, ns+nsh, H]
+        outs.append((gate.unsqueeze(-1) * cat).sum(1))
+    if f"{prefix}.gate_shared.0.weight" in sd:
+        gate = torch.softmax(_lin(x_list[-1], sd, f"{prefix}.gate_shared.0"), dim=1)
+        cat = torch.stack(spec + shared, dim=1)
+        outs.append((gate.unsqueeze(-1) * cat).sum(1))
+    return outs
+
+
+def ple_forward(sd, x_i32, field_dims, n_tower, training=True, stats_out=None, prefix=""):
+    sd = _strip(sd, prefix)
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    n_level = _count(sd, r"cgc_layers\.(\d+)\.")
+    inputs = [e] * (n_tower + 1)
+    for lvl in range(n_level):
+        inputs = cgc(inputs, sd, f"cgc_layers.{lvl}", n_tower, training)
+    return towers(inputs[:n_tower], [wide_logit(e, sd)], sd, training, _prefixed(stats_out, prefix))
+
+
+# --------------------------------------------------------------------------------------------------
+# MMoE  (model/mmoe.py:53-74)
+# --------------------------------------------------------------------------------------------------
+def mmoe_forward(sd, x_i32, field_dims, n_tower, training=True, stats_out=None, prefix=""):
+    sd = _strip(sd, prefix)
+    so = _prefixed(stats_out, prefix)
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    n_expert = _count(sd, r"experts\.(\d+)\.")
+    experts = torch.stack([mlp(e, sd, f"experts.{k}", training, so) for k in range(n_expert)], dim=1)   # [B, n_e, H]
+    tin = []
+    for i in range(n_tower):
+        gate = torch.softmax(_lin(e, sd, f"gates.{i}.0"), dim=1)
+        tin.append((gate.unsqueeze(-1) * experts).sum(1))
+    return towers(tin, [wide_logit(e, sd)], sd, training, so)
+
+
+# --------------------------------------------------------------------------------------------------
+# cross networks + DCN / DCNv2  (model/layer.py:303-407, model/dcn.py:36-43, model/dcnv2.py:59-70)
+# --------------------------------------------------------------------------------------------------
+def cross_network(x, sd, prefix):
+    n = _count(sd, re.escape(prefix) + r"\.w\.(\d+)\.")
+    x0 = x
+    for i in range(n):
+        xw = x @ sd[f"{prefix}.w.{i}.weight"].t()                  # [B,1]
+        x = x0 * xw + sd[f"{prefix}.b.{i}"] + x
+    return x
+
+
+def cross_network_v2(x, sd, prefix):
+    n = _count(sd, re.escape(prefix) + r"\.w\.(\d+)\.")
+    x0 = x
+    for i in range(n):
+        x = x0 * (x @ sd[f"{prefix}.w.{i}.weight"].t()) + sd[f"{prefix}.b.{i}"] + x
+    return x
+
+
+def cross_network_mix(x, sd, prefix):
+    """model/layer.py:372-407, incl. the trailing squeeze() that drops the batch dim when B == 1."""
+    n_layers = _count(sd, re.escape(prefix) + r"\.u_list\.(\d+)$")
+    n_exp = sd[f"{prefix}.u_list.0"].shape[0]
+    x0 = x
+    xl = x
+    for i in range(n_layers):
+        U, V, Cm = sd[f"{prefix}.u_list.{i}"], sd[f"{prefix}.v_list.{i}"], sd[f"{prefix}.c_list.{i}"]
+        bias = sd[f"{prefix}.bias.{i}"].squeeze(1)
+        outs, scores = [], []
+        for k in range(n_exp):
+            scores.append(xl @ sd[f"{prefix}.gating.{k}.weight"].t())          # [B,1]
+            v = torch.tanh(xl @ V[k])                                           # [B,r]
+            v = torch.tanh(v @ Cm[k].t())
+            uv = v @ U[k].t()                                                   # [B,E]
+            outs.append(x0 * (uv + bias))
+        outs = torch.stack(outs, 2)                                             # [B,E,n_exp]
+        gate = torch.softmax(torch.stack(scores, 1), dim=1)                     # [B,n_exp,1]
+        xl = torch.matmul(outs, gate).squeeze(2) + xl
+    return xl.squeeze()
+
+
+def dcn_forward(sd, x_i32, field_dims, training=True, stats_out=None):
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    cn = cross_network(e, sd, "cn")
+    deep = mlp(e, sd, "mlp", training, stats_out)
+    stack = torch.cat([cn, deep], dim=1)
+    return torch.sigmoid(wide_logit(e, sd) + stack @ sd["mlp_linear.weight"].t()).squeeze(1)
+
+
+def dcnv2_forward(sd, x_i32, field_dims, training=True, stats_out=None, model_structure="parallel"):
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    if "crossnet.u_list.0" in sd:
+        cross = cross_network_mix(e, sd, "crossnet")
+        if cross.dim() == 1:
+            cross = cross.unsqueeze(0) if e.shape[0] == 1 else cross
+    else:
+        cross = cross_network_v2(e, sd, "crossnet")
+    if model_structure == "crossnet_only":
+        final = cross
+    elif model_structure == "stacked":
+        final = mlp(cross, sd, "dnn", training, stats_out)
+    else:
+        final = torch.cat([cross, mlp(e, sd, "dnn", training, stats_out)], dim=1)
+    return torch.sigmoid(final @ sd["dnn_linear.weight"].t() + wide_logit(e, sd)).squeeze(1)
+
+
+# --------------------------------------------------------------------------------------------------
+# STAR  (model/star.py:62-114, 133-181)
+# --------------------------------------------------------------------------------------------------
+def _star_tower(h, sd, g, training, stats_out):
+    n_layers = _count(sd, r"shared_dnn\.linears\.(\d+)\.")
+    if h.shape[0] != 1:                                             # MDR_BatchNorm returns its input for one row
+        gamma = sd[f"domain_norm.{g}.weight"] * sd["shared_bn_weight"]
+        beta = sd[f"domain_norm.{g}.bias"] + sd["shared_bn_bias"]
+        h = _bn(h, sd, f"domain_norm.{g}", training, stats_out, gamma=gamma, beta=beta)
+    for i in range(n_layers):
+        w = sd[f"domain_dnns.{g}.linears.{i}.weight"] * sd[f"shared_dnn.linears.{i}.weight"]
+        b = sd[f"domain_dnns.{g}.linears.{i}.bias"] + sd[f"shared_dnn.linears.{i}.bias"]
+        h = h @ w.t() + b
+        if h.shape[0] > 1:
+            h = _bn(h, sd, f"domain_dnns.{g}.bn.{i}", training, stats_out)
+        h = torch.relu(h)
+    w = sd[f"domain_dnn_linears.{g}.weight"] * sd["shared_dnn_linear.weight"]
+    b = sd[f"domain_dnn_linears.{g}.bias"] + sd["shared_dnn_linear.bias"]
+    return h @ w.t() + b
+
+
+def star_forward(sd, x_i32, field_dims, n_tower, x_group=None, targets=None, training=True, stats_out=None, prefix=""):
+    """x_group None: every tower over the full batch -> [B, n_tower]; else rows are partitioned by group id
+    (ascending group, original order inside a group) -> ([B,1] group-ordered, targets group-ordered)."""
+    sd = _strip(sd, prefix)
+    so = _prefixed(stats_out, prefix)
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    wide = wide_logit(e, sd)
+    ys, ts = [], []
+    for g in range(n_tower):
+        if x_group is None:
+            h, w_g, t_g = e, wide, targets
+        else:
+            mask = (torch.as_tensor(x_group) == g).reshape(-1)
+            h, w_g = e[mask], wide[mask]
+            t_g = None if targets is None else torch.as_tensor(targets)[mask]
+        if h.shape[0] == 0 and training:
+            # F.batch_norm on an empty training batch: no rows -> nothing to emit (see tests for the statistics)
+            ys.append(torch.zeros((0, 1)))
+            ts.append(t_g)
+            continue
+        ys.append(torch.sigmoid(_star_tower(h, sd, g, training, so) + w_g))
+        ts.append(t_g)
+    if x_group is None:
+        return torch.cat(ys, dim=1)
+    return torch.cat(ys, dim=0), (None if targets is None else torch.cat(ts, dim=0))
+
+
+# --------------------------------------------------------------------------------------------------
+# CDC.forward  (model/cdc.py:95-111)
+# --------------------------------------------------------------------------------------------------
+def cdc_forward(base_forward, x_i32, domain2group, domain_idx, mode="split", domain_i=None):
+    y = base_forward(x_i32)
+    if mode == "warmup":
+        return y.mean(dim=1)
+    d2g = torch.as_tensor(domain2group, dtype=torch.int64)
+    if domain_i is None:
+        groups = d2g[torch.as_tensor(np.asarray(x_i32)[:, domain_idx].astype(np.int64))]
+        return y.gather(1, groups.unsqueeze(1))
+    return y[:, int(d2g[domain_i])]
+
+
+# --------------------------------------------------------------------------------------------------
+# loss, regularisation, optimiser  (run.py:484-492, 720-723; model/layer.py:96-112)
+# --------------------------------------------------------------------------------------------------
+def bce_mean(p, y):
+    """torch.nn.BCELoss(reduction='mean') on probabilities: log terms clamped at -100."""
+    y = y.float()
+    return (-(y * torch.clamp(torch.log(p), min=-100.0) + (1 - y) * torch.clamp(torch.log1p(-p), min=-100.0))).mean()
+
+
+def reg_loss(sd, l2_by_name):
+    """sum_w l2_w * sum(w^2) over the registered tensors -> shape (1,) (model/layer.py:96-112)."""
+    total = torch.zeros((1,))
+    for name, l2 in l2_by_name.items():
+        if l2 > 0:
+            total = total + torch.sum(l2 * torch.square(sd[name]))
+    return total
+
+
+def reg_names(names, model_kind):
+    """Which state_dict entries the reference registers for L2 (BaseModel.__init__ + each model's filters).
+    The filter is `'weight' in name and 'bn' not in name` on names RELATIVE to the filtered sub-module, so
+    BatchNorm gammas of MultiLayerPerceptron (`layers.N.weight`) are included, DNN's `bn.N.weight` are not."""
+    out = []
+    for n in names:
+        base = n.split("base_model_instance.")[-1]
+        if base == "embedding.embedding_dict.weight" or base == "linear.fc.weight":
+            out.append(n)
+            continue
+        if "running_" in base or "num_batches" in base:
+            continue
+        top = base.split(".")[0]
+        rel = base[len(top) + 1:]
+        if model_kind == "ple" and top in ("cgc_layers", "towers") and "weight" in rel and "bn" not in rel:
+            out.append(n)
+        elif model_kind == "mmoe" and top in ("experts", "towers") and "weight" in rel and "bn" not in rel:
+            out.append(n)
+        elif model_kind == "dcn" and top in ("mlp", "cn") and "weight" in rel and "bn" not in rel:
+            out.append(n)
+        elif model_kind == "dcnv2":
+            if top == "dnn" and "weight" in rel and "bn" not in rel:
+                out.append(n)
+            elif base == "dnn_linear.weight" or re.match(r"crossnet\.(u_list|v_list|c_list)\.\d+$", base):
+                out.append(n)
+        elif model_kind == "star" and top in ("domain_dnns", "shared_dnn") and "weight" in rel and "bn" not in rel:
+            out.append(n)
+    return out
+
+
+def adam_scalars(step, lr=1e-3, beta1=0.9, beta2=0.99):
+    """step_size and sqrt(bias_correction2) as torch/optim/adam.py forms them (Python doubles)."""
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    return lr / bc1, math.sqrt(bc2)
+
+
+def adam_step(w, g, m, v, step, lr=1e-3, beta1=0.9, beta2=0.99, eps=1e-8, weight_decay=1e-8):
+    """One torch.optim.Adam step (single-tensor CPU path), functional: returns (w, m, v)."""
+    if weight_decay != 0:
+        g = g.add(w, alpha=weight_decay)
+    m = m.lerp(g, 1 - beta1)
+    v = v.mul(beta2).addcmul(g, g, value=1 - beta2)
+    step_size, bc2s = adam_scalars(step, lr, beta1, beta2)
+    denom = (v.sqrt() / bc2s).add(eps)
+    w = w.addcdiv(m, denom, value=-step_size)
+    return w, m, v
+
+
+# --------------------------------------------------------------------------------------------------
+# metrics  (run.py:682-711: sklearn roc_auc_score / log_loss)
+# --------------------------------------------------------------------------------------------------
+def auc(targets, scores):
+    """Tie-aware ROC AUC (Mann-Whitney U with mid-ranks) == sklearn.metrics.roc_auc_score."""
+    t = np.asarray(targets).astype(np.int64).reshape(-1)
+    s = np.asarray(scores, dtype=np.float64).reshape(-1)
+    n_pos = int(t.sum())
+    n_neg = t.size - n_pos
+    if n_pos == 0 or n_neg == 0:
+        raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+    order = np.argsort(s, kind="mergesort")
+    ss = s[order]
+    ranks = np.empty(t.size, dtype=np.float64)
+    i = 0
+    while i < t.size:
+        j = i
+        while j + 1 < t.size and ss[j + 1] == ss[i]:
+            j += 1
+        ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+        i = j + 1
+    return (ranks[t == 1].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg)
+
+
+def logloss(targets, scores, eps=None):
+    """sklearn.metrics.log_loss for binary labels (probabilities clipped to float eps of their dtype)."""
+    t = np.asarray(targets).astype(np.float64).reshape(-1)
+    s = np.asarray(scores).reshape(-1)
+    e = np.finfo(s.dtype).eps if eps is None else eps
+    p = np.clip(s.astype(np.float64), e, 1 - e)
+    return float(-(t * np.log(p) + (1 - t) * np.log(1 - p)).mean())
+
+
+# --------------------------------------------------------------------------------------------------
+def _strip(sd, prefix):
+    if not prefix:
+        return sd
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+class _Prefixed(dict):
+    def __init__(self, target, prefix):
+        super().__init__()
+        self.target, self.prefix = target, prefix
+
+    def __setitem__(self, k, v):
+        self.target[self.prefix + k] = v
+
+
+def _prefixed(stats_out, prefix):
+    if stats_out is None or not prefix:
+        return stats_out
+    return _Prefixed(stats_out, prefix)
