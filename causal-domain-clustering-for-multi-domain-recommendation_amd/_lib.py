@@ -145,6 +145,7 @@ _SIGNATURES = {
     "cdc_abi_version": (c_i32, []),
     "cdc_last_error": (C.c_char_p, []),
     "cdc_embed_gather_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
+    "cdc_embed_index": (c_i32, [c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
     "cdc_embed_adam_touched": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32, c_p]),

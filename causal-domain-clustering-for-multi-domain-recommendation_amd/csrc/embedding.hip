@@ -57,6 +57,20 @@ extern "C" int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, 
     return 0;
 }
 
+// row indices only (the lazy table optimiser needs them BEFORE the gather to bring the rows up to date)
+__global__ void __launch_bounds__(256) k_embed_index(const int32_t* __restrict__ ids, const int32_t* __restrict__ offsets,
+                                                     int32_t* __restrict__ idx_out, int64_t n_pos, int32_t F) {
+    for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n_pos; pos += (int64_t)gridDim.x * blockDim.x)
+        idx_out[pos] = (int32_t)((uint32_t)ids[pos] + (uint32_t)offsets[pos % F]);
+}
+extern "C" int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out, int64_t B, int32_t F, void* stream) {
+    CDC_CHECK_ARG(ids && offsets && idx_out && B > 0 && F > 0, CDC_E_BADARG, "embed_index: bad argument");
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(B * F, 256), 4096);
+    hipLaunchKernelGGL(k_embed_index, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, idx_out, B * F, F);
+    CDC_LAUNCH_CHECK("embed_index");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-field sort + dedupe: one workgroup per field, bitonic sort of (row<<32 | b) in LDS
 // ------------------------------------------------------------------------------------------------

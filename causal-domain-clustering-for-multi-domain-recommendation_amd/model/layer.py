@@ -168,11 +168,12 @@ def _bn_seg(x, norm, out=None, row_group=0):
             "num_batches_tracked": norm.num_batches_tracked, "row_group": row_group}
 
 
-def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmoid=False, final_outs=None):
+def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmoid=False, final_outs=None, last_outs=None):
     """Runs structurally identical MultiLayerPerceptrons side by side: one grouped-linear launch (and one
     BatchNorm launch) per layer depth for all of them.
 
     extra_groups: extra linear groups (dicts x/w/b/out) riding in the first launch (gates).
+    last_outs: where the last hidden layer's activations go (e.g. columns of a concat buffer) instead of a new buffer.
     Returns (outputs per mlp, outputs of the extra groups)."""
     n = len(mlps)
     cur = list(inputs)
@@ -185,10 +186,14 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
         width = mlps[0].hidden[j][0].out_features
         use_bn = mlps[0].use_bn
         pre = plan.new(n * width)
+        dst = None
+        if j == depth - 1 and last_outs is not None:
+            dst = list(last_outs)
         groups = []
         for i, m in enumerate(mlps):
             lin = m.hidden[j][0]
-            groups.append({"x": cur[i], "w": lin.weight, "b": lin.bias, "out": pre.slice(i * width, (i + 1) * width)})
+            o = pre.slice(i * width, (i + 1) * width) if (use_bn or dst is None) else dst[i]
+            groups.append({"x": cur[i], "w": lin.weight, "b": lin.bias, "out": o})
         n_extra = 0
         if j == 0 and extra_groups:
             for g in extra_groups:
@@ -198,11 +203,12 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
                 n_extra += 1
         if use_bn:
             op = P.GLinear(plan, groups, relu=False, dropout=False)
-            post = plan.new(n * width)
-            segs = [_bn_seg(pre.slice(i * width, (i + 1) * width), m.hidden[j][1], out=post.slice(i * width, (i + 1) * width))
-                    for i, m in enumerate(mlps)]
+            if dst is None:
+                post = plan.new(n * width)
+                dst = [post.slice(i * width, (i + 1) * width) for i in range(n)]
+            segs = [_bn_seg(pre.slice(i * width, (i + 1) * width), m.hidden[j][1], out=dst[i]) for i, m in enumerate(mlps)]
             P.BatchNorm(plan, segs, relu=True, dropout=True)
-            cur = [post.slice(i * width, (i + 1) * width) for i in range(n)]
+            cur = dst
         else:
             op = P.GLinear(plan, groups, relu=True, dropout=True)
             cur = [op.outs[i] for i in range(n)]

@@ -1,0 +1,216 @@
+"""Adam with the reference's exact semantics, fused for the HIP path.
+
+The reference trains with torch.optim.Adam(lr, betas=(0.9, 0.99), eps=1e-8, weight_decay=wd) over ALL parameters
+(run.py:720-721) and adds sum(l2 * w^2) over the registered tensors — the whole embedding table included — to the
+loss every step (run.py:489, model/layer.py:31,96-112).  So every table row moves every step, looked up or not
+(SURVEY.md F3).  This optimiser reproduces that, in two interchangeable forms for the table:
+
+  table_mode="dense"  touched rows (batch gradient + L2) -> side buffer, one streaming pass over the whole
+                      table for the L2-only rows, then the side buffer is patched in.  12 B read + 12 B
+                      written per table element per step: the HBM-roofline kernel of the step.
+  table_mode="lazy"   rows carry the step they are valid for; the L2-only recurrence is replayed only when a
+                      row is next looked up (before the gather) or when flush() is called (state_dict, eval,
+                      regularisation-loss report).  Bit-identical to "dense" (same per-element routine).
+
+Dense parameters go through one multi-tensor kernel with the L2 gradient 2*l2*w folded in.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def step_scalar_table(lr, beta1, beta2, n=4096):
+    """[n,2] fp32: step_size_t = lr / (1 - beta1^t) and sqrt(1 - beta2^t), formed in double like torch/optim/adam.py."""
+    rows = [(0.0, 1.0)]
+    for t in range(1, n):
+        rows.append((lr / (1.0 - beta1 ** t), math.sqrt(1.0 - beta2 ** t)))
+    return torch.tensor(rows, dtype=torch.float64).to(torch.float32)
+
+
+class FusedAdam:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode="dense"):
+        assert table_mode in ("dense", "lazy")
+        self.model = model
+        self.lib = L.load()
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.table_mode = table_mode
+        self.table = model.embedding.embedding_dict.weight
+        dev = self.table.device
+        if dev.type != "cuda":
+            raise L.HipExtensionError("FusedAdam needs the model on a GPU; there is no CPU fallback")
+        self.device = dev
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)       # 1-based step of the current update
+        self.scalars = step_scalar_table(lr, betas[0], betas[1]).to(dev).contiguous()
+        self.reg_sum = torch.zeros(2, dtype=torch.float64, device=dev)       # [0] dense params (l2 applied), [1] table sum(w^2)
+        f32 = lambda v: float(torch.tensor(v, dtype=torch.float64).to(torch.float32))  # noqa: E731
+        self._lerp_w = f32(1.0 - betas[0])
+        self._beta2 = f32(betas[1])
+        self._omb2 = f32(1.0 - betas[1])
+        self._eps = f32(eps)
+        self._wd = f32(weight_decay)
+        # per-parameter L2 coefficient from the model's regularisation registry
+        l2_of = {}
+        for p, l1, l2 in model.regularized_parameters():
+            if l1:
+                raise NotImplementedError("l1 regularisation is never enabled by the reference's models")
+            l2_of[id(p)] = l2_of.get(id(p), 0.0) + l2
+        self._l2_of = l2_of
+        self.l2_table = l2_of.get(id(self.table), 0.0)
+        self.state = {}                                                       # id(param) -> (m, v)
+        self.table_m = torch.zeros_like(self.table.data)
+        self.table_v = torch.zeros_like(self.table.data)
+        self.table_last = torch.zeros(self.table.shape[0], dtype=torch.int32, device=dev) if table_mode == "lazy" else None
+        self._dense_args = None
+        self._dense_sig = None
+        self._ws = {}
+        total_dense = sum(p.numel() + 4 for p in model.parameters() if p is not self.table)
+        self.grad_arena = torch.zeros(total_dense, dtype=torch.float32, device=dev)
+        self.grad_scale = 1.0
+
+    # ------------------------------------------------------------------------------------------
+    def _hp(self):
+        hp = L.AdamHP()
+        hp.lerp_w, hp.beta2, hp.one_minus_beta2, hp.eps = self._lerp_w, self._beta2, self._omb2, self._eps
+        hp.weight_decay = self._wd
+        hp.l2_twice = 2.0 * float(torch.tensor(self.l2_table, dtype=torch.float64).to(torch.float32))
+        hp.step_scalars = self.scalars.data_ptr()
+        hp.n_scalars = self.scalars.shape[0]
+        return hp
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _workspace(self, B, F, D):
+        key = (B, F, D)
+        ws = self._ws.get(key)
+        if ws is None:
+            dev = self.device
+            ws = {"uniq": torch.empty((F, B), dtype=torch.int32, device=dev),
+                  "seg": torch.empty((F, B + 1), dtype=torch.int32, device=dev),
+                  "perm": torch.empty((F, B), dtype=torch.int32, device=dev),
+                  "cnt": torch.zeros((F,), dtype=torch.int32, device=dev),
+                  "side": torch.empty((F * B * 3 * D,), dtype=torch.float32, device=dev) if self.table_mode == "dense" else None}
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------
+    def begin_step(self):
+        """++step and clear the regularisation accumulators (call before the forward of the step)."""
+        s = self._stream()
+        L.check(self.lib.cdc_step_increment(self.step_dev.data_ptr(), s), "step_increment")
+        L.check(self.lib.cdc_fill_f64(self.reg_sum.data_ptr(), 0.0, 2, s), "fill_f64")
+
+    def sort_rows(self, idx, B, F, D):
+        ws = self._workspace(B, F, D)
+        L.check(self.lib.cdc_embed_sort_dedupe(idx.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(),
+                                               ws["cnt"].data_ptr(), B, F, self._stream()), "embed_sort_dedupe")
+        return ws
+
+    def table_catchup(self, ids, offsets, idx, B, F, D):
+        """lazy mode, BEFORE the gather of this step: row indices -> dedupe -> replay the rows up to step t-1."""
+        assert self.table_mode == "lazy"
+        s = self._stream()
+        L.check(self.lib.cdc_embed_index(ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), B, F, s), "embed_index")
+        ws = self.sort_rows(idx, B, F, D)
+        L.check(self.lib.cdc_embed_lazy_catchup(ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(),
+                                                self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
+                                                self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D, s), "embed_lazy_catchup")
+
+    def table_step(self, idx, d_out, B, F, D):
+        """Adam step t on the table from the batch's row indices [B,F] and the gradient of the gathered rows [B,F*D]."""
+        s = self._stream()
+        hp = self._hp()
+        w, m, v = self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr()
+        if self.table_mode == "dense":
+            ws = self.sort_rows(idx, B, F, D)
+            L.check(self.lib.cdc_embed_adam_touched(d_out.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(),
+                                                    ws["cnt"].data_ptr(), w, m, v, ws["side"].data_ptr(), hp, self.step_dev.data_ptr(),
+                                                    B, F, D, s), "embed_adam_touched")
+            L.check(self.lib.cdc_embed_adam_dense_pass(w, m, v, self.table.numel(), hp, self.step_dev.data_ptr(),
+                                                       self.reg_sum.data_ptr() + 8, s), "embed_adam_dense_pass")
+            L.check(self.lib.cdc_embed_adam_patch(ws["side"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), w, m, v, B, F, D, s),
+                    "embed_adam_patch")
+        else:
+            ws = self._workspace(B, F, D)        # rows were sorted by table_catchup of this step
+            L.check(self.lib.cdc_embed_lazy_update(d_out.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(),
+                                                   ws["cnt"].data_ptr(), w, m, v, self.table_last.data_ptr(), hp,
+                                                   self.step_dev.data_ptr(), None, 0, B, F, D, s), "embed_lazy_update")
+
+    def flush_table(self):
+        """lazy mode: bring every row to the current step (needed before state_dict / eval / reading the table)."""
+        if self.table_mode != "lazy":
+            return
+        L.check(self.lib.cdc_embed_lazy_flush(self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
+                                              self.table_last.data_ptr(), self.table.shape[0], self.table.shape[1], self._hp(),
+                                              self.step_dev.data_ptr(), 0, None, 0, self._stream()), "embed_lazy_flush")
+
+    # ------------------------------------------------------------------------------------------
+    def dense_step(self, param_grads, param_refs):
+        """Adam step t on every dense parameter that has a gradient in the plan (params without one are skipped,
+        as torch.optim.Adam skips `grad is None`)."""
+        sig = tuple((k, g.data_ptr()) for k, g in param_grads.items())
+        if self._dense_sig != sig:
+            items = []
+            for k, g in param_grads.items():
+                p = param_refs[k]
+                if p is self.table:
+                    continue
+                st = self.state.get(k)
+                if st is None:
+                    st = (torch.zeros_like(p.data), torch.zeros_like(p.data))
+                    self.state[k] = st
+                items.append((p, g, st))
+            args = []
+            for c0 in range(0, len(items), L.MAX_TENSORS):
+                a = L.AdamArgs()
+                chunk = items[c0:c0 + L.MAX_TENSORS]
+                a.n_tensors = len(chunk)
+                a.lerp_w, a.beta2, a.one_minus_beta2, a.eps, a.weight_decay = self._lerp_w, self._beta2, self._omb2, self._eps, self._wd
+                a.step_scalars, a.n_scalars = self.scalars.data_ptr(), self.scalars.shape[0]
+                a.grad_scale = self.grad_scale
+                a.step_dev = self.step_dev.data_ptr()
+                a.reg_sum = self.reg_sum.data_ptr()
+                for i, (p, g, st) in enumerate(chunk):
+                    T = a.t[i]
+                    T.w, T.g, T.m, T.v, T.n = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel()
+                    T.l2 = float(torch.tensor(self._l2_of.get(id(p), 0.0), dtype=torch.float64).to(torch.float32))
+                args.append(a)
+            self._dense_args, self._dense_sig = args, sig
+        s = self._stream()
+        for a in self._dense_args:
+            L.check(self.lib.cdc_adam_multi(C.byref(a), s), "adam_multi")
+
+    def reg_loss(self):
+        """device double: the step's regularisation term sum(l2*w^2) (dense params + table). In lazy mode the table
+        part only covers rows replayed this step; call flush_table() + table_reg_loss() for the exact figure."""
+        return self.reg_sum[0] + self.l2_table * self.reg_sum[1]
+
+    def table_reg_loss(self):
+        self.flush_table()
+        return self.l2_table * torch.sum(torch.square(self.table.data.double()))
+
+    # ---- checkpointing (run.py:447: 'optimizer': optimizer.state_dict()) -------------------------------------
+    def state_dict(self):
+        self.flush_table()
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        st = {names[k]: {"exp_avg": m.clone(), "exp_avg_sq": v.clone()} for k, (m, v) in self.state.items() if k in names}
+        st[names[id(self.table)]] = {"exp_avg": self.table_m.clone(), "exp_avg_sq": self.table_v.clone()}
+        return {"step": int(self.step_dev.item()), "state": st,
+                "hyper": {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}}
+
+    def load_state_dict(self, sd):
+        params = dict(self.model.named_parameters())
+        self.step_dev.fill_(int(sd["step"]))
+        for n, st in sd["state"].items():
+            p = params[n]
+            if p is self.table:
+                self.table_m.copy_(st["exp_avg"])
+                self.table_v.copy_(st["exp_avg_sq"])
+            else:
+                self.state[id(p)] = (st["exp_avg"].to(self.device).clone(), st["exp_avg_sq"].to(self.device).clone())
+        if self.table_last is not None:
+            self.table_last.fill_(int(sd["step"]))
+        self._dense_sig = None

@@ -94,7 +94,7 @@ class _GradState:
 
 
 class Plan:
-    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0):
+    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0, step_dev=None, grad_arena=None):
         assert precision in ("bf16", "f32")
         self.lib = L.load()
         self.device = torch.device(device)
@@ -115,7 +115,11 @@ class Plan:
         self._param_refs = {}
         self._param_grad_set = set()
         self._op_count = 0
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # dropout stream offset
+        # device step counter: offsets the dropout stream per step (shared with the optimiser when given)
+        self.step_dev = step_dev if step_dev is not None else torch.zeros(1, dtype=torch.int32, device=self.device)
+        # optional flat fp32 arena the dense-parameter gradients are carved from (one all-reduce under DP)
+        self.grad_arena = grad_arena
+        self._arena_used = 0
         self._bn_ws = None
         self._bn_ws_need = 0
         self._rowdot_ws = None
@@ -141,7 +145,13 @@ class Plan:
     def param_grad(self, p):
         g = self.param_grads.get(id(p))
         if g is None:
-            g = torch.zeros_like(p.data)
+            n = p.numel()
+            if self.grad_arena is not None and self._arena_used + n <= self.grad_arena.numel():
+                g = self.grad_arena[self._arena_used:self._arena_used + n].view(p.shape)
+                g.zero_()
+                self._arena_used += (n + 3) // 4 * 4          # keep every slice 16-byte aligned
+            else:
+                g = torch.zeros_like(p.data)
             self.param_grads[id(p)] = g
             self._param_refs[id(p)] = p
         return g

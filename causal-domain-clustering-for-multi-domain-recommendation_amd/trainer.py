@@ -1,0 +1,121 @@
+"""Step driver of the HIP path: one training step with the reference's order of operations
+(Run.train, run.py:470-497):
+
+    pred = model(X) ; loss = BCE(pred.gather(1, group), y) ; loss += model.get_regularization_loss()
+    model.zero_grad() ; loss.backward() ; optimizer.step() ; loss.item()
+
+Here the whole step is a fixed sequence of launches (plan forward -> BCE+grad -> plan backward -> table and
+dense Adam with the L2 term folded in), replayable as ONE hipGraph.  Nothing synchronises with the host:
+`TrainStep.step()` returns device scalars; read them (loss.item()) only when you log.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .optim import FusedAdam
+
+
+class TrainStep:
+    """mode:
+         "multi"   multi-tower models (PLE / MMoE / CDC): pred = model(X).gather(1, group)        (run.py:481-484)
+         "single"  DCN / DCNv2: pred = model(X)                                                   (run.py:486-488)
+    """
+
+    def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None):
+        self.model, self.opt, self.B, self.mode = model, optimizer, int(batch_size), mode
+        self.lib = L.load()
+        self.dist = dist
+        self.world = 1 if dist is None else dist.world_size
+        self.global_B = self.B * self.world
+        dev = optimizer.device
+        self.device = dev
+        model.train()
+        # the plan shares the optimiser's step counter (dropout stream) and its flat gradient arena
+        self.holder = self._build_plan()
+        self.plan = self.holder.plan
+        self.emb = self.holder.emb_op
+        self.out = self.holder.outputs[0]
+        self.y = torch.zeros(self.B, dtype=torch.int16, device=dev)
+        self.group = torch.zeros(self.B, dtype=torch.int64, device=dev) if mode == "multi" else None
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.use_graph = use_graph
+        self.graph = None
+        self._warm = 0
+        if self.world > 1:
+            F, D = self.emb.F, self.emb.D
+            self.idx_all = torch.empty((self.global_B, F), dtype=torch.int32, device=dev)
+            self.dE_all = torch.empty((self.global_B, F * D), dtype=torch.float32, device=dev)
+
+    def _build_plan(self):
+        model, opt = self.model, self.opt
+        B = self.B
+        dev = opt.device
+        from .functional import PlanHolder
+        from . import plan as P
+
+        def build():
+            plan = P.Plan(dev, B, precision=model.precision, training=True, dropout=float(getattr(model, "dropout_p", 0.0)),
+                          seed=int(getattr(model, "seed", 0)), step_dev=opt.step_dev, grad_arena=opt.grad_arena)
+            emb = model.embedding.describe(plan)
+            outs, ins, extra = model.describe(plan, emb)
+            plan.finalize(outs)
+            return PlanHolder(plan, [emb.ids] + ins, outs, emb_op=emb, extra_outputs=extra)
+
+        return model._cache().get(model, ("train_step", id(opt)), B, build)
+
+    # ------------------------------------------------------------------------------------------
+    def _launch_all(self):
+        opt, plan, emb = self.opt, self.plan, self.emb
+        B, F, D = self.B, emb.F, emb.D
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        opt.begin_step()
+        if opt.table_mode == "lazy":
+            if self.world > 1:
+                raise NotImplementedError("lazy table mode under data parallelism")
+            opt.table_catchup(emb.ids, emb.offsets, emb.idx, B, F, D)
+        plan.forward()
+        og = self.out.grad
+        n_col = self.out.cols
+        L.check(self.lib.cdc_bce_fwd_bwd(self.out.ptr, self.out.ld, None if self.group is None else self.group.data_ptr(),
+                                         self.y.data_ptr(), None, self.loss.data_ptr(), og.ptr, og.ld, B, n_col,
+                                         1.0 / self.global_B, s), "bce_fwd_bwd")
+        plan.backward()
+        dE = emb.out.grad
+        if self.world > 1:
+            # dense gradients: one SUM all-reduce of the flat arena (the loss already carries 1/global_batch);
+            # table: every rank applies the identical update from the all-gathered (row index, row gradient) pairs
+            self.dist.all_reduce_sum(opt.grad_arena[:max(plan._arena_used, 1)])
+            self.dist.all_gather_rows(self.idx_all, emb.idx)
+            self.dist.all_gather_rows(self.dE_all, dE.root)
+            self.dist.all_reduce_sum(self.loss)
+            opt.table_step(self.idx_all, self.dE_all, self.global_B, F, D)
+        else:
+            opt.table_step(emb.idx, dE.root, B, F, D)
+        opt.dense_step(plan.param_grads, plan._param_refs)
+
+    def step(self, X, y, group=None):
+        """One training step. X int32 [B,F]; y int16/float [B] or [B,1]; group int64 [B] or [B,1] (multi mode).
+        Returns (bce_loss, reg_loss) as device tensors (no host synchronisation)."""
+        self.emb.ids.copy_(X)
+        self.y.copy_(y.reshape(-1))
+        if self.group is not None:
+            self.group.copy_(group.reshape(-1))
+        if self.use_graph and self._warm >= 2:
+            if self.graph is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch_all()
+                self.graph = g
+            self.graph.replay()
+        else:
+            self._launch_all()
+            self._warm += 1
+        return self.loss, self.opt.reg_loss()
+
+    def check_ids(self):
+        """Host-synchronising: raises IndexError like the reference if the last batch held an out-of-range id."""
+        bad = int(self.emb.err.item())
+        if bad:
+            self.emb.err.zero_()
+            raise IndexError(f"index out of range in self (flat position {bad - 1})")

@@ -58,6 +58,9 @@ int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, const float
                          float* out, int32_t* idx_out, int32_t* err_flag,
                          int64_t B, int32_t F, int32_t D, int64_t R, void* stream);
 
+/* model/layer.py:152 alone: idx_out[b,f] = ids[b,f] + offsets[f] (int32, wrapping). */
+int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out, int64_t B, int32_t F, void* stream);
+
 /* Per-field sort + dedupe of the row indices of one batch (rows of different fields never
  * collide, so each field is sorted on its own in LDS).  B <= CDC_SORT_MAX_B.
  *   idx       [B,F] int32 row indices (from cdc_embed_gather_fwd)

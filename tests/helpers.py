@@ -63,7 +63,7 @@ def is_pre_bn_bias(k, names):
     return False
 
 
-def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=None):
+def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=None, bn_active=True):
     """Gradient check per parameter (pre-BatchNorm biases only have to be negligible)."""
     names = set(all_names) if all_names is not None else set(want)
     for k, g in want.items():
@@ -72,9 +72,15 @@ def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=No
         got = named_params[k].grad
         assert got is not None, f"no gradient for {k}"
         scale = max(float(g.abs().max()), 1e-6)
-        if is_pre_bn_bias(k, names):
+        if bn_active and is_pre_bn_bias(k, names):
             wscale = float(want[k[:-5] + ".weight"].abs().max())
             assert float(got.abs().max()) <= 1e-3 * max(wscale, 1e-3) + 1e-4, f"pre-BN bias grad {k} not ~0"
             continue
-        extra = 2e-2 * scale if bf16 else 0.0
-        assert_close(got, g, rtol, atol * max(scale, 1.0) + extra, f"grad {k}")
+        if bf16:
+            # bf16 operands flip the sign of near-zero pre-activations, so single elements can move by O(1) of their
+            # value; the stated bound for the bf16 path is on the relative L2 error of each gradient tensor
+            gd, wd = got.detach().cpu().double(), g.double()
+            rel = float((gd - wd).norm() / max(float(wd.norm()), 1e-12))
+            assert rel < 8e-2 or float((gd - wd).abs().max()) < 1e-4, f"grad {k}: relative L2 error {rel:.3e} (bf16 bound 8e-2)"
+        else:
+            assert_close(got, g, rtol, atol * max(scale, 1.0), f"grad {k}")

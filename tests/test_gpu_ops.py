@@ -1,0 +1,293 @@
+"""Kernel-level parity tests through the C-ABI (plans of one op) against plain torch fp32 references.
+
+bf16 contractions are checked against the SAME arithmetic restated on the CPU: operands rounded to bf16
+(round-to-nearest-even), products accumulated in fp32 — so the bf16 path is held to fp32-accumulation
+tolerance, not to a loose "bf16 noise" bound."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import O, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _plan(cuda, B, precision="f32", training=True, dropout=0.0):
+    from cdcmdr_amd import plan as P
+    return P, P.Plan(cuda, B, precision=precision, training=training, dropout=dropout)
+
+
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,F,D,R", [(64, 7, 8, None), (1, 3, 16, None), (4096, 26, 16, None), (33, 5, 3, None)])
+def test_gather_bit_exact(cuda, B, F, D, R):
+    from cdcmdr_amd.model.layer import FeaturesEmbedding
+    rng = np.random.default_rng(B + F)
+    fd = [int(v) for v in rng.integers(1, 2000, size=F)]
+    torch.manual_seed(1)
+    emb = FeaturesEmbedding(fd, D).to(cuda)
+    x = np.stack([rng.integers(0, d, size=B) for d in fd], axis=1).astype(np.int32)
+    out = emb(torch.from_numpy(x).to(cuda), squeeze_dim=True)
+    want = O.embed(emb.embedding_dict.weight.detach().cpu(), x, fd)
+    assert torch.equal(out.cpu(), want)                                   # bit-exact row selection
+    out3 = emb(torch.from_numpy(x).to(cuda))
+    assert out3.shape == (B, F, D) and torch.equal(out3.cpu().flatten(1), want)
+
+
+def test_gather_golden_g1(cuda):
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g1_gather.npz"))
+    from cdcmdr_amd.model.layer import FeaturesEmbedding
+    emb = FeaturesEmbedding(d["field_dims"].tolist(), 8).to(cuda)
+    emb.load_state_dict({"embedding_dict.weight": torch.from_numpy(d["table"])})
+    out = emb(torch.from_numpy(d["x"]).to(cuda), squeeze_dim=True)
+    assert torch.equal(out.cpu(), torch.from_numpy(d["out"]))
+    holder = next(iter(emb._cache().plans.values()))[1]
+    assert np.array_equal(holder.emb_op.idx.cpu().numpy(), d["idx"])   # int32 index selection, bit-exact
+
+
+def test_gather_dense_grad_matches_embedding_backward(cuda):
+    from cdcmdr_amd.model.layer import FeaturesEmbedding
+    fd = [5, 3, 40, 2]                       # small vocab: many duplicate ids inside the batch
+    torch.manual_seed(0)
+    emb = FeaturesEmbedding(fd, 4).to(cuda)
+    rng = np.random.default_rng(0)
+    B = 300
+    x = np.stack([rng.integers(0, d, size=B) for d in fd], axis=1).astype(np.int32)
+    out = emb(torch.from_numpy(x).to(cuda), squeeze_dim=True)
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+    out.backward(g.to(cuda))
+    table = emb.embedding_dict.weight.detach().cpu().clone().requires_grad_(True)
+    O.embed(table, x, fd).backward(g)
+    # same ascending-batch summation order as aten::embedding_dense_backward on the CPU -> equal to the last bit
+    assert torch.equal(emb.embedding_dict.weight.grad.cpu(), table.grad)
+
+
+def test_gather_out_of_range_sets_flag(cuda):
+    from cdcmdr_amd.model.layer import FeaturesEmbedding
+    emb = FeaturesEmbedding([4, 4], 4).to(cuda)
+    x = torch.tensor([[0, 1], [3, 9]], dtype=torch.int32, device=cuda)   # 9 + 4 = 13 >= 8 rows
+    out = emb(x, squeeze_dim=True)
+    holder = next(iter(emb._cache().plans.values()))[1]
+    assert int(holder.emb_op.err.item()) == 4                             # 1 + flat position of the bad id
+    assert float(out[1, 4:].abs().max()) == 0.0
+
+
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("M,K,Ns", [(64, 24, [32, 16, 4]), (257, 416, [256, 8]), (1, 40, [7]), (130, 65, [129, 3, 64])])
+def test_glinear_fwd_bwd(cuda, precision, M, K, Ns):
+    P, plan = _plan(cuda, M, precision)
+    gen = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=gen)
+    xb = plan.new(K)
+    xb.tensor().copy_(x)
+    ws = [torch.nn.Parameter((torch.randn(n, K, generator=gen) / K ** 0.5).to(cuda)) for n in Ns]
+    bs = [torch.nn.Parameter(torch.randn(n, generator=gen).to(cuda)) for n in Ns]
+    # first group: relu; all groups share x -> grad-input reduces over the groups inside one kernel
+    op = P.GLinear(plan, [{"x": xb, "w": w, "b": b, "act_cols": (w.shape[0] if i == 0 else 0)} for i, (w, b) in enumerate(zip(ws, bs))],
+                   relu=True)
+    plan.finalize(op.outs)
+    plan.forward()
+    gouts = [torch.randn(M, n, generator=gen) for n in Ns]
+    for o, g in zip(op.outs, gouts):
+        o.grad.tensor().copy_(g)
+    # the gradient buffer of a relu-fused output holds dZ: apply the mask the consumer kernel would have applied
+    y0 = op.outs[0].tensor().cpu()
+    op.outs[0].grad.tensor().mul_((y0 > 0).float().to(cuda))
+    plan.backward()
+    rnd = _bf16_round if precision == "bf16" else (lambda t: t)
+    xr = x.clone().requires_grad_(True)
+    tot = 0
+    outs_ref = []
+    wr = [w.detach().cpu().clone().requires_grad_(True) for w in ws]
+    br = [b.detach().cpu().clone().requires_grad_(True) for b in bs]
+    for i in range(len(Ns)):
+        y = rnd(xr) @ rnd(wr[i]).t() + br[i]
+        y = torch.relu(y) if i == 0 else y
+        outs_ref.append(y)
+        tot = tot + (y * gouts[i]).sum()
+    tot.backward()
+    for i, o in enumerate(op.outs):
+        assert_close(o.tensor(), outs_ref[i], 2e-5, 2e-5, f"y{i}")
+    if precision == "f32":
+        assert_close(xb.grad.tensor(), xr.grad, 1e-4, 1e-4, "dx")
+        for i in range(len(Ns)):
+            assert_close(plan.param_grads[id(ws[i])], wr[i].grad, 1e-4, 1e-4, f"dw{i}")
+            assert_close(plan.param_grads[id(bs[i])], br[i].grad, 1e-4, 1e-4, f"db{i}")
+    else:
+        # backward contractions round THEIR operands (dZ, W, X) to bf16: restate them the same way
+        dzs = [gouts[0] * (outs_ref[0] > 0).float()] + gouts[1:]
+        dx = sum(_bf16_round(dz) @ _bf16_round(w.detach().cpu()) for dz, w in zip(dzs, ws))
+        assert_close(xb.grad.tensor(), dx, 1e-4, 1e-4, "dx")
+        for i in range(len(Ns)):
+            assert_close(plan.param_grads[id(ws[i])], _bf16_round(dzs[i]).t() @ _bf16_round(x), 1e-4, 2e-4, f"dw{i}")
+            assert_close(plan.param_grads[id(bs[i])], dzs[i].sum(0), 1e-5, 1e-4, f"db{i}")      # bias grad stays fp32
+
+
+def test_glinear_dropout_statistics_and_backward_mask(cuda):
+    P, plan = _plan(cuda, 512, "f32", training=True, dropout=0.2)
+    x = plan.new(64)
+    x.tensor().copy_(torch.rand(512, 64) + 0.5)                          # positive inputs, positive weights -> relu never clamps
+    w = torch.nn.Parameter(torch.rand(128, 64, device=cuda) / 64)
+    op = P.GLinear(plan, [{"x": x, "w": w, "b": None}], relu=True, dropout=True)
+    plan.finalize(op.outs)
+    plan.forward()
+    y = op.outs[0].tensor().cpu()
+    ref = x.tensor().cpu() @ w.detach().cpu().t()
+    kept = y != 0
+    keep_rate = kept.float().mean().item()
+    assert abs(keep_rate - 0.8) < 0.01                                   # golden g8: torch's dropout keeps 1-p
+    assert_close(y[kept], (ref / 0.8)[kept], 1e-4, 1e-5, "kept values are scaled by 1/(1-p)")
+    plan.step_dev.add_(1)                                                # next step -> a different mask
+    plan.forward()
+    y2 = op.outs[0].tensor().cpu()
+    assert ((y2 != 0) != kept).float().mean().item() > 0.2
+
+
+# --------------------------------------------------------------------------------------------------
+def test_gate_pool_fwd_bwd(cuda):
+    B, E, H = 130, 5, 24
+    P, plan = _plan(cuda, B)
+    gen = torch.Generator().manual_seed(3)
+    ex = plan.new(E * H)
+    exv = torch.randn(B, E * H, generator=gen)
+    ex.tensor().copy_(exv)
+    sels = [[0, 1, 4], [2, 3, 4], [0, 1, 2, 3, 4]]
+    lgs = []
+    for s in sels:
+        lb = plan.new(len(s))
+        lb.tensor().copy_(torch.randn(B, len(s), generator=gen))
+        lgs.append(lb)
+    op = P.GatePool(plan, ex, E, H, list(zip(lgs, sels)))
+    plan.finalize(op.outs)
+    plan.forward()
+    gouts = [torch.randn(B, H, generator=gen) for _ in sels]
+    for o, g in zip(op.outs, gouts):
+        o.grad.tensor().copy_(g)
+    plan.backward()
+    exr = exv.clone().requires_grad_(True)
+    lr = [l.tensor().cpu().clone().requires_grad_(True) for l in lgs]
+    tot = 0
+    for i, s in enumerate(sels):
+        p = torch.softmax(lr[i], dim=1)
+        cat = exr.view(B, E, H)[:, s, :]
+        out = (p.unsqueeze(-1) * cat).sum(1)
+        assert_close(op.outs[i].tensor(), out, 1e-5, 1e-6, f"pool out {i}")
+        tot = tot + (out * gouts[i]).sum()
+    tot.backward()
+    assert_close(ex.grad.tensor(), exr.grad, 1e-5, 1e-6, "d experts")
+    for i in range(len(sels)):
+        assert_close(lgs[i].grad.tensor(), lr[i].grad, 1e-4, 1e-6, f"d logits {i}")
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("M", [1, 2, 64, 200])
+def test_batchnorm_fwd_bwd(cuda, training, M):
+    P, plan = _plan(cuda, M, training=training)
+    gen = torch.Generator().manual_seed(M)
+    Cs = [70, 8]
+    bns = [torch.nn.BatchNorm1d(c).to(cuda) for c in Cs]
+    for bn in bns:
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_()
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 2.0)
+    xs = [torch.randn(M, c, generator=gen) * 2 + 1 for c in Cs]
+    segs = []
+    for xv, bn in zip(xs, bns):
+        xb = plan.new(xv.shape[1])
+        xb.tensor().copy_(xv)
+        segs.append({"x": xb, "gamma": bn.weight, "beta": bn.bias, "gamma_param": bn.weight, "beta_param": bn.bias,
+                     "running_mean": bn.running_mean, "running_var": bn.running_var,
+                     "num_batches_tracked": bn.num_batches_tracked})
+    refs = [torch.nn.BatchNorm1d(c) for c in Cs]
+    for r, bn in zip(refs, bns):
+        r.load_state_dict({k: v.cpu() for k, v in bn.state_dict().items()})
+        r.train(training)
+    op = P.BatchNorm(plan, segs, relu=True, dropout=False)
+    plan.finalize(op.outs)
+    plan.forward()
+    gouts = [torch.randn(M, c, generator=gen) for c in Cs]
+    for o, g in zip(op.outs, gouts):
+        o.grad.tensor().copy_(g)
+    plan.backward()
+    for i, (r, xv) in enumerate(zip(refs, xs)):
+        xr = xv.clone().requires_grad_(True)
+        y = torch.relu(xr if M == 1 else r(xr))                 # the reference skips BatchNorm for one row
+        (y * gouts[i]).sum().backward()
+        assert_close(op.outs[i].tensor(), y, 1e-4, 1e-5, f"bn out {i}")
+        assert_close(segs[i]["x"].grad.tensor(), xr.grad, 2e-4, 2e-5, f"bn dx {i}")
+        if M > 1:
+            assert_close(plan.param_grads[id(bns[i].weight)], r.weight.grad, 2e-4, 2e-5, f"dgamma {i}")
+            assert_close(plan.param_grads[id(bns[i].bias)], r.bias.grad, 2e-4, 2e-5, f"dbeta {i}")
+            assert_close(bns[i].running_mean, r.running_mean, 1e-5, 1e-6, "running_mean")
+            assert_close(bns[i].running_var, r.running_var, 1e-5, 1e-6, "running_var")
+            assert int(bns[i].num_batches_tracked) == int(r.num_batches_tracked)
+        else:
+            assert int(bns[i].num_batches_tracked) == 0
+
+
+def test_rowdot_towers_with_addend(cuda):
+    B, K = 100, 33
+    P, plan = _plan(cuda, B)
+    gen = torch.Generator().manual_seed(9)
+    xs = [torch.randn(B, K, generator=gen) for _ in range(3)]
+    bufs = []
+    for xv in xs:
+        b = plan.new(K)
+        b.tensor().copy_(xv)
+        bufs.append(b)
+    wide_in = plan.new(K)
+    wide_in.tensor().copy_(torch.randn(B, K, generator=gen))
+    lin_w = torch.nn.Linear(K, 1).to(cuda)
+    wide = P.RowDot(plan, [{"x": wide_in, "w": lin_w.weight, "b": lin_w.bias}])
+    lins = [torch.nn.Linear(K, 1).to(cuda) for _ in range(3)]
+    out = plan.new(3)
+    op = P.RowDot(plan, [{"x": b, "w": l.weight, "b": l.bias, "out": out.slice(i, i + 1)} for i, (b, l) in enumerate(zip(bufs, lins))],
+                  addends=[wide.outs[0]], sigmoid=True)
+    plan.finalize([out])
+    plan.forward()
+    g = torch.randn(B, 3, generator=gen)
+    out.grad.tensor().copy_(g)
+    plan.backward()
+    xr = [xv.clone().requires_grad_(True) for xv in xs]
+    wr = wide_in.tensor().cpu().clone().requires_grad_(True)
+    lw = torch.nn.Linear(K, 1)
+    lw.load_state_dict({k: v.cpu() for k, v in lin_w.state_dict().items()})
+    refl = []
+    for l in lins:
+        r = torch.nn.Linear(K, 1)
+        r.load_state_dict({k: v.cpu() for k, v in l.state_dict().items()})
+        refl.append(r)
+    wl = lw(wr)
+    y = torch.cat([torch.sigmoid(refl[i](xr[i]) + wl) for i in range(3)], dim=1)
+    (y * g).sum().backward()
+    assert_close(out.tensor(), y, 1e-5, 1e-6, "towers out")
+    for i in range(3):
+        assert_close(bufs[i].grad.tensor(), xr[i].grad, 1e-4, 1e-6, f"dx{i}")
+        assert_close(plan.param_grads[id(lins[i].weight)], refl[i].weight.grad, 1e-4, 1e-5, f"dw{i}")
+        assert_close(plan.param_grads[id(lins[i].bias)], refl[i].bias.grad, 1e-4, 1e-5, f"db{i}")
+    assert_close(wide_in.grad.tensor(), wr.grad, 1e-4, 1e-6, "d wide in")
+    assert_close(plan.param_grads[id(lin_w.weight)], lw.weight.grad, 1e-4, 1e-5, "d wide w")
+    assert_close(plan.param_grads[id(lin_w.bias)], lw.bias.grad, 1e-4, 1e-5, "d wide b")
+
+
+def test_bce_golden_g7(cuda):
+    import ctypes as C
+    import os
+    from cdcmdr_amd import _lib as L
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_bce.npz"))
+    lib = L.load()
+    p = torch.from_numpy(d["p"]).to(cuda).reshape(-1, 1).contiguous()
+    y = torch.from_numpy(d["y"]).to(cuda).contiguous()
+    n = p.shape[0]
+    loss = torch.zeros(1, device=cuda)
+    dp = torch.empty_like(p)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.cdc_bce_fwd_bwd(p.data_ptr(), 1, None, None, y.data_ptr(), loss.data_ptr(), dp.data_ptr(), 1, n, 1, 1.0 / n, s), "bce")
+    assert_close(loss, d["loss"].reshape(1), 1e-6, 1e-6, "bce loss incl. the -100 clamp")
+    assert_close(dp.reshape(-1), d["dp"], 1e-5, 0.0, "bce gradient incl. the 1e-12 clamp")
