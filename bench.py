@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""Headline benchmark of the HIP hot path: PLE 3-domain training step (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one full training step of run.py:481-493 (forward, BCE, L2 term over every registered tensor incl. the
+whole embedding table, backward, Adam on every parameter) on one resident synthetic batch.  Prints ONE JSON line.
+`roofline` is for the dominant kernel of the step, timed with HIP events on the launch stream; `cpu_baseline` is the
+CPU oracle (reference semantics, stock torch CPU ops) timed on this host's cores on a bounded sample (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+METRIC = "train samples/sec + AUC parity, PLE 3-domain batch 4096 at 1/2/4/8 MI355X"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--fields", type=int, default=26)
+    ap.add_argument("--vocab", type=int, default=1_000_000)
+    ap.add_argument("--embed-dim", type=int, default=16)
+    ap.add_argument("--dropout", type=float, default=0.2, help="reference default (ple.py:17)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--table-mode", default="lazy", choices=["dense", "lazy"])
+    ap.add_argument("--graph", type=int, default=1, help="replay the step as one hipGraph (single GPU)")
+    ap.add_argument("--id-dist", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--pool", type=int, default=32, help="resident synthetic batches cycled through")
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    from cdcmdr_amd.model.ple import PLE
+    torch.manual_seed(2000)
+    field_dims = [args.vocab] * args.fields
+    with torch.device(device):
+        model = PLE(field_dims, args.embed_dim, 3, 2, 2, ((256, 128), (64,)), (64, 32), dropout=args.dropout)
+    model.set_precision(args.precision)
+    return model, field_dims
+
+
+def cpu_baseline(args, model, field_dims, Xc, yc, gc):
+    """The oracle restatement of the reference step on the host cores: dense table gradient, whole-table L2,
+    dense torch.optim.Adam — exactly what run.py:481-493 makes torch do."""
+    from oracle import cdc_oracle as O
+    n_threads = os.cpu_count() or 1
+    torch.set_num_threads(n_threads)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    sd.update(leaves)
+    l2 = {n: 1e-5 for n in O.reg_names(list(sd), "ple")}
+    opt = torch.optim.Adam(list(leaves.values()), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    O.DROPOUT_P = args.dropout
+    B = args.batch
+    times = []
+    for s in range(1 + args.cpu_steps):
+        x = Xc[s % len(Xc)]
+        y = torch.from_numpy(yc[s % len(yc)])
+        g = torch.from_numpy(gc[s % len(gc)]).reshape(-1, 1)
+        t0 = time.perf_counter()
+        stats = {}
+        p = O.ple_forward(sd, x, field_dims, 3, training=True, stats_out=stats).gather(1, g).squeeze(1)
+        loss = O.bce_mean(p, y) + O.reg_loss(sd, l2)
+        opt.zero_grad()
+        loss.sum().backward()
+        opt.step()
+        float(loss.sum())                                    # loss.item() as run.py:493
+        for k, v in stats.items():
+            sd[k] = v
+        times.append(time.perf_counter() - t0)
+    O.DROPOUT_P = 0.0
+    t = float(np.mean(times[1:]))
+    return {"value": B / t, "unit": "samples/s", "cores": n_threads, "kind": "port",
+            "sample": f"{args.cpu_steps} steps of batch {B} after 1 warm-up, same shapes, weights copied from the GPU model "
+                      f"({t * 1e3:.0f} ms/step)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    from cdcmdr_amd.dist import DataParallel
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.synth import make_dataset
+    from cdcmdr_amd.trainer import TrainStep
+    dp = DataParallel() if world > 1 else None
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    model, field_dims = build_model(args, device)
+    table_mode = args.table_mode
+    use_graph = bool(args.graph) and world == 1
+    if world > 1 and table_mode == "lazy":
+        table_mode = "dense"                                   # lazy replay under DP is a next-round item
+    opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode)
+    ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dp)
+
+    B = args.batch
+    n_rows = B * args.pool * world
+    X, y = make_dataset(n_rows, field_dims, n_domain=3, domain_idx=10, seed=2000, dist=args.id_dist)
+    lo = rank * B * args.pool
+    Xr, yr = X[lo:lo + B * args.pool], y[lo:lo + B * args.pool]
+    gr = Xr[:, 10].astype(np.int64)                            # identity domain -> tower map (3-domain PLE)
+    Xd = torch.from_numpy(Xr).to(device).view(args.pool, B, -1)
+    yd = torch.from_numpy(yr).to(device).view(args.pool, B)
+    gd = torch.from_numpy(gr).to(device).view(args.pool, B)
+
+    def run(n, first=0):
+        for i in range(n):
+            j = (first + i) % args.pool
+            ts.step(Xd[j], yd[j], gd[j])
+
+    run(args.warmup)
+    if dp:
+        dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    elapsed = time.perf_counter() - t0
+    if dp:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dp.all_reduce_max(tmax)
+        elapsed = float(tmax.item())
+    loss_val = float(ts.loss.item())
+
+    # ---- roofline of the dominant kernel, HIP events on the launch stream (instrumented eager steps) ----------
+    roof = measure_roofline(args, ts, opt, Xd, yd, gd)
+
+    cpu = None
+    if args.cpu_baseline and world == 1 and rank == 0:
+        Xc = [Xr[i * B:(i + 1) * B] for i in range(min(args.pool, 1 + args.cpu_steps))]
+        yc = [yr[i * B:(i + 1) * B].astype(np.float32) for i in range(len(Xc))]
+        gc = [gr[i * B:(i + 1) * B] for i in range(len(Xc))]
+        opt.flush_table()
+        cpu = cpu_baseline(args, model, field_dims, Xc, yc, gc)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": METRIC, "value": B * world * args.steps / elapsed, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "PLE 3-domain full training step (fwd + BCE + whole-table L2 + bwd + Adam), "
+                                   f"{args.fields} fields x vocab {args.vocab}, emb_dim={args.embed_dim}, batch {B}/GPU",
+                       "global_batch": B * world, "dropout": args.dropout, "table_mode": table_mode,
+                       "hip_graph": use_graph, "id_dist": args.id_dist, "parallelism": f"dp{world}",
+                       "last_bce_loss": loss_val},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dp:
+        dp.close()
+
+
+def measure_roofline(args, ts, opt, Xd, yd, gd):
+    """Per-launch HIP-event timing of instrumented eager steps (same launches as the timed region, which may be
+    replayed as a graph where events cannot be placed).  The roofline object is for the step's dominant kernel."""
+    batches = [(Xd[i], yd[i], gd[i]) for i in range(len(Xd))]
+    prof = ts.profile(batches, n_steps=12, skip=2)
+    total = sum(v["ms_per_step"] for v in prof.values())
+    top = sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])
+    name, d = top[0]
+    breakdown = {k: round(v["ms_per_step"], 4) for k, v in top[:8]}
+    per_launch_ms = d["ms_per_step"] / max(d["launches_per_step"], 1e-9)
+    if d["flops_per_step"] > 0:
+        achieved = d["flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_step": d["flops_per_step"]}
+    else:
+        nbytes = d["bytes_per_step"]
+        achieved = nbytes / (d["ms_per_step"] * 1e-3) / 1e9 if nbytes else None
+        roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": nbytes}
+    roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": None,
+                 "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown})
+    # all MFMA launches together (north-star figure: expert GEMMs vs bf16 peak)
+    gm = [v for k, v in prof.items() if "glinear" in k]
+    if gm:
+        fl = sum(v["flops_per_step"] for v in gm)
+        ms = sum(v["ms_per_step"] for v in gm)
+        roof["all_gemm_tflops"] = fl / (ms * 1e-3) / 1e12
+        roof["all_gemm_ms_per_step"] = ms
+    g = prof.get("cdc_embed_gather_fwd")
+    if g:
+        B, F, D = ts.B, ts.emb.F, ts.emb.D
+        gb = B * F * (D * 4 + 4 + D * 4)
+        roof["gather_GBps"] = gb / (g["ms_per_step"] * 1e-3) / 1e9
+    return roof
+
+
+if __name__ == "__main__":
+    main()

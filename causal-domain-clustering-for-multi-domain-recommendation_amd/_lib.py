@@ -226,3 +226,25 @@ def check(rc, what):
     if rc != 0:
         msg = load().cdc_last_error()
         raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py / tools): HIP events on the launch stream around every C-ABI call
+# ---------------------------------------------------------------------------------------------------------
+PROFILE = None      # None, or a list receiving (name, start_event, end_event, flops, bytes)
+
+
+def launch(name, fn, args, stream, flops=0.0, nbytes=0.0):
+    """Calls fn(*args, stream); with PROFILE set, brackets it with timing events recorded on the current stream
+    (the one every launch of this package goes to)."""
+    if PROFILE is None:
+        rc = fn(*args, stream)
+    else:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args, stream)
+        e1.record()
+        PROFILE.append((name, e0, e1, flops, nbytes))
+    if rc != 0:
+        check(rc, name)

@@ -1,0 +1,63 @@
+"""Data parallelism for the training step: one process per GPU, torch.distributed over RCCL ("nccl" backend on ROCm;
+"gloo" for the CPU rehearsal of the same call pattern in tests).
+
+The reference has no multi-device code at all; the exchange pattern is this build's:
+  * samples shard across ranks (global batch = world_size x local batch, BCE mean over the GLOBAL batch);
+  * dense gradients: ONE sum all-reduce of the flat gradient arena per step;
+  * embedding table (replicated): all-gather of the (row index, row gradient) pairs, then every rank applies the
+    identical table update — no divergence, no table broadcast.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, backend=None, device=None):
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        self.backend = backend
+        if self.world_size > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group(backend, device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend)
+        self.device = device
+
+    def all_reduce_sum(self, t):
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def all_reduce_max(self, t):
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
+
+    def all_gather_rows(self, out, local):
+        """out [world*B, C] <- concat over ranks of local [B, C] (rank order)."""
+        if self.world_size > 1:
+            dist.all_gather_into_tensor(out, local.contiguous())
+        else:
+            out.copy_(local)
+        return out
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier()
+
+    def shard(self, n):
+        """contiguous [begin, end) of n items owned by this rank."""
+        per = n // self.world_size
+        return self.rank * per, (self.rank + 1) * per
+
+    def close(self):
+        if self.world_size > 1 and dist.is_initialized():
+            dist.destroy_process_group()

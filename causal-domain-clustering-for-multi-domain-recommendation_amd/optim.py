@@ -100,24 +100,25 @@ class FusedAdam:
     def begin_step(self):
         """++step and clear the regularisation accumulators (call before the forward of the step)."""
         s = self._stream()
-        L.check(self.lib.cdc_step_increment(self.step_dev.data_ptr(), s), "step_increment")
-        L.check(self.lib.cdc_fill_f64(self.reg_sum.data_ptr(), 0.0, 2, s), "fill_f64")
+        L.launch("cdc_step_increment", self.lib.cdc_step_increment, (self.step_dev.data_ptr(),), s)
+        L.launch("cdc_fill_f64", self.lib.cdc_fill_f64, (self.reg_sum.data_ptr(), 0.0, 2), s)
 
     def sort_rows(self, idx, B, F, D):
         ws = self._workspace(B, F, D)
-        L.check(self.lib.cdc_embed_sort_dedupe(idx.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(),
-                                               ws["cnt"].data_ptr(), B, F, self._stream()), "embed_sort_dedupe")
+        L.launch("cdc_embed_sort_dedupe", self.lib.cdc_embed_sort_dedupe,
+                 (idx.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), B, F),
+                 self._stream())
         return ws
 
     def table_catchup(self, ids, offsets, idx, B, F, D):
         """lazy mode, BEFORE the gather of this step: row indices -> dedupe -> replay the rows up to step t-1."""
         assert self.table_mode == "lazy"
         s = self._stream()
-        L.check(self.lib.cdc_embed_index(ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), B, F, s), "embed_index")
+        L.launch("cdc_embed_index", self.lib.cdc_embed_index, (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), B, F), s)
         ws = self.sort_rows(idx, B, F, D)
-        L.check(self.lib.cdc_embed_lazy_catchup(ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(),
-                                                self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-                                                self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D, s), "embed_lazy_catchup")
+        L.launch("cdc_embed_lazy_catchup", self.lib.cdc_embed_lazy_catchup,
+                 (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(), self.table_m.data_ptr(),
+                  self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D), s)
 
     def table_step(self, idx, d_out, B, F, D):
         """Adam step t on the table from the batch's row indices [B,F] and the gradient of the gathered rows [B,F*D]."""
@@ -126,26 +127,28 @@ class FusedAdam:
         w, m, v = self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr()
         if self.table_mode == "dense":
             ws = self.sort_rows(idx, B, F, D)
-            L.check(self.lib.cdc_embed_adam_touched(d_out.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(),
-                                                    ws["cnt"].data_ptr(), w, m, v, ws["side"].data_ptr(), hp, self.step_dev.data_ptr(),
-                                                    B, F, D, s), "embed_adam_touched")
-            L.check(self.lib.cdc_embed_adam_dense_pass(w, m, v, self.table.numel(), hp, self.step_dev.data_ptr(),
-                                                       self.reg_sum.data_ptr() + 8, s), "embed_adam_dense_pass")
-            L.check(self.lib.cdc_embed_adam_patch(ws["side"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), w, m, v, B, F, D, s),
-                    "embed_adam_patch")
+            L.launch("cdc_embed_adam_touched", self.lib.cdc_embed_adam_touched,
+                     (d_out.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(),
+                      w, m, v, ws["side"].data_ptr(), hp, self.step_dev.data_ptr(), B, F, D), s)
+            L.launch("cdc_embed_adam_dense_pass", self.lib.cdc_embed_adam_dense_pass,
+                     (w, m, v, self.table.numel(), hp, self.step_dev.data_ptr(), self.reg_sum.data_ptr() + 8), s,
+                     nbytes=24.0 * self.table.numel())
+            L.launch("cdc_embed_adam_patch", self.lib.cdc_embed_adam_patch,
+                     (ws["side"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), w, m, v, B, F, D), s)
         else:
             ws = self._workspace(B, F, D)        # rows were sorted by table_catchup of this step
-            L.check(self.lib.cdc_embed_lazy_update(d_out.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(),
-                                                   ws["cnt"].data_ptr(), w, m, v, self.table_last.data_ptr(), hp,
-                                                   self.step_dev.data_ptr(), None, 0, B, F, D, s), "embed_lazy_update")
+            L.launch("cdc_embed_lazy_update", self.lib.cdc_embed_lazy_update,
+                     (d_out.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(),
+                      w, m, v, self.table_last.data_ptr(), hp, self.step_dev.data_ptr(), None, 0, B, F, D), s)
 
     def flush_table(self):
         """lazy mode: bring every row to the current step (needed before state_dict / eval / reading the table)."""
         if self.table_mode != "lazy":
             return
-        L.check(self.lib.cdc_embed_lazy_flush(self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(),
-                                              self.table_last.data_ptr(), self.table.shape[0], self.table.shape[1], self._hp(),
-                                              self.step_dev.data_ptr(), 0, None, 0, self._stream()), "embed_lazy_flush")
+        L.launch("cdc_embed_lazy_flush", self.lib.cdc_embed_lazy_flush,
+                 (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
+                  self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), 0, None, 0), self._stream(),
+                 nbytes=24.0 * self.table.numel())
 
     # ------------------------------------------------------------------------------------------
     def dense_step(self, param_grads, param_refs):
@@ -181,7 +184,7 @@ class FusedAdam:
             self._dense_args, self._dense_sig = args, sig
         s = self._stream()
         for a in self._dense_args:
-            L.check(self.lib.cdc_adam_multi(C.byref(a), s), "adam_multi")
+            L.launch("cdc_adam_multi", self.lib.cdc_adam_multi, (C.byref(a),), s)
 
     def reg_loss(self):
         """device double: the step's regularisation term sum(l2*w^2) (dense params + table). In lazy mode the table

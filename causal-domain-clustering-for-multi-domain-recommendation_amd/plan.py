@@ -209,14 +209,12 @@ class Plan:
         for fn in self.bwd_steps:
             fn(s)
 
-    def call(self, fn_name, *args, what=None):
+    def call(self, fn_name, *args, what=None, flops=0.0, nbytes=0.0):
         fn = getattr(self.lib, fn_name)
         what = what or fn_name
 
         def run(stream):
-            rc = fn(*args, stream)
-            if rc != 0:
-                L.check(rc, what)
+            L.launch(what, fn, args, stream, flops, nbytes)
         return run
 
 
@@ -301,7 +299,8 @@ class GLinear:
                 G.M, G.N, G.K = self.M, N, K
                 G.act_cols = g["act_cols"]
             self._keep = getattr(self, "_keep", []) + [a]
-            plan.fwd_steps.append(plan.call("cdc_glinear_fwd", C.byref(a), plan.prec))
+            fl = sum(2.0 * self.M * g["w"].shape[0] * g["w"].shape[1] for g in chunk)
+            plan.fwd_steps.append(plan.call("cdc_glinear_fwd", C.byref(a), plan.prec, flops=fl))
 
     def build_bwd(self, plan, gs):
         # dZ of every group lives in y.grad (pre-activation gradient, see module docstring)
@@ -332,7 +331,8 @@ class GLinear:
                 G.M, G.N, G.K = self.M, N, K
                 G.accumulate = 1 if acc_w else 0
             self._keep.append(a)
-            plan.bwd_steps.append(plan.call("cdc_glinear_bwd_w", C.byref(a), plan.prec))
+            fl = sum(2.0 * self.M * g["w"].shape[0] * g["w"].shape[1] for g in chunk)
+            plan.bwd_steps.append(plan.call("cdc_glinear_bwd_w", C.byref(a), plan.prec, flops=fl))
         # ---- grad-input: groups reading the same x reduce into one output
         outs = []      # list of (x Buf, [group indices])
         for gi, g in enumerate(self.groups):
@@ -392,7 +392,8 @@ class GLinear:
                     si += 1
             a.n_seg = si
             self._keep.append(a)
-            plan.bwd_steps.append(plan.call("cdc_glinear_bwd_x", C.byref(a), plan.prec))
+            fl = sum(2.0 * self.M * self.groups[gi]["w"].shape[0] * self.groups[gi]["w"].shape[1] for _, gis in la for gi in gis)
+            plan.bwd_steps.append(plan.call("cdc_glinear_bwd_x", C.byref(a), plan.prec, flops=fl))
 
 
 class GatePool:

@@ -77,9 +77,9 @@ class TrainStep:
         plan.forward()
         og = self.out.grad
         n_col = self.out.cols
-        L.check(self.lib.cdc_bce_fwd_bwd(self.out.ptr, self.out.ld, None if self.group is None else self.group.data_ptr(),
-                                         self.y.data_ptr(), None, self.loss.data_ptr(), og.ptr, og.ld, B, n_col,
-                                         1.0 / self.global_B, s), "bce_fwd_bwd")
+        L.launch("cdc_bce_fwd_bwd", self.lib.cdc_bce_fwd_bwd,
+                 (self.out.ptr, self.out.ld, None if self.group is None else self.group.data_ptr(), self.y.data_ptr(), None,
+                  self.loss.data_ptr(), og.ptr, og.ld, B, n_col, 1.0 / self.global_B), s)
         plan.backward()
         dE = emb.out.grad
         if self.world > 1:
@@ -112,6 +112,33 @@ class TrainStep:
             self._launch_all()
             self._warm += 1
         return self.loss, self.opt.reg_loss()
+
+    def profile(self, batches, n_steps=10, skip=2):
+        """Per-launch timing of `n_steps` eager steps (HIP events on the launch stream).  Returns
+        {name: {"ms_per_step", "launches_per_step", "flops_per_step", "bytes_per_step"}}."""
+        was_graph, self.use_graph = self.use_graph, False
+        rec = []
+        L.PROFILE = rec
+        try:
+            marks = []
+            for i in range(n_steps):
+                marks.append(len(rec))
+                b = batches[i % len(batches)]
+                self.step(*b)
+            torch.cuda.synchronize()
+        finally:
+            L.PROFILE = None
+            self.use_graph = was_graph
+        out = {}
+        start = marks[skip] if len(marks) > skip else 0
+        used = n_steps - skip if len(marks) > skip else n_steps
+        for name, e0, e1, fl, nb in rec[start:]:
+            d = out.setdefault(name, {"ms_per_step": 0.0, "launches_per_step": 0.0, "flops_per_step": 0.0, "bytes_per_step": 0.0})
+            d["ms_per_step"] += e0.elapsed_time(e1) / used
+            d["launches_per_step"] += 1.0 / used
+            d["flops_per_step"] += fl / used
+            d["bytes_per_step"] += nb / used
+        return out
 
     def check_ids(self):
         """Host-synchronising: raises IndexError like the reference if the last batch held an out-of-range id."""

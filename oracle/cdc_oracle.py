@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+DROPOUT_P = 0.0     # parity runs use 0; bench.py's cpu_baseline sets the reference default (0.2) to time the same work
 
 
 # --------------------------------------------------------------------------------------------------
@@ -99,6 +100,8 @@ def mlp(x, sd, prefix, training, stats_out=None, output_layer=False):
         if k + 1 < len(layers) and layers[k + 1][1] == 1 and x.shape[0] != 1:
             y = _bn(y, sd, f"{prefix}.layers.{layers[k + 1][0]}", training, stats_out)
         x = torch.relu(y)
+        if DROPOUT_P > 0 and training:
+            x = F.dropout(x, DROPOUT_P, True)
     return x
 
 
