@@ -62,7 +62,8 @@ class BwdwGroup(C.Structure):
 
 
 class LinBwdwArgs(C.Structure):
-    _fields_ = [("n_groups", c_i32), ("row_offsets", c_p), ("g", BwdwGroup * MAX_GROUPS)]
+    _fields_ = [("n_groups", c_i32), ("split_k", c_i32), ("workspace", c_p), ("row_offsets", c_p),
+                ("g", BwdwGroup * MAX_GROUPS)]
 
 
 class PoolFwdGate(C.Structure):
@@ -93,7 +94,7 @@ class BnSeg(C.Structure):
 
 
 class BnFwdArgs(C.Structure):
-    _fields_ = [("n_seg", c_i32), ("training", c_i32), ("relu", c_i32), ("eps", c_f), ("momentum", c_f),
+    _fields_ = [("n_seg", c_i32), ("training", c_i32), ("relu", c_i32), ("skip_le1", c_i32), ("eps", c_f), ("momentum", c_f),
                 ("drop_p", c_f), ("seed", C.c_uint64), ("seed_offset_dev", c_p), ("M", c_i64),
                 ("row_offsets", c_p), ("workspace", c_p), ("s", BnSeg * MAX_BN_SEGS)]
 
@@ -101,7 +102,7 @@ class BnFwdArgs(C.Structure):
 class BnBSeg(C.Structure):
     _fields_ = [("dy", c_p), ("lddy", c_i64), ("y", c_p), ("ldy", c_i64), ("x", c_p), ("ldx", c_i64),
                 ("dx", c_p), ("lddx", c_i64), ("gamma", c_p), ("save_mean", c_p), ("save_invstd", c_p),
-                ("dgamma", c_p), ("dbeta", c_p), ("C", c_i32), ("row_group", c_i32)]
+                ("dgamma", c_p), ("dbeta", c_p), ("C", c_i32), ("row_group", c_i32), ("accumulate_dx", c_i32), ("pad_", c_i32)]
 
 
 class BnBwdArgs(C.Structure):
@@ -130,6 +131,11 @@ class RowdotBwdArgs(C.Structure):
                 ("g", RowdotBGroup * MAX_GROUPS)]
 
 
+class StarFuseArgs(C.Structure):
+    _fields_ = [("n", c_i32), ("op", c_i32), ("size", c_i64), ("s", c_p), ("ds", c_p), ("accumulate_ds", c_i32), ("pad_", c_i32),
+                ("a", c_p * MAX_GROUPS), ("out", c_p * MAX_GROUPS), ("da", c_p * MAX_GROUPS)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("w", c_p), ("g", c_p), ("m", c_p), ("v", c_p), ("n", c_i64), ("l2", c_f)]
 
@@ -147,12 +153,13 @@ _SIGNATURES = {
     "cdc_embed_gather_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
     "cdc_embed_index": (c_i32, [c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
-    "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
-    "cdc_embed_adam_touched": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32, c_p]),
+    "cdc_embed_segment_sum": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
+    "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
+    "cdc_embed_adam_touched": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_adam_dense_pass": (c_i32, [c_p, c_p, c_p, c_i64, AdamHP, c_p, c_p, c_p]),
     "cdc_embed_adam_patch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_catchup": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
-    "cdc_embed_lazy_update": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
+    "cdc_embed_lazy_update": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_p, c_i32, c_p]),
     "cdc_glinear_fwd": (c_i32, [C.POINTER(LinFwdArgs), c_i32, c_p]),
     "cdc_glinear_bwd_x": (c_i32, [C.POINTER(LinBwdxArgs), c_i32, c_p]),
@@ -166,6 +173,16 @@ _SIGNATURES = {
     "cdc_bce_fwd_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f, c_p]),
     "cdc_cross_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i32, c_p]),
     "cdc_cross_bwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "cdc_tanh_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_p]),
+    "cdc_tanh_bwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
+    "cdc_cross_combine_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
+    "cdc_cross_combine_bwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i32,
+                                      c_p, c_i32, c_p, c_i32, c_p, c_i64, c_i32, c_i32, c_p]),
+    "cdc_add_out": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_p]),
+    "cdc_copy_or_add": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
+    "cdc_star_fuse_fwd": (c_i32, [C.POINTER(StarFuseArgs), c_p]),
+    "cdc_star_fuse_bwd": (c_i32, [C.POINTER(StarFuseArgs), c_p]),
+    "cdc_sum_slices": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_adam_multi": (c_i32, [C.POINTER(AdamArgs), c_p]),
     "cdc_step_increment": (c_i32, [c_p, c_p]),
     "cdc_fill_f32": (c_i32, [c_p, c_f, c_i64, c_p]),

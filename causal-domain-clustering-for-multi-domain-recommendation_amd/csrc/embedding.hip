@@ -161,10 +161,61 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-row gradient: rowgrad[f, j, :] = sum over the segment of unique row j of d_out[b, f*D:(f+1)*D]
+// Two launches so that skewed fields (a domain column has a handful of rows, each thousands of entries long)
+// do not serialise on dependent random loads: (1) the batch gradient rows are gathered into sorted order
+// (fully parallel random reads), (2) every (row, d) sums its now CONTIGUOUS segment in ascending batch order —
+// the order aten::embedding_dense_backward uses on the CPU.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_sorted_gather(const float* __restrict__ d_out, const int32_t* __restrict__ perm,
+                                                       float* __restrict__ sorted, int32_t B, int32_t F, int32_t D) {
+    const int64_t total = (int64_t)F * B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t pos = i / D;                 // f * B + sorted position
+        const int f = (int)(pos / B);
+        sorted[i] = d_out[((int64_t)perm[pos] * F + f) * D + d];
+    }
+}
+__global__ void __launch_bounds__(256) k_segment_sum(const float* __restrict__ sorted, const int32_t* __restrict__ seg_start,
+                                                     const int32_t* __restrict__ uniq_cnt, float* __restrict__ rowgrad,
+                                                     int32_t B, int32_t F, int32_t D) {
+    const int64_t total = (int64_t)F * B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t slot = i / D;
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+        const int k0 = sst[j], k1 = sst[j + 1];
+        const float* src = sorted + ((int64_t)f * B + k0) * D + d;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < k1 - k0; ++k) acc = __fadd_rn(acc, src[(int64_t)k * D]);
+        rowgrad[i] = acc;
+    }
+}
+
+extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_start, const int32_t* perm,
+                                     const int32_t* uniq_cnt, float* sorted_scratch, float* rowgrad, int64_t B, int32_t F,
+                                     int32_t D, void* stream) {
+    CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && sorted_scratch && rowgrad, CDC_E_BADARG, "embed_segment_sum: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_B, CDC_E_BADARG, "embed_segment_sum: bad sizes");
+    const int64_t total = (int64_t)F * B * D;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 32);
+    hipLaunchKernelGGL(k_sorted_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, perm, sorted_scratch, (int32_t)B, F, D);
+    CDC_LAUNCH_CHECK("embed_sorted_gather");
+    hipLaunchKernelGGL(k_segment_sum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sorted_scratch, seg_start, uniq_cnt, rowgrad,
+                       (int32_t)B, F, D);
+    CDC_LAUNCH_CHECK("embed_segment_sum");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // dense gradient (drop-in path: feeds torch.optim.Adam like aten::embedding_dense_backward)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_grad_dense(const float* __restrict__ d_out, const int32_t* __restrict__ uniq_row,
-                                                    const int32_t* __restrict__ seg_start, const int32_t* __restrict__ perm,
+__global__ void __launch_bounds__(256) k_grad_dense(const float* __restrict__ rowgrad, const int32_t* __restrict__ uniq_row,
                                                     const int32_t* __restrict__ uniq_cnt, float* __restrict__ grad,
                                                     int32_t B, int32_t F, int32_t D, int64_t R) {
     const int64_t total = (int64_t)F * B * D;
@@ -174,25 +225,20 @@ __global__ void __launch_bounds__(256) k_grad_dense(const float* __restrict__ d_
         const int f = (int)(slot / B);
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
-        const int32_t row = uniq_row[(int64_t)f * B + j];
+        const int32_t row = uniq_row[slot];
         if (row < 0 || (int64_t)row >= R) continue;
-        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
-        const int32_t* prm = perm + (int64_t)f * B;
-        float acc = 0.f;
-        for (int k = sst[j]; k < sst[j + 1]; ++k) acc += d_out[((int64_t)prm[k] * F + f) * D + d];
-        grad[(int64_t)row * D + d] += acc;
+        grad[(int64_t)row * D + d] += rowgrad[i];
     }
 }
 
-extern "C" int cdc_embed_grad_dense(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
-                                    const int32_t* perm, const int32_t* uniq_cnt, float* grad, int64_t B, int32_t F,
-                                    int32_t D, int64_t R, void* stream) {
-    CDC_CHECK_ARG(d_out && uniq_row && seg_start && perm && uniq_cnt && grad, CDC_E_BADARG, "embed_grad_dense: null pointer");
+extern "C" int cdc_embed_grad_dense(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt, float* grad,
+                                    int64_t B, int32_t F, int32_t D, int64_t R, void* stream) {
+    CDC_CHECK_ARG(rowgrad && uniq_row && uniq_cnt && grad, CDC_E_BADARG, "embed_grad_dense: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_B, CDC_E_BADARG, "embed_grad_dense: bad sizes");
     const int64_t total = (int64_t)F * B * D;
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
-    hipLaunchKernelGGL(k_grad_dense, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, uniq_row, seg_start, perm,
-                       uniq_cnt, grad, (int32_t)B, F, D, R);
+    hipLaunchKernelGGL(k_grad_dense, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, grad,
+                       (int32_t)B, F, D, R);
     CDC_LAUNCH_CHECK("embed_grad_dense");
     return 0;
 }
@@ -200,8 +246,7 @@ extern "C" int cdc_embed_grad_dense(const float* d_out, const int32_t* uniq_row,
 // ------------------------------------------------------------------------------------------------
 // table optimiser, dense form
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_adam_touched(const float* __restrict__ d_out, const int32_t* __restrict__ uniq_row,
-                                                      const int32_t* __restrict__ seg_start, const int32_t* __restrict__ perm,
+__global__ void __launch_bounds__(256) k_adam_touched(const float* __restrict__ rowgrad, const int32_t* __restrict__ uniq_row,
                                                       const int32_t* __restrict__ uniq_cnt, const float* __restrict__ w,
                                                       const float* __restrict__ m, const float* __restrict__ v,
                                                       float* __restrict__ side, cdc_adam_hp hp,
@@ -216,29 +261,24 @@ __global__ void __launch_bounds__(256) k_adam_touched(const float* __restrict__ 
         const int f = (int)(slot / B);
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
-        const int64_t row = uniq_row[(int64_t)f * B + j];
-        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
-        const int32_t* prm = perm + (int64_t)f * B;
-        float g = 0.f;
-        for (int k = sst[j]; k < sst[j + 1]; ++k) g = __fadd_rn(g, d_out[((int64_t)prm[k] * F + f) * D + d]);
+        const int64_t row = uniq_row[slot];
         float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
-        adam_elem(wv, mv, vv, g, c, step_size, bc2s);
+        adam_elem(wv, mv, vv, rowgrad[i], c, step_size, bc2s);
         float* s = side + slot * 3 * D;
         s[d] = wv; s[D + d] = mv; s[2 * D + d] = vv;
     }
 }
 
-extern "C" int cdc_embed_adam_touched(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
-                                      const int32_t* perm, const int32_t* uniq_cnt, const float* w, const float* m,
-                                      const float* v, float* side, cdc_adam_hp hp, const int32_t* step_dev, int64_t B,
-                                      int32_t F, int32_t D, void* stream) {
-    CDC_CHECK_ARG(d_out && uniq_row && seg_start && perm && uniq_cnt && w && m && v && side && step_dev && hp.step_scalars,
-                  CDC_E_BADARG, "embed_adam_touched: null pointer");
+extern "C" int cdc_embed_adam_touched(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt, const float* w,
+                                      const float* m, const float* v, float* side, cdc_adam_hp hp, const int32_t* step_dev,
+                                      int64_t B, int32_t F, int32_t D, void* stream) {
+    CDC_CHECK_ARG(rowgrad && uniq_row && uniq_cnt && w && m && v && side && step_dev && hp.step_scalars, CDC_E_BADARG,
+                  "embed_adam_touched: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_B && hp.n_scalars > 0, CDC_E_BADARG, "embed_adam_touched: bad sizes");
     const int64_t total = (int64_t)F * B * D;
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
-    hipLaunchKernelGGL(k_adam_touched, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, uniq_row, seg_start, perm,
-                       uniq_cnt, w, m, v, side, hp, step_dev, (int32_t)B, F, D);
+    hipLaunchKernelGGL(k_adam_touched, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, w, m, v, side,
+                       hp, step_dev, (int32_t)B, F, D);
     CDC_LAUNCH_CHECK("embed_adam_touched");
     return 0;
 }
@@ -391,8 +431,7 @@ extern "C" int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* un
 
 // step t for the batch's rows: rows are at t-1 after catchup (last[] still holds the older value,
 // which is ignored here); writes last[row] = t.
-__global__ void __launch_bounds__(256) k_lazy_update(const float* __restrict__ d_out, const int32_t* __restrict__ uniq_row,
-                                                     const int32_t* __restrict__ seg_start, const int32_t* __restrict__ perm,
+__global__ void __launch_bounds__(256) k_lazy_update(const float* __restrict__ rowgrad, const int32_t* __restrict__ uniq_row,
                                                      const int32_t* __restrict__ uniq_cnt, float* __restrict__ w,
                                                      float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ last,
                                                      cdc_adam_hp hp, const int32_t* __restrict__ step_dev, int32_t B,
@@ -408,30 +447,25 @@ __global__ void __launch_bounds__(256) k_lazy_update(const float* __restrict__ d
         const int f = (int)(slot / B);
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
-        const int64_t row = uniq_row[(int64_t)f * B + j];
-        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
-        const int32_t* prm = perm + (int64_t)f * B;
-        float g = 0.f;
-        for (int k = sst[j]; k < sst[j + 1]; ++k) g = __fadd_rn(g, d_out[((int64_t)prm[k] * F + f) * D + d]);
+        const int64_t row = uniq_row[slot];
         float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
-        adam_elem(wv, mv, vv, g, c, step_size, bc2s);
+        adam_elem(wv, mv, vv, rowgrad[i], c, step_size, bc2s);
         w[row * D + d] = wv; m[row * D + d] = mv; v[row * D + d] = vv;
         if (d == 0) last[row] = t;
     }
 }
 
-extern "C" int cdc_embed_lazy_update(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
-                                     const int32_t* perm, const int32_t* uniq_cnt, float* w, float* m, float* v,
-                                     int32_t* last, cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring,
+extern "C" int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt, float* w, float* m,
+                                     float* v, int32_t* last, cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring,
                                      int32_t ring_len, int64_t B, int32_t F, int32_t D, void* stream) {
     (void)reg_ring; (void)ring_len;
-    CDC_CHECK_ARG(d_out && uniq_row && seg_start && perm && uniq_cnt && w && m && v && last && step_dev && hp.step_scalars &&
-                      hp.n_scalars > 0, CDC_E_BADARG, "embed_lazy_update: null pointer");
+    CDC_CHECK_ARG(rowgrad && uniq_row && uniq_cnt && w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0,
+                  CDC_E_BADARG, "embed_lazy_update: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0 && D > 0, CDC_E_BADARG, "embed_lazy_update: bad sizes");
     const int64_t total = (int64_t)F * B * D;
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
-    hipLaunchKernelGGL(k_lazy_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, uniq_row, seg_start, perm,
-                       uniq_cnt, w, m, v, last, hp, step_dev, (int32_t)B, F, D);
+    hipLaunchKernelGGL(k_lazy_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, w, m, v, last, hp,
+                       step_dev, (int32_t)B, F, D);
     CDC_LAUNCH_CHECK("embed_lazy_update");
     return 0;
 }

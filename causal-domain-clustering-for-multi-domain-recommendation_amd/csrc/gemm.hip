@@ -280,27 +280,41 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bw
 }
 
 // =================================================================================================
-// grad-weight: dW_g = dZ_gᵀ · X_g ; db_g = colsum(dZ_g)
+// grad-weight: dW_g = dZ_gᵀ · X_g ; db_g = colsum(dZ_g).  The reduction runs over the batch rows, the output is
+// small: with split_k > 1 each (tile, row slice) pair is its own workgroup writing an fp32 slab, and
+// k_bwd_w_reduce adds the slabs in slice order.
 // =================================================================================================
 template <bool BF16, int BM, int BN>
-__global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bwdw_args a) {
+__global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bwdw_args a, int64_t slab_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int S = a.split_k > 1 ? a.split_k : 1;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id % S;
+    int tile = id / S;
     int g = 0, tn_cnt = 1;
+    int64_t g_off = 0;
     for (; g < a.n_groups; ++g) {
         tn_cnt = (a.g[g].K + BN - 1) / BN;
         const int t = ((a.g[g].N + BM - 1) / BM) * tn_cnt;
         if (tile < t) break;
         tile -= t;
+        g_off += (int64_t)a.g[g].N * a.g[g].K + a.g[g].N;
     }
     if (g >= a.n_groups) return;
     const cdc_bwdw_group& G = a.g[g];
     int row_lo = 0, M = G.M;
     if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
+    // this workgroup's slice of the batch rows (multiple of BK so every slice but the last is whole K-slabs)
+    int chunk = ((M + S - 1) / S + BK - 1) / BK * BK;
+    if (chunk < BK) chunk = BK;
+    const int r0 = split * chunk;
+    int rn = M - r0;
+    if (rn > chunk) rn = chunk;
+    if (rn < 0) rn = 0;
     const int i0 = (tile / tn_cnt) * BM, j0 = (tile % tn_cnt) * BN;   // i over N (dW rows), j over K (dW cols)
 
-    Operand A{G.dz + (int64_t)row_lo * G.lddz, 1, G.lddz, G.N, M};     // (i=n, r=b)  i contiguous
-    Operand B{G.x + (int64_t)row_lo * G.ldx, 1, G.ldx, G.K, M};        // (j=k, r=b)  j contiguous
+    Operand A{G.dz + (int64_t)(row_lo + r0) * G.lddz, 1, G.lddz, G.N, rn};     // (i=n, r=b)  i contiguous
+    Operand B{G.x + (int64_t)(row_lo + r0) * G.ldx, 1, G.ldx, G.K, rn};        // (j=k, r=b)  j contiguous
     f32x4_t acc[BM / 32][BN / 32];
 #pragma unroll
     for (int mt = 0; mt < BM / 32; ++mt)
@@ -311,6 +325,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
     if (want_db) gemm_accumulate<BF16, BM, BN, false, false, true>(A, B, i0, j0, smem, acc, &colsum);
     else         gemm_accumulate<BF16, BM, BN, false, false, false>(A, B, i0, j0, smem, acc, nullptr);
 
+    float* slab = S > 1 ? a.workspace + (int64_t)split * slab_stride + g_off : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (want_db) {
         // threads tid % (BM/4) share the same 4 columns; fixed-order reduction through LDS
@@ -321,10 +336,13 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
         __syncthreads();
         if (tid < BM) {
             const int c4 = tid / 4, q = tid % 4;
-            float s = 0.f;
-            for (int t = c4; t < GEMM_THREADS; t += BM / 4) s += red[t * 4 + q];
+            float sum = 0.f;
+            for (int t = c4; t < GEMM_THREADS; t += BM / 4) sum += red[t * 4 + q];
             const int n = i0 + tid;
-            if (n < G.N) G.db[n] = G.accumulate ? G.db[n] + s : s;
+            if (n < G.N) {
+                if (slab) slab[(int64_t)G.N * G.K + n] = sum;
+                else G.db[n] = G.accumulate ? G.db[n] + sum : sum;
+            }
         }
     }
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -338,11 +356,38 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
                 if (row >= G.N) continue;
-                float* dst = G.dw + (int64_t)row * G.lddw + col;
                 const float val = acc[mt][nt][r];
-                *dst = G.accumulate ? *dst + val : val;
+                if (slab) slab[(int64_t)row * G.K + col] = val;
+                else {
+                    float* dst = G.dw + (int64_t)row * G.lddw + col;
+                    *dst = G.accumulate ? *dst + val : val;
+                }
             }
         }
+}
+
+__global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a, int64_t slab_stride) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < slab_stride; e += (int64_t)gridDim.x * blockDim.x) {
+        int g = 0;
+        int64_t local = e;
+        for (; g < a.n_groups; ++g) {
+            const int64_t sz = (int64_t)a.g[g].N * a.g[g].K + a.g[g].N;
+            if (local < sz) break;
+            local -= sz;
+        }
+        if (g >= a.n_groups) return;
+        const cdc_bwdw_group& G = a.g[g];
+        float sum = 0.f;
+        for (int s = 0; s < a.split_k; ++s) sum += a.workspace[(int64_t)s * slab_stride + e];
+        const int64_t nk = (int64_t)G.N * G.K;
+        if (local < nk) {
+            float* dst = G.dw + (local / G.K) * G.lddw + (local % G.K);
+            *dst = G.accumulate ? *dst + sum : sum;
+        } else if (G.db) {
+            float* dst = G.db + (local - nk);
+            *dst = G.accumulate ? *dst + sum : sum;
+        }
+    }
 }
 
 // =================================================================================================
@@ -423,19 +468,29 @@ extern "C" int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void*
 extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void* stream) {
     CDC_CHECK_ARG(a && a->n_groups > 0 && a->n_groups <= CDC_MAX_GROUPS, CDC_E_BADARG, "glinear_bwd_w: bad group count");
     CDC_CHECK_ARG(prec == CDC_PREC_BF16 || prec == CDC_PREC_F32, CDC_E_BADARG, "glinear_bwd_w: bad precision");
-    int64_t t64 = 0;
+    CDC_CHECK_ARG(a->split_k <= 1 || a->workspace, CDC_E_BADARG, "glinear_bwd_w: split_k needs a workspace");
+    CDC_CHECK_ARG(a->split_k <= 256, CDC_E_BADARG, "glinear_bwd_w: split_k too large");
+    int64_t t64 = 0, slab = 0;
     for (int g = 0; g < a->n_groups; ++g) {
         const cdc_bwdw_group& G = a->g[g];
         CDC_CHECK_ARG(G.dz && G.x && G.dw && G.M >= 0 && G.N > 0 && G.K > 0 && G.lddz >= G.N && G.ldx >= G.K && G.lddw >= G.K,
                       CDC_E_BADARG, "glinear_bwd_w: group %d malformed", g);
         t64 += cdc_ceil_div(G.N, 64) * cdc_ceil_div(G.K, 64);
+        slab += (int64_t)G.N * G.K + G.N;
     }
-    CDC_CHECK_ARG(t64 < (1ll << 31), CDC_E_TOOBIG, "glinear_bwd_w: grid too large");
+    const int S = a->split_k > 1 ? a->split_k : 1;
+    const int64_t grid = t64 * S;
+    CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "glinear_bwd_w: grid too large");
     hipStream_t st = (hipStream_t)stream;
     if (prec == CDC_PREC_BF16)
-        hipLaunchKernelGGL((k_glinear_bwd_w<true, 64, 64>), dim3(t64), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
+        hipLaunchKernelGGL((k_glinear_bwd_w<true, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a, slab);
     else
-        hipLaunchKernelGGL((k_glinear_bwd_w<false, 64, 64>), dim3(t64), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
+        hipLaunchKernelGGL((k_glinear_bwd_w<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a, slab);
     CDC_LAUNCH_CHECK("glinear_bwd_w");
+    if (S > 1) {
+        int blocks = (int)std::min<int64_t>(cdc_ceil_div(slab, 256), 4096);
+        hipLaunchKernelGGL(k_bwd_w_reduce, dim3(blocks), dim3(256), 0, st, *a, slab);
+        CDC_LAUNCH_CHECK("bwd_w_reduce");
+    }
     return 0;
 }

@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
     const cdc_bn_seg& S = a.s[t.seg];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = t.c0 + lane;
-    const bool skip_norm = (t.M == 1);           // reference skips BN when the (group's) batch has one row
+    // the reference skips BN when the (group's) batch has one row (MLP / MDR_BatchNorm) or at most one row (DNN)
+    const bool skip_norm = (t.M == 1) || (a.skip_le1 && t.M <= 1);
     float mean = 0.f, invstd = 1.f;
     if (c < S.C && !skip_norm) {
         if (a.training) {
@@ -327,7 +328,8 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
             const float xhat = (S.x[gr * S.ldx + c] - mean) * invstd;
             dx = gam * invstd * (dz - invM * (db + xhat * dg));
         } else dx = gam * invstd * dz;
-        S.dx[gr * S.lddx + c] = dx;
+        float* dst = S.dx + gr * S.lddx + c;
+        *dst = S.accumulate_dx ? *dst + dx : dx;
     }
 }
 
@@ -637,5 +639,254 @@ extern "C" int cdc_adam_multi(const cdc_adam_args* a, void* stream) {
     CDC_CHECK_ARG(chunks < (1ll << 31), CDC_E_TOOBIG, "adam_multi: too many chunks");
     hipLaunchKernelGGL(k_adam_multi, dim3(chunks), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
     CDC_LAUNCH_CHECK("adam_multi");
+    return 0;
+}
+
+// =================================================================================================
+// DCN-v2 element-wise pieces (model/layer.py:339-343 CrossNetV2, :372-407 CrossNetMix)
+// =================================================================================================
+__global__ void __launch_bounds__(ROW_THREADS) k_tanh_fwd(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+                                                          int64_t rows, int32_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        y[r * ldy + c] = tanhf(x[r * ldx + c]);
+    }
+}
+extern "C" int cdc_tanh_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int32_t cols, void* stream) {
+    CDC_CHECK_ARG(x && y && rows >= 0 && cols > 0, CDC_E_BADARG, "tanh_fwd: bad argument");
+    if (rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(rows * cols, ROW_THREADS), 4096);
+    hipLaunchKernelGGL(k_tanh_fwd, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream, x, ldx, y, ldy, rows, cols);
+    CDC_LAUNCH_CHECK("tanh_fwd");
+    return 0;
+}
+// dx (=|+=) dy * (1 - y^2)
+__global__ void __launch_bounds__(ROW_THREADS) k_tanh_bwd(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y,
+                                                          int64_t ldy, float* __restrict__ dx, int64_t lddx, int64_t rows,
+                                                          int32_t cols, int32_t accumulate) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float yv = y[r * ldy + c];
+        const float v = dy[r * lddy + c] * (1.f - yv * yv);
+        float* dst = dx + r * lddx + c;
+        *dst = accumulate ? *dst + v : v;
+    }
+}
+extern "C" int cdc_tanh_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t lddx, int64_t rows,
+                            int32_t cols, int32_t accumulate, void* stream) {
+    CDC_CHECK_ARG(dy && y && dx && rows >= 0 && cols > 0, CDC_E_BADARG, "tanh_bwd: bad argument");
+    if (rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(rows * cols, ROW_THREADS), 4096);
+    hipLaunchKernelGGL(k_tanh_bwd, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream, dy, lddy, y, ldy, dx, lddx, rows, cols, accumulate);
+    CDC_LAUNCH_CHECK("tanh_bwd");
+    return 0;
+}
+
+// out[:, k*P + e] = x0[:, e] * (u[:, k*P + e] + b1[e]) + b2[e] + r[:, k*P + e]     (b1, b2, r optional; P = period,
+// n_rep blocks of P columns share x0 / b1 / b2: the n experts of a CrossNetMix layer in one launch)
+__global__ void __launch_bounds__(ROW_THREADS) k_cross_combine_fwd(const float* __restrict__ x0, int64_t ld0, const float* __restrict__ u,
+                                                                   int64_t ldu, const float* __restrict__ b1,
+                                                                   const float* __restrict__ b2, const float* __restrict__ r,
+                                                                   int64_t ldr, float* __restrict__ out, int64_t ldo, int64_t rows,
+                                                                   int32_t period, int32_t n_rep) {
+    const int cols = period * n_rep;
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / cols;
+        const int c = (int)(i - row * cols);
+        const int e = c % period;
+        float uv = u[row * ldu + c];
+        if (b1) uv += b1[e];
+        float v = x0[row * ld0 + e] * uv;
+        if (b2) v += b2[e];
+        if (r) v += r[row * ldr + c];
+        out[row * ldo + c] = v;
+    }
+}
+extern "C" int cdc_cross_combine_fwd(const float* x0, int64_t ld0, const float* u, int64_t ldu, const float* b1, const float* b2,
+                                     const float* r, int64_t ldr, float* out, int64_t ldo, int64_t rows, int32_t period,
+                                     int32_t n_rep, void* stream) {
+    CDC_CHECK_ARG(x0 && u && out && rows >= 0 && period > 0 && n_rep > 0, CDC_E_BADARG, "cross_combine_fwd: bad argument");
+    if (rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(rows * period * n_rep, ROW_THREADS), 4096);
+    hipLaunchKernelGGL(k_cross_combine_fwd, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream, x0, ld0, u, ldu, b1, b2, r, ldr, out,
+                       ldo, rows, period, n_rep);
+    CDC_LAUNCH_CHECK("cross_combine_fwd");
+    return 0;
+}
+// d_u = d_out*x0 ; d_x0 += sum_k d_out*(u+b1) ; d_r (=|+=) d_out ; db1 = colsum(d_out*x0) ; db2 = colsum(d_out)
+// thread = base column e (owns every replica k of it: no race on d_x0), CDC_ROWDOT_PARTS row parts ->
+// workspace partials [parts][2][period] -> ordered final sum
+__global__ void __launch_bounds__(ROW_THREADS) k_cross_combine_bwd(const float* __restrict__ d_out, int64_t lddo, const float* __restrict__ x0,
+                                                                   int64_t ld0, const float* __restrict__ u, int64_t ldu,
+                                                                   const float* __restrict__ b1, float* __restrict__ d_u, int64_t lddu,
+                                                                   float* __restrict__ d_x0_acc, int64_t lddx0, float* __restrict__ d_r,
+                                                                   int64_t lddr, int32_t accumulate_r, float* __restrict__ workspace,
+                                                                   int64_t rows, int32_t period, int32_t n_rep) {
+    const int part = blockIdx.y;
+    const int64_t per = (rows + CDC_ROWDOT_PARTS - 1) / CDC_ROWDOT_PARTS;
+    const int64_t r_begin = part * per, r_end = min(r_begin + per, rows);
+    for (int e = blockIdx.x * ROW_THREADS + threadIdx.x; e < period; e += gridDim.x * ROW_THREADS) {
+        float s1 = 0.f, s2 = 0.f;
+        const float bv = b1 ? b1[e] : 0.f;
+        for (int64_t row = r_begin; row < r_end; ++row) {
+            const float xv = x0[row * ld0 + e];
+            float dx0 = 0.f;
+            for (int k = 0; k < n_rep; ++k) {
+                const int c = k * period + e;
+                const float d = d_out[row * lddo + c];
+                const float g = d * xv;
+                d_u[row * lddu + c] = g;
+                dx0 += d * (u[row * ldu + c] + bv);
+                if (d_r) { float* dst = d_r + row * lddr + c; *dst = accumulate_r ? *dst + d : d; }
+                s1 += g; s2 += d;
+            }
+            d_x0_acc[row * lddx0 + e] += dx0;
+        }
+        workspace[((int64_t)part * 2 + 0) * period + e] = s1;
+        workspace[((int64_t)part * 2 + 1) * period + e] = s2;
+    }
+}
+__global__ void __launch_bounds__(ROW_THREADS) k_cross_combine_bwd_final(const float* __restrict__ workspace, float* __restrict__ db1,
+                                                                         float* __restrict__ db2, int32_t period, int32_t acc1,
+                                                                         int32_t acc2) {
+    const int c = blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (c >= period) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < CDC_ROWDOT_PARTS; ++p) {
+        s1 += workspace[((int64_t)p * 2 + 0) * period + c];
+        s2 += workspace[((int64_t)p * 2 + 1) * period + c];
+    }
+    if (db1) db1[c] = acc1 ? db1[c] + s1 : s1;
+    if (db2) db2[c] = acc2 ? db2[c] + s2 : s2;
+}
+extern "C" int cdc_cross_combine_bwd(const float* d_out, int64_t lddo, const float* x0, int64_t ld0, const float* u, int64_t ldu,
+                                     const float* b1, float* d_u, int64_t lddu, float* d_x0_acc, int64_t lddx0, float* d_r,
+                                     int64_t lddr, int32_t accumulate_r, float* db1, int32_t accumulate_b1, float* db2,
+                                     int32_t accumulate_b2, float* workspace, int64_t rows, int32_t period, int32_t n_rep,
+                                     void* stream) {
+    CDC_CHECK_ARG(d_out && x0 && u && d_u && d_x0_acc && workspace && rows > 0 && period > 0 && n_rep > 0, CDC_E_BADARG,
+                  "cross_combine_bwd: bad argument");
+    dim3 grid((unsigned)cdc_ceil_div(period, ROW_THREADS), CDC_ROWDOT_PARTS);
+    hipLaunchKernelGGL(k_cross_combine_bwd, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, d_out, lddo, x0, ld0, u, ldu, b1, d_u, lddu,
+                       d_x0_acc, lddx0, d_r, lddr, accumulate_r, workspace, rows, period, n_rep);
+    CDC_LAUNCH_CHECK("cross_combine_bwd");
+    if (db1 || db2) {
+        hipLaunchKernelGGL(k_cross_combine_bwd_final, dim3(cdc_ceil_div(period, ROW_THREADS)), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                           workspace, db1, db2, period, accumulate_b1, accumulate_b2);
+        CDC_LAUNCH_CHECK("cross_combine_bwd_final");
+    }
+    return 0;
+}
+
+// out = a + b
+__global__ void __launch_bounds__(ROW_THREADS) k_add_out(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                         float* __restrict__ out, int64_t ldo, int64_t rows, int32_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        out[r * ldo + c] = a[r * lda + c] + b[r * ldb + c];
+    }
+}
+extern "C" int cdc_add_out(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t rows,
+                           int32_t cols, void* stream) {
+    CDC_CHECK_ARG(a && b && out && rows >= 0 && cols > 0, CDC_E_BADARG, "add_out: bad argument");
+    if (rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(rows * cols, ROW_THREADS), 4096);
+    hipLaunchKernelGGL(k_add_out, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, rows, cols);
+    CDC_LAUNCH_CHECK("add_out");
+    return 0;
+}
+// dst (=|+=) src   (gradient routing of identity / residual edges)
+__global__ void __launch_bounds__(ROW_THREADS) k_copy_or_add(float* __restrict__ dst, int64_t ldd, const float* __restrict__ src,
+                                                             int64_t lds, int64_t rows, int32_t cols, int32_t accumulate) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float v = src[r * lds + c];
+        float* p = dst + r * ldd + c;
+        *p = accumulate ? *p + v : v;
+    }
+}
+extern "C" int cdc_copy_or_add(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t rows, int32_t cols,
+                               int32_t accumulate, void* stream) {
+    CDC_CHECK_ARG(dst && src && rows >= 0 && cols > 0, CDC_E_BADARG, "copy_or_add: bad argument");
+    if (rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(rows * cols, ROW_THREADS), 4096);
+    hipLaunchKernelGGL(k_copy_or_add, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream, dst, ldd, src, lds, rows, cols, accumulate);
+    CDC_LAUNCH_CHECK("copy_or_add");
+    return 0;
+}
+
+
+// =================================================================================================
+// STAR parameter fusion (model/star.py:90-93,100-102,169-176)
+// =================================================================================================
+__global__ void __launch_bounds__(ROW_THREADS) k_star_fuse_fwd(const cdc_star_fuse_args a) {
+    const int g = blockIdx.y;
+    const float* ag = a.a[g];
+    float* og = a.out[g];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.size; i += (int64_t)gridDim.x * blockDim.x)
+        og[i] = a.op == 0 ? ag[i] * a.s[i] : ag[i] + a.s[i];
+}
+extern "C" int cdc_star_fuse_fwd(const cdc_star_fuse_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n > 0 && a->n <= CDC_MAX_GROUPS && a->size > 0 && a->s && (a->op == 0 || a->op == 1), CDC_E_BADARG,
+                  "star_fuse_fwd: bad argument");
+    for (int g = 0; g < a->n; ++g) CDC_CHECK_ARG(a->a[g] && a->out[g], CDC_E_BADARG, "star_fuse_fwd: domain %d malformed", g);
+    dim3 grid((unsigned)std::min<int64_t>(cdc_ceil_div(a->size, ROW_THREADS), 1024), a->n);
+    hipLaunchKernelGGL(k_star_fuse_fwd, grid, dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("star_fuse_fwd");
+    return 0;
+}
+__global__ void __launch_bounds__(ROW_THREADS) k_star_fuse_bwd(const cdc_star_fuse_args a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.size; i += (int64_t)gridDim.x * blockDim.x) {
+        const float sv = a.s[i];
+        float acc = 0.f;
+        for (int g = 0; g < a.n; ++g) {
+            const float d = a.out[g][i];
+            if (a.da[g]) a.da[g][i] = a.op == 0 ? d * sv : d;
+            acc += a.op == 0 ? d * a.a[g][i] : d;
+        }
+        if (a.ds) a.ds[i] = a.accumulate_ds ? a.ds[i] + acc : acc;
+    }
+}
+extern "C" int cdc_star_fuse_bwd(const cdc_star_fuse_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n > 0 && a->n <= CDC_MAX_GROUPS && a->size > 0 && a->s && (a->op == 0 || a->op == 1), CDC_E_BADARG,
+                  "star_fuse_bwd: bad argument");
+    for (int g = 0; g < a->n; ++g) CDC_CHECK_ARG(a->a[g] && a->out[g], CDC_E_BADARG, "star_fuse_bwd: domain %d malformed", g);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(a->size, ROW_THREADS), 2048);
+    hipLaunchKernelGGL(k_star_fuse_bwd, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("star_fuse_bwd");
+    return 0;
+}
+
+// out[r, c] (=|+=) sum_g in[r, g*cols + c]   (fixed order over g)
+__global__ void __launch_bounds__(ROW_THREADS) k_sum_slices(const float* __restrict__ in, int64_t ld_in, float* __restrict__ out,
+                                                            int64_t ld_out, int64_t rows, int32_t cols, int32_t n_slices,
+                                                            int32_t accumulate) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        float acc = 0.f;
+        for (int g = 0; g < n_slices; ++g) acc += in[r * ld_in + (int64_t)g * cols + c];
+        float* dst = out + r * ld_out + c;
+        *dst = accumulate ? *dst + acc : acc;
+    }
+}
+extern "C" int cdc_sum_slices(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows, int32_t cols,
+                              int32_t n_slices, int32_t accumulate, void* stream) {
+    CDC_CHECK_ARG(in && out && rows >= 0 && cols > 0 && n_slices > 0, CDC_E_BADARG, "sum_slices: bad argument");
+    if (rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(rows * cols, ROW_THREADS), 4096);
+    hipLaunchKernelGGL(k_sum_slices, dim3(blocks), dim3(ROW_THREADS), 0, (hipStream_t)stream, in, ld_in, out, ld_out, rows, cols, n_slices,
+                       accumulate);
+    CDC_LAUNCH_CHECK("sum_slices");
     return 0;
 }

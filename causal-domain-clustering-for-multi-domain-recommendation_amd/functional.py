@@ -51,7 +51,11 @@ def table_dense_grad(plan, emb_op, table):
                                       B, F, s), "embed_sort_dedupe")
     g = emb_op.out.grad
     assert g.ld == F * D
-    L.check(lib.cdc_embed_grad_dense(g.ptr, uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(), grad.data_ptr(),
+    scratch = torch.empty((F * B * D,), dtype=torch.float32, device=dev)
+    rowgrad = torch.empty((F * B * D,), dtype=torch.float32, device=dev)
+    L.check(lib.cdc_embed_segment_sum(g.ptr, seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(), scratch.data_ptr(), rowgrad.data_ptr(),
+                                      B, F, D, s), "embed_segment_sum")
+    L.check(lib.cdc_embed_grad_dense(rowgrad.data_ptr(), uniq.data_ptr(), cnt.data_ptr(), grad.data_ptr(),
                                      B, F, D, table.shape[0], s), "embed_grad_dense")
     return grad
 

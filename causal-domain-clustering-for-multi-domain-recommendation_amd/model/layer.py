@@ -304,6 +304,73 @@ class CrossNetwork(HipModule):
         return _run_float_module(self, "cross", x, lambda plan, xb: [self.describe(plan, xb)])
 
 
+class CrossNetV2(HipModule):
+    """DCN-v2 full-matrix cross: x_{l+1} = x0 * (W_l x_l) + b_l + x_l.  Reference: model/layer.py:332-343."""
+
+    def __init__(self, input_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        self.w = nn.ModuleList([nn.Linear(input_dim, input_dim, bias=False) for _ in range(num_layers)])
+        self.b = nn.ParameterList([nn.Parameter(torch.zeros((input_dim,))) for _ in range(num_layers)])
+
+    def describe(self, plan, x0, out=None):
+        cur = x0
+        for i in range(self.num_layers):
+            u = P.GLinear(plan, [{"x": cur, "w": self.w[i].weight, "b": None}]).outs[0]
+            dst = out if (i == self.num_layers - 1) else None
+            cur = P.CrossCombine(plan, x0, u, b2=self.b[i], r=cur, out=dst).out
+        return cur
+
+    def forward(self, x):
+        return _run_float_module(self, "crossv2", x, lambda plan, xb: [self.describe(plan, xb)])
+
+
+class CrossNetMix(HipModule):
+    """DCN-v2 mixture of low-rank experts.  Reference: model/layer.py:346-407.
+    Per layer: gate score x_l.g_k per expert (the n gates are shared by every layer), expert
+    x0 * (U_k tanh(C_k tanh(V_k^T x_l)) + bias_l), softmax-weighted mixture, residual."""
+
+    def __init__(self, input_dim, num_layers=2, low_rank=32, num_experts=4):
+        super().__init__()
+        self.num_layers, self.num_experts, self.low_rank, self.input_dim = num_layers, num_experts, low_rank, input_dim
+        self.u_list = nn.ParameterList([nn.Parameter(nn.init.xavier_normal_(torch.empty(num_experts, input_dim, low_rank)))
+                                        for _ in range(num_layers)])
+        self.v_list = nn.ParameterList([nn.Parameter(nn.init.xavier_normal_(torch.empty(num_experts, input_dim, low_rank)))
+                                        for _ in range(num_layers)])
+        self.c_list = nn.ParameterList([nn.Parameter(nn.init.xavier_normal_(torch.empty(num_experts, low_rank, low_rank)))
+                                        for _ in range(num_layers)])
+        self.gating = nn.ModuleList([nn.Linear(input_dim, 1, bias=False) for _ in range(num_experts)])
+        self.bias = nn.ParameterList([nn.Parameter(nn.init.zeros_(torch.empty(input_dim, 1))) for _ in range(num_layers)])
+
+    def describe(self, plan, x0, out=None):
+        if plan.B == 1:
+            # model/layer.py:406 `x_l.squeeze()` drops the batch dimension too; every caller then fails (golden g6)
+            raise IndexError("Dimension out of range (CrossNetMix squeezes a batch of one to 1-D, as the reference does)")
+        n, r, E = self.num_experts, self.low_rank, self.input_dim
+        xl = x0
+        for i in range(self.num_layers):
+            scores = plan.new(n)
+            P.RowDot(plan, [{"x": xl, "w": self.gating[k].weight, "b": None, "out": scores.slice(k, k + 1)} for k in range(n)])
+            v_pre = plan.new(n * r)
+            P.MatmulRight(plan, [{"x": xl, "m": P.PView(self.v_list[i], k), "out": v_pre.slice(k * r, (k + 1) * r)} for k in range(n)])
+            v = P.Tanh(plan, v_pre).out
+            c_pre = plan.new(n * r)
+            P.GLinear(plan, [{"x": v.slice(k * r, (k + 1) * r), "w": P.PView(self.c_list[i], k), "b": None,
+                              "out": c_pre.slice(k * r, (k + 1) * r)} for k in range(n)])
+            c = P.Tanh(plan, c_pre).out
+            uv = plan.new(n * E)
+            P.GLinear(plan, [{"x": c.slice(k * r, (k + 1) * r), "w": P.PView(self.u_list[i], k), "b": None,
+                              "out": uv.slice(k * E, (k + 1) * E)} for k in range(n)])
+            dot = P.CrossCombine(plan, x0, uv, b1=self.bias[i], n_rep=n).out
+            moe = P.GatePool(plan, dot, n, E, [(scores, list(range(n)))]).outs[0]
+            dst = out if (i == self.num_layers - 1) else None
+            xl = P.AddOut(plan, moe, xl, out=dst).out
+        return xl
+
+    def forward(self, x):
+        return _run_float_module(self, "crossmix", x, lambda plan, xb: [self.describe(plan, xb)])
+
+
 # --------------------------------------------------------------------------------------------------
 # BaseModel
 # --------------------------------------------------------------------------------------------------

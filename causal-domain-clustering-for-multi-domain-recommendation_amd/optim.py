@@ -92,6 +92,8 @@ class FusedAdam:
                   "seg": torch.empty((F, B + 1), dtype=torch.int32, device=dev),
                   "perm": torch.empty((F, B), dtype=torch.int32, device=dev),
                   "cnt": torch.zeros((F,), dtype=torch.int32, device=dev),
+                  "sorted": torch.empty((F * B * D,), dtype=torch.float32, device=dev),
+                  "rowgrad": torch.empty((F * B * D,), dtype=torch.float32, device=dev),
                   "side": torch.empty((F * B * 3 * D,), dtype=torch.float32, device=dev) if self.table_mode == "dense" else None}
             self._ws[key] = ws
         return ws
@@ -127,8 +129,9 @@ class FusedAdam:
         w, m, v = self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr()
         if self.table_mode == "dense":
             ws = self.sort_rows(idx, B, F, D)
+            self._segment_sum(ws, d_out, B, F, D, s)
             L.launch("cdc_embed_adam_touched", self.lib.cdc_embed_adam_touched,
-                     (d_out.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(),
+                     (ws["rowgrad"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(),
                       w, m, v, ws["side"].data_ptr(), hp, self.step_dev.data_ptr(), B, F, D), s)
             L.launch("cdc_embed_adam_dense_pass", self.lib.cdc_embed_adam_dense_pass,
                      (w, m, v, self.table.numel(), hp, self.step_dev.data_ptr(), self.reg_sum.data_ptr() + 8), s,
@@ -137,9 +140,15 @@ class FusedAdam:
                      (ws["side"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), w, m, v, B, F, D), s)
         else:
             ws = self._workspace(B, F, D)        # rows were sorted by table_catchup of this step
+            self._segment_sum(ws, d_out, B, F, D, s)
             L.launch("cdc_embed_lazy_update", self.lib.cdc_embed_lazy_update,
-                     (d_out.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(),
+                     (ws["rowgrad"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(),
                       w, m, v, self.table_last.data_ptr(), hp, self.step_dev.data_ptr(), None, 0, B, F, D), s)
+
+    def _segment_sum(self, ws, d_out, B, F, D, s):
+        L.launch("cdc_embed_segment_sum", self.lib.cdc_embed_segment_sum,
+                 (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["sorted"].data_ptr(),
+                  ws["rowgrad"].data_ptr(), B, F, D), s)
 
     def flush_table(self):
         """lazy mode: bring every row to the current step (needed before state_dict / eval / reading the table)."""

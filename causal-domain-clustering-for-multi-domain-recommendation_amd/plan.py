@@ -68,6 +68,45 @@ class Buf:
         return Buf(g, self.rows, self.cols, g.stride(0), self.col0, self.plan)
 
 
+class PView:
+    """One index of the leading dimension of a Parameter (e.g. expert k of a [n_expert, E, r] tensor), usable
+    wherever an op takes a weight: same .shape / .data_ptr() / .numel() surface; its gradient is the matching
+    slice of the parameter's gradient."""
+
+    def __init__(self, param, index):
+        self.param, self.index = param, index
+        self.shape = param.shape[1:]
+
+    def data_ptr(self):
+        return self.param.data[self.index].data_ptr()
+
+    def numel(self):
+        return self.param.data[self.index].numel()
+
+    @property
+    def data(self):
+        return self.param.data[self.index]
+
+
+class TView:
+    """A plain tensor used as a weight, with its own gradient tensor (STAR's fused W_d*W_s etc.): not a parameter,
+    so it never shows up in plan.param_grads."""
+
+    def __init__(self, tensor, grad):
+        self.tensor, self.grad_tensor = tensor, grad
+        self.shape = tensor.shape
+
+    def data_ptr(self):
+        return self.tensor.data_ptr()
+
+    def numel(self):
+        return self.tensor.numel()
+
+    @property
+    def data(self):
+        return self.tensor
+
+
 class _GradState:
     """Tracks which column intervals of a root gradient tensor the backward sequence has initialised."""
 
@@ -86,6 +125,15 @@ class _GradState:
             if not (c1 <= a or b <= c0):
                 raise RuntimeError(f"partial gradient overlap on a buffer: [{c0},{c1}) vs [{a},{b})")
         iv.append((c0, c1))
+        # merge adjacent column intervals (slices claimed one by one later read as one whole buffer)
+        iv.sort()
+        merged = [iv[0]]
+        for a, b in iv[1:]:
+            if a == merged[-1][1]:
+                merged[-1] = (merged[-1][0], b)
+            else:
+                merged.append((a, b))
+        iv[:] = merged
         return False
 
     def is_set(self, buf):
@@ -124,6 +172,8 @@ class Plan:
         self._bn_ws_need = 0
         self._rowdot_ws = None
         self._rowdot_ws_need = 0
+        self._gemm_ws = None
+        self._gemm_ws_need = 0
         self.finalized = False
         self.loss_inputs = None
 
@@ -143,6 +193,10 @@ class Plan:
         return g
 
     def param_grad(self, p):
+        if isinstance(p, TView):
+            return p.grad_tensor
+        if isinstance(p, PView):
+            return self.param_grad(p.param)[p.index]
         g = self.param_grads.get(id(p))
         if g is None:
             n = p.numel()
@@ -164,9 +218,10 @@ class Plan:
             gs.claim(buf)
 
     def _claim_param(self, p):
-        if id(p) in self._param_grad_set:
+        key = (id(p.param), p.index) if isinstance(p, PView) else (id(p.tensor) if isinstance(p, TView) else id(p))
+        if key in self._param_grad_set:
             return True
-        self._param_grad_set.add(id(p))
+        self._param_grad_set.add(key)
         return False
 
     def _next_seed(self):
@@ -175,6 +230,9 @@ class Plan:
 
     def need_bn_ws(self, rows, total_c):
         self._bn_ws_need = max(self._bn_ws_need, 2 * math.ceil(rows / L.BN_ROWS_PER_BLOCK) * total_c)
+
+    def need_gemm_ws(self, n):
+        self._gemm_ws_need = max(self._gemm_ws_need, n)
 
     def need_rowdot_ws(self, n):
         self._rowdot_ws_need = max(self._rowdot_ws_need, n)
@@ -188,6 +246,7 @@ class Plan:
         """outputs: list of Bufs whose .grad the caller seeds before backward()."""
         self._bn_ws = torch.empty(max(self._bn_ws_need, 1), dtype=torch.float64, device=self.device)
         self._rowdot_ws = torch.empty(max(self._rowdot_ws_need, 1), dtype=torch.float32, device=self.device)
+        self._gemm_ws = torch.empty(max(self._gemm_ws_need, 1), dtype=torch.float32, device=self.device)
         gs = _GradState()
         for o in outputs:
             gs.claim(o)
@@ -277,6 +336,15 @@ class GLinear:
                 y.mask = (plan.keep_scale if self.drop_p > 0 else 1.0, g["act_cols"])
             g["y"] = y
             self.outs.append(y)
+        # grad-weight split-K: enough (tile, row-slice) workgroups to fill 256 CUs several times over
+        self.split_k = []
+        for c0 in range(0, len(groups), L.MAX_GROUPS):
+            chunk = groups[c0:c0 + L.MAX_GROUPS]
+            tiles = sum(math.ceil(g["w"].shape[0] / 64) * math.ceil(g["w"].shape[1] / 64) for g in chunk)
+            S = max(1, min(1024 // max(tiles, 1), max(self.M // 128, 1), 64))
+            self.split_k.append(S)
+            if S > 1:
+                plan.need_gemm_ws(S * sum(g["w"].numel() + g["w"].shape[0] for g in chunk))
         plan.add(self)
 
     def build_fwd(self, plan):
@@ -311,6 +379,8 @@ class GLinear:
             chunk = self.groups[c0:c0 + L.MAX_GROUPS]
             a = L.LinBwdwArgs()
             a.n_groups = len(chunk)
+            a.split_k = self.split_k[c0 // L.MAX_GROUPS]
+            a.workspace = plan._gemm_ws.data_ptr()
             a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr() + 4 * c0
             for i, g in enumerate(chunk):
                 G = a.g[i]
@@ -358,8 +428,12 @@ class GLinear:
         if cur_o:
             launches.append(cur_o)
         if self.row_offsets is not None:
-            # ragged rows: outputs must line up one-to-one with the row groups
-            assert all(len(o[1]) == 1 for o in outs), "ragged linear groups cannot share an input"
+            # ragged rows: group g owns rows [ro[g], ro[g+1]) of the (shared) buffers: one output per group, in group
+            # order, and ONE accumulate decision per distinct input buffer
+            outs = [(g["x"], [gi]) for gi, g in enumerate(self.groups) if not g.get("no_dx")]
+            assert len(outs) == len(self.groups) and len(outs) <= L.MAX_GROUPS, "ragged launch limited to one chunk"
+            launches = [outs]
+        ragged_acc = {}
         for la in launches:
             # all outputs of one launch share the mask scale (one plan-wide dropout rate)
             a = L.LinBwdxArgs()
@@ -380,7 +454,13 @@ class GLinear:
                     O.mask_y = None
                     O.mask_cols = 0
                 O.M, O.K = self.M, x.cols
-                O.accumulate = 1 if gs.claim(x) else 0
+                if self.row_offsets is not None:
+                    key = (id(x.root), x.col0, x.cols)
+                    if key not in ragged_acc:
+                        ragged_acc[key] = gs.claim(x)
+                    O.accumulate = 1 if ragged_acc[key] else 0
+                else:
+                    O.accumulate = 1 if gs.claim(x) else 0
                 for gi in gis:
                     g = self.groups[gi]
                     S = a.s[si]
@@ -470,8 +550,9 @@ class BatchNorm:
           (or explicit tensors gamma/beta), out: Buf or None, row_group: int}
     """
 
-    def __init__(self, plan, segs, relu=True, dropout=True, eps=1e-5, momentum=0.1, row_offsets=None, M=None):
+    def __init__(self, plan, segs, relu=True, dropout=True, eps=1e-5, momentum=0.1, row_offsets=None, M=None, skip_le1=False):
         self.segs = segs
+        self.skip_le1 = skip_le1
         self.relu = relu
         self.drop_p = plan.dropout if dropout else 0.0
         self.eps, self.momentum = eps, momentum
@@ -500,6 +581,7 @@ class BatchNorm:
             chunk = self.segs[c0:c0 + L.MAX_BN_SEGS]
             a = L.BnFwdArgs()
             a.n_seg, a.training, a.relu = len(chunk), 1 if plan.training else 0, 1 if self.relu else 0
+            a.skip_le1 = 1 if self.skip_le1 else 0
             a.eps, a.momentum, a.drop_p = self.eps, self.momentum, self.drop_p
             a.seed, a.seed_offset_dev = (self.seed + c0) & 0xFFFFFFFFFFFFFFFF, plan.step_dev.data_ptr()
             a.M = self.M
@@ -520,6 +602,16 @@ class BatchNorm:
             plan.fwd_steps.append(plan.call("cdc_bn_fwd", C.byref(a)))
 
     def build_bwd(self, plan, gs):
+        # segments that normalise the SAME input over the same rows (STAR all-towers: every domain_norm reads the
+        # embeddings) cannot write one gradient buffer concurrently: each writes its own slice, summed afterwards
+        keys = [(id(s["x"].root), s["x"].col0, s["x"].cols) for s in self.segs]
+        shared = self.row_offsets is None and len(set(keys)) < len(keys)
+        fan_in = None
+        if shared:
+            assert len(set(keys)) == 1, "BatchNorm launch mixes shared and private inputs"
+            x = self.segs[0]["x"]
+            fan_in = plan.new(x.cols * len(self.segs), rows=x.rows)
+        ragged_acc = {}
         for c0 in range(0, len(self.segs), L.MAX_BN_SEGS):
             chunk = self.segs[c0:c0 + L.MAX_BN_SEGS]
             a = L.BnBwdArgs()
@@ -537,10 +629,20 @@ class BatchNorm:
                 S.dy, S.lddy = yg.ptr, yg.ld
                 S.y, S.ldy = s["y"].ptr, s["y"].ld
                 S.x, S.ldx = s["x"].ptr, s["x"].ld
-                xg = s["x"].grad
-                if gs.claim(s["x"]):
-                    raise RuntimeError("a BatchNorm input feeds more than one consumer")
-                S.dx, S.lddx = xg.ptr, xg.ld
+                S.accumulate_dx = 0
+                if fan_in is not None:
+                    sl = fan_in.slice((c0 + i) * s["x"].cols, (c0 + i + 1) * s["x"].cols)
+                    S.dx, S.lddx = sl.ptr, sl.ld
+                else:
+                    xg = s["x"].grad
+                    key = keys[c0 + i]
+                    if self.row_offsets is not None:
+                        if key not in ragged_acc:
+                            ragged_acc[key] = gs.claim(s["x"])
+                        S.accumulate_dx = 1 if ragged_acc[key] else 0
+                    elif gs.claim(s["x"]):
+                        S.accumulate_dx = 1
+                    S.dx, S.lddx = xg.ptr, xg.ld
                 S.gamma = s["gamma"].data_ptr()
                 if plan.training:
                     S.save_mean, S.save_invstd = s["save_mean"].data_ptr(), s["save_invstd"].data_ptr()
@@ -562,6 +664,14 @@ class BatchNorm:
             self._keep.append(a)
             plan.bwd_steps.extend(pre)
             plan.bwd_steps.append(plan.call("cdc_bn_bwd", C.byref(a)))
+        if fan_in is not None:
+            x = self.segs[0]["x"]
+            if x.mask is not None:
+                raise RuntimeError("shared BatchNorm input cannot be an activation-fused linear output")
+            acc = 1 if gs.claim(x) else 0
+            xg = x.grad
+            plan.bwd_steps.append(plan.call("cdc_sum_slices", fan_in.cptr(), C.c_int64(fan_in.ld), xg.cptr(), C.c_int64(xg.ld),
+                                            C.c_int64(x.rows), x.cols, len(self.segs), acc))
 
 
 class RowDot:
@@ -587,7 +697,11 @@ class RowDot:
         self.outs = [g["out"] for g in groups]
         plan.need_rowdot_ws(len(groups) * L.ROWDOT_PARTS * (kmax + 1))
         if self.addends:
-            self.dlogit = [plan.new(1) for _ in groups]
+            if row_offsets is not None:
+                shared = plan.new(1)                      # ragged groups own disjoint rows of one buffer
+                self.dlogit = [shared for _ in groups]
+            else:
+                self.dlogit = [plan.new(1) for _ in groups]
         self._keep = []
         plan.add(self)
 
@@ -609,13 +723,34 @@ class RowDot:
         plan.fwd_steps.append(plan.call("cdc_rowdot_fwd", C.byref(a)))
 
     def build_bwd(self, plan, gs):
+        # groups that read the SAME x (CrossNetMix's gate scores) would race on dx inside one launch: they go out
+        # in successive launches; groups with private inputs (towers) share one
+        waves = []
+        for i, g in enumerate(self.groups):
+            key = (id(g["x"].root), g["x"].col0, g["x"].cols)
+            for w in waves:
+                if self.row_offsets is not None or key not in w["keys"]:
+                    w["keys"].add(key)
+                    w["idx"].append(i)
+                    break
+            else:
+                waves.append({"keys": {key}, "idx": [i]})
+        ragged_acc = {}
+        for w in waves:
+            self._build_bwd_launch(plan, gs, w["idx"], ragged_acc)
+
+    def _build_bwd_launch(self, plan, gs, idxs, ragged_acc):
         a = L.RowdotBwdArgs()
-        a.n_groups, a.sigmoid, a.M = len(self.groups), 1 if self.sigmoid else 0, self.M
-        a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr()
+        a.n_groups, a.sigmoid, a.M = len(idxs), 1 if self.sigmoid else 0, self.M
+        first = idxs[0]
+        a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr() + 4 * first
+        if self.row_offsets is not None:
+            assert idxs == list(range(first, first + len(idxs)))
         a.workspace = plan._rowdot_ws.data_ptr()
         post = []
-        for i, g in enumerate(self.groups):
-            G = a.g[i]
+        for slot, i in enumerate(idxs):
+            g = self.groups[i]
+            G = a.g[slot]
             plan.ensure_grad(g["out"], gs)
             og = g["out"].grad
             G.dout, G.ld_dout = og.ptr, og.ld
@@ -629,11 +764,24 @@ class RowDot:
                     raise RuntimeError("rowdot cannot consume an activation-fused linear output")
                 xg = g["x"].grad
                 G.dx, G.lddx = xg.ptr, xg.ld
-                G.accumulate_dx = 1 if gs.claim(g["x"]) else 0
+                if self.row_offsets is not None:
+                    key = (id(g["x"].root), g["x"].col0, g["x"].cols)
+                    if key not in ragged_acc:
+                        ragged_acc[key] = gs.claim(g["x"])
+                    G.accumulate_dx = 1 if ragged_acc[key] else 0
+                else:
+                    G.accumulate_dx = 1 if gs.claim(g["x"]) else 0
             gw = plan.param_grad(g["w"])
             if plan._claim_param(g["w"]):
-                raise RuntimeError("rowdot weight used twice in one plan")
-            G.dw = gw.data_ptr()
+                # the same weight is used by an earlier-built op (CrossNetMix gates are shared by every layer):
+                # write this use's gradient to a temporary and add it afterwards
+                tmp = torch.zeros_like(gw)
+                self._keep.append(tmp)
+                G.dw = tmp.data_ptr()
+                post.append(plan.call("cdc_copy_or_add", _p(gw), C.c_int64(gw.numel()), _p(tmp), C.c_int64(gw.numel()),
+                                      C.c_int64(1), gw.numel(), 1))
+            else:
+                G.dw = gw.data_ptr()
             if g.get("b") is not None:
                 gb = plan.param_grad(g["b"])
                 plan._claim_param(g["b"])
@@ -642,7 +790,7 @@ class RowDot:
                 G.dbias = None
             if self.addends:
                 G.dlogit, G.ld_dlogit = self.dlogit[i].ptr, self.dlogit[i].ld
-                for ad in self.addends:
+                for ad in (self.addends if (self.row_offsets is None or i == 0) else []):
                     adg = ad.grad
                     if gs.claim(ad):
                         post.append(plan.call("cdc_add_inplace", adg.cptr(), C.c_int64(adg.ld), self.dlogit[i].cptr(),
@@ -697,3 +845,261 @@ class CrossLayer:
         if same:
             plan.bwd_steps.append(plan.call("cdc_add_inplace", x0g.cptr(), C.c_int64(x0g.ld), dxl.cptr(), C.c_int64(dxl.ld),
                                             C.c_int64(plan.B), self.x0.cols))
+
+
+class Tanh:
+    """y = tanh(x) over a whole buffer (CrossNetMix, model/layer.py:387,389)."""
+
+    def __init__(self, plan, x, out=None):
+        self.x = x
+        self.out = out if out is not None else plan.new(x.cols, rows=x.rows)
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        plan.fwd_steps.append(plan.call("cdc_tanh_fwd", self.x.cptr(), C.c_int64(self.x.ld), self.out.cptr(), C.c_int64(self.out.ld),
+                                        C.c_int64(self.x.rows), self.x.cols))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        if self.x.mask is not None:
+            raise RuntimeError("tanh cannot consume an activation-fused linear output")
+        acc = gs.claim(self.x)
+        og, xg = self.out.grad, self.x.grad
+        plan.bwd_steps.append(plan.call("cdc_tanh_bwd", og.cptr(), C.c_int64(og.ld), self.out.cptr(), C.c_int64(self.out.ld), xg.cptr(),
+                                        C.c_int64(xg.ld), C.c_int64(self.x.rows), self.x.cols, 1 if acc else 0))
+
+
+class MatmulRight:
+    """y_g = x_g @ M_g with M_g stored [K, N] row-major (CrossNetMix's V: model/layer.py:384 `v_list[i][k].t() @ x`).
+    The three contractions reuse the grouped-linear kernels with the operand roles rotated."""
+
+    def __init__(self, plan, groups):
+        self.groups = groups
+        self.M = plan.B
+        assert len(groups) <= L.MAX_GROUPS
+        for g in groups:
+            K, N = g["m"].shape
+            assert g["x"].cols == K
+            if g.get("out") is None:
+                g["out"] = plan.new(N)
+        self.outs = [g["out"] for g in groups]
+        self._keep = []
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        a = L.LinBwdxArgs()
+        a.n_out = a.n_seg = len(self.groups)
+        a.mask_scale = 1.0
+        a.row_offsets = None
+        for i, g in enumerate(self.groups):
+            K, N = g["m"].shape
+            O, S = a.o[i], a.s[i]
+            O.dx, O.lddx = g["out"].ptr, g["out"].ld
+            O.mask_y, O.mask_cols, O.accumulate = None, 0, 0
+            O.M, O.K = self.M, N
+            S.dz, S.lddz = g["x"].ptr, g["x"].ld
+            S.w, S.ldw = g["m"].data_ptr(), N
+            S.N, S.out = K, i
+        self._keep.append(a)
+        fl = sum(2.0 * self.M * g["m"].shape[0] * g["m"].shape[1] for g in self.groups)
+        plan.fwd_steps.append(plan.call("cdc_glinear_bwd_x", C.byref(a), plan.prec, what="cdc_glinear_bwd_x(matmul_right fwd)", flops=fl))
+
+    def build_bwd(self, plan, gs):
+        for g in self.groups:
+            plan.ensure_grad(g["out"], gs)
+        # dM = x^T @ dY  (grad-weight kernel with dz := x, x := dY)
+        a = L.LinBwdwArgs()
+        a.n_groups, a.split_k, a.workspace, a.row_offsets = len(self.groups), 1, None, None
+        for i, g in enumerate(self.groups):
+            K, N = g["m"].shape
+            G = a.g[i]
+            og = g["out"].grad
+            G.dz, G.lddz = g["x"].ptr, g["x"].ld
+            G.x, G.ldx = og.ptr, og.ld
+            gm = plan.param_grad(g["m"])
+            G.dw, G.lddw = gm.data_ptr(), N
+            G.db = None
+            G.M, G.N, G.K = self.M, K, N
+            G.accumulate = 1 if plan._claim_param(g["m"]) else 0
+        self._keep.append(a)
+        plan.bwd_steps.append(plan.call("cdc_glinear_bwd_w", C.byref(a), plan.prec, what="cdc_glinear_bwd_w(matmul_right)"))
+        # dX = dY @ M^T  (forward kernel with w := M as [N=K_in, K=N_out]); it cannot accumulate, so go through a temporary
+        f = L.LinFwdArgs()
+        f.n_groups, f.relu, f.drop_p, f.seed, f.seed_offset_dev, f.row_offsets = len(self.groups), 0, 0.0, 0, None, None
+        post = []
+        for i, g in enumerate(self.groups):
+            K, N = g["m"].shape
+            if g["x"].mask is not None:
+                raise RuntimeError("matmul_right cannot consume an activation-fused linear output")
+            G = f.g[i]
+            og = g["out"].grad
+            xg = g["x"].grad
+            acc = gs.claim(g["x"])
+            if acc:
+                tmp = plan.new(K)
+                dst = tmp
+                post.append(plan.call("cdc_copy_or_add", xg.cptr(), C.c_int64(xg.ld), tmp.cptr(), C.c_int64(tmp.ld), C.c_int64(self.M), K, 1))
+            else:
+                dst = xg
+            G.x, G.ldx = og.ptr, og.ld
+            G.w, G.ldw = g["m"].data_ptr(), N
+            G.bias = None
+            G.y, G.ldy = dst.ptr, dst.ld
+            G.M, G.N, G.K = self.M, K, N
+            G.act_cols = 0
+        self._keep.append(f)
+        plan.bwd_steps.append(plan.call("cdc_glinear_fwd", C.byref(f), plan.prec, what="cdc_glinear_fwd(matmul_right bwd)"))
+        plan.bwd_steps.extend(post)
+
+
+class CrossCombine:
+    """out[:, k*P+e] = x0[:, e] * (u[:, k*P+e] + b1[e]) + b2[e] + r[:, k*P+e]
+    CrossNetV2 (n_rep=1, b2=b_l, r=x_l: model/layer.py:342) and CrossNetMix's `x_0 * (uv_x + bias)` (:393-394)."""
+
+    def __init__(self, plan, x0, u, b1=None, b2=None, r=None, n_rep=1, out=None):
+        self.x0, self.u, self.b1, self.b2, self.r, self.n_rep = x0, u, b1, b2, r, n_rep
+        self.P = x0.cols
+        assert u.cols == self.P * n_rep
+        self.out = out if out is not None else plan.new(u.cols)
+        self.ws = torch.empty(L.ROWDOT_PARTS * 2 * self.P, dtype=torch.float32, device=plan.device)
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        r = self.r
+        plan.fwd_steps.append(plan.call("cdc_cross_combine_fwd", self.x0.cptr(), C.c_int64(self.x0.ld), self.u.cptr(), C.c_int64(self.u.ld),
+                                        _p(None if self.b1 is None else self.b1.data), _p(None if self.b2 is None else self.b2.data),
+                                        None if r is None else r.cptr(), C.c_int64(0 if r is None else r.ld), self.out.cptr(),
+                                        C.c_int64(self.out.ld), C.c_int64(plan.B), self.P, self.n_rep))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        for b in (self.x0, self.u, self.r):
+            if b is not None and b.mask is not None:
+                raise RuntimeError("cross_combine cannot consume an activation-fused linear output")
+        og = self.out.grad
+        plan.ensure_grad(self.x0, gs)                      # d_x0 accumulates inside the kernel
+        x0g = self.x0.grad
+        if gs.claim(self.u):
+            raise RuntimeError("cross_combine: u feeds more than one consumer")
+        ug = self.u.grad
+        rg, acc_r = None, 0
+        if self.r is not None:
+            acc_r = 1 if gs.claim(self.r) else 0
+            rg = self.r.grad
+        db1 = db2 = None
+        a1 = a2 = 0
+        if self.b1 is not None:
+            db1 = plan.param_grad(self.b1)
+            a1 = 1 if plan._claim_param(self.b1) else 0
+        if self.b2 is not None:
+            db2 = plan.param_grad(self.b2)
+            a2 = 1 if plan._claim_param(self.b2) else 0
+        plan.bwd_steps.append(plan.call(
+            "cdc_cross_combine_bwd", og.cptr(), C.c_int64(og.ld), self.x0.cptr(), C.c_int64(self.x0.ld), self.u.cptr(), C.c_int64(self.u.ld),
+            _p(None if self.b1 is None else self.b1.data), ug.cptr(), C.c_int64(ug.ld), x0g.cptr(), C.c_int64(x0g.ld),
+            None if rg is None else rg.cptr(), C.c_int64(0 if rg is None else rg.ld), acc_r, _p(db1), a1, _p(db2), a2, _p(self.ws),
+            C.c_int64(plan.B), self.P, self.n_rep))
+
+
+class AddOut:
+    """out = a + b (CrossNetMix residual `moe_out + x_l`, model/layer.py:403)."""
+
+    def __init__(self, plan, a, b, out=None):
+        self.a, self.b = a, b
+        self.out = out if out is not None else plan.new(a.cols)
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        plan.fwd_steps.append(plan.call("cdc_add_out", self.a.cptr(), C.c_int64(self.a.ld), self.b.cptr(), C.c_int64(self.b.ld),
+                                        self.out.cptr(), C.c_int64(self.out.ld), C.c_int64(plan.B), self.a.cols))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        og = self.out.grad
+        for t in (self.a, self.b):
+            if t.mask is not None:
+                raise RuntimeError("add cannot consume an activation-fused linear output")
+            acc = 1 if gs.claim(t) else 0
+            tg = t.grad
+            plan.bwd_steps.append(plan.call("cdc_copy_or_add", tg.cptr(), C.c_int64(tg.ld), og.cptr(), C.c_int64(og.ld),
+                                            C.c_int64(plan.B), t.cols, acc))
+
+
+class StarFuse:
+    """out_g = a_g (*|+) s for every domain g in one launch (model/star.py:90-93,100-102,169-176).
+    a: list of per-domain Parameters, s: the shared Parameter; outputs live in one [n, ...] scratch tensor whose
+    per-domain slices are handed to the consumers as TViews (their gradients come back through the same scratch)."""
+
+    def __init__(self, plan, a_list, s, op):
+        assert op in ("mul", "add")
+        self.a_list, self.s, self.op = a_list, s, 0 if op == "mul" else 1
+        n = len(a_list)
+        shape = tuple(s.shape)
+        self.out = torch.empty((n,) + shape, dtype=torch.float32, device=plan.device)
+        self.d_out = torch.zeros((n,) + shape, dtype=torch.float32, device=plan.device)
+        self.views = [TView(self.out[g], self.d_out[g]) for g in range(n)]
+        self._keep = []
+        plan.add(self)
+
+    def _args(self, c0, chunk, backward, plan):
+        a = L.StarFuseArgs()
+        a.n, a.op, a.size = len(chunk), self.op, self.s.numel()
+        a.s = self.s.data_ptr()
+        if backward:
+            a.ds = plan.param_grad(self.s).data_ptr()
+            a.accumulate_ds = 1 if plan._claim_param(self.s) else 0
+        for i, p in enumerate(chunk):
+            a.a[i] = p.data_ptr()
+            if backward:
+                a.out[i] = self.d_out[c0 + i].data_ptr()
+                a.da[i] = plan.param_grad(p).data_ptr()
+                if plan._claim_param(p):
+                    raise RuntimeError("a STAR domain parameter is used twice in one plan")
+            else:
+                a.out[i] = self.out[c0 + i].data_ptr()
+        self._keep.append(a)
+        return a
+
+    def build_fwd(self, plan):
+        for c0 in range(0, len(self.a_list), L.MAX_GROUPS):
+            a = self._args(c0, self.a_list[c0:c0 + L.MAX_GROUPS], False, plan)
+            plan.fwd_steps.append(plan.call("cdc_star_fuse_fwd", C.byref(a)))
+
+    def build_bwd(self, plan, gs):
+        for c0 in range(0, len(self.a_list), L.MAX_GROUPS):
+            a = self._args(c0, self.a_list[c0:c0 + L.MAX_GROUPS], True, plan)
+            plan.bwd_steps.append(plan.call("cdc_star_fuse_bwd", C.byref(a)))
+
+
+class GroupPartition:
+    """Stable partition of the batch rows by group id + permuted copy of a [B, C] buffer (model/star.py:84-86):
+    rows come out in ascending group order, original order inside a group."""
+
+    def __init__(self, plan, x, n_group):
+        self.x, self.n_group = x, n_group
+        self.group = torch.zeros(plan.B, dtype=torch.int64, device=plan.device)
+        self.row_offsets = torch.zeros(n_group + 1, dtype=torch.int32, device=plan.device)
+        self.order = torch.zeros(plan.B, dtype=torch.int32, device=plan.device)
+        self.out = plan.new(x.cols)
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        plan.fwd_steps.append(plan.call("cdc_group_partition", _p(self.group), _p(self.row_offsets), _p(self.order), C.c_int64(plan.B),
+                                        self.n_group))
+        plan.fwd_steps.append(plan.call("cdc_rows_permute", self.x.cptr(), C.c_int64(self.x.ld), _p(self.order), self.out.cptr(),
+                                        C.c_int64(self.out.ld), C.c_int64(plan.B), self.x.cols, 0))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        og = self.out.grad
+        if gs.claim(self.x):
+            tmp = plan.new(self.x.cols)
+            xg = self.x.grad
+            plan.bwd_steps.append(plan.call("cdc_rows_permute", og.cptr(), C.c_int64(og.ld), _p(self.order), tmp.cptr(), C.c_int64(tmp.ld),
+                                            C.c_int64(plan.B), self.x.cols, 1))
+            plan.bwd_steps.append(plan.call("cdc_copy_or_add", xg.cptr(), C.c_int64(xg.ld), tmp.cptr(), C.c_int64(tmp.ld),
+                                            C.c_int64(plan.B), self.x.cols, 1))
+        else:
+            xg = self.x.grad
+            plan.bwd_steps.append(plan.call("cdc_rows_permute", og.cptr(), C.c_int64(og.ld), _p(self.order), xg.cptr(), C.c_int64(xg.ld),
+                                            C.c_int64(plan.B), self.x.cols, 1))

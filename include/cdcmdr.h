@@ -73,11 +73,15 @@ int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out
 int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
                           int32_t* uniq_cnt, int64_t B, int32_t F, void* stream);
 
-/* Dense gradient of the table, as aten::embedding_dense_backward produces it for the
- * reference (model/layer.py:140,153): grad[row,:] += sum over the row's segment of
- * d_out[b, f*D:(f+1)*D], summed in ascending b (the CPU reference's order). */
-int cdc_embed_grad_dense(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
-                         const int32_t* perm, const int32_t* uniq_cnt, float* grad,
+/* Per-row gradient of the batch: rowgrad[f, j, :] = sum over unique row j's segment of d_out[b, f*D:(f+1)*D],
+ * summed in ascending b (the order aten::embedding_dense_backward uses on the CPU, model/layer.py:140,153).
+ * sorted_scratch and rowgrad are [F, B, D] floats. */
+int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
+                          float* sorted_scratch, float* rowgrad, int64_t B, int32_t F, int32_t D, void* stream);
+
+/* Dense gradient of the table as the reference's nn.Embedding produces it (drop-in path feeding
+ * torch.optim.Adam): grad[uniq_row[f,j], :] += rowgrad[f,j,:]. */
+int cdc_embed_grad_dense(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt, float* grad,
                          int64_t B, int32_t F, int32_t D, int64_t R, void* stream);
 
 /* Adam hyper-parameters of run.py:720-721 (+ the L2 coefficient of model/layer.py:31), already
@@ -94,13 +98,12 @@ typedef struct {
 } cdc_adam_hp;
 
 /* Exact dense-Adam semantics for the whole table, in three launches:
- *  (1) touched: for every unique row of the batch: g = segsum(d_out) + 2*l2*w + wd*w, Adam
+ *  (1) touched: for every unique row of the batch: g = rowgrad (cdc_embed_segment_sum) + 2*l2*w + wd*w, Adam
  *      step t, result written to side[f,j,{w,m,v},D] (the table itself is not modified);
  *  (2) dense_pass: every row updated as an untouched row (g = 2*l2*w + wd*w) in one streaming
  *      pass; reg_sum (device double, may be NULL) += sum(w_old^2) (caller multiplies by l2);
  *  (3) patch: side rows copied over the rows touched by the batch. */
-int cdc_embed_adam_touched(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
-                           const int32_t* perm, const int32_t* uniq_cnt,
+int cdc_embed_adam_touched(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt,
                            const float* w, const float* m, const float* v, float* side,
                            cdc_adam_hp hp, const int32_t* step_dev,
                            int64_t B, int32_t F, int32_t D, void* stream);
@@ -118,8 +121,7 @@ int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* uniq_cnt,
                            float* w, float* m, float* v, int32_t* last,
                            cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring, int32_t ring_len,
                            int64_t B, int32_t F, int32_t D, void* stream);
-int cdc_embed_lazy_update(const float* d_out, const int32_t* uniq_row, const int32_t* seg_start,
-                          const int32_t* perm, const int32_t* uniq_cnt,
+int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt,
                           float* w, float* m, float* v, int32_t* last,
                           cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring, int32_t ring_len,
                           int64_t B, int32_t F, int32_t D, void* stream);
@@ -192,6 +194,10 @@ typedef struct {
 } cdc_bwdw_group;
 typedef struct {
     int32_t n_groups;
+    int32_t split_k;                 /* > 1: the batch rows are cut into split_k slices, each reduced by its own
+                                        workgroup into an fp32 slab; a second launch adds the slabs in slice order
+                                        (deterministic; no float atomics) */
+    float* workspace;                /* split_k > 1: >= split_k * sum_g (N_g*K_g + N_g) floats */
     const int32_t* row_offsets;      /* ragged rows (device [n_groups+1]) or NULL */
     cdc_bwdw_group g[CDC_MAX_GROUPS];
 } cdc_lin_bwdw_args;
@@ -259,6 +265,8 @@ typedef struct {
     int32_t n_seg;
     int32_t training;
     int32_t relu;
+    int32_t skip_le1;                 /* 0: normalisation skipped when the (group's) batch has exactly 1 row
+                                         (model/layer.py:202, star.py:134); 1: when it has <= 1 rows (DNN, layer.py:293) */
     float eps, momentum;
     float drop_p; uint64_t seed; const int32_t* seed_offset_dev;
     int64_t M;                        /* rows (upper bound when ragged) */
@@ -279,6 +287,8 @@ typedef struct {
     float* dgamma; float* dbeta;
     int32_t C;
     int32_t row_group;
+    int32_t accumulate_dx;            /* 1: dx += (several segments normalise the same input: STAR's domain_norm) */
+    int32_t pad_;
 } cdc_bn_bseg;
 typedef struct {
     int32_t n_seg;
@@ -361,6 +371,31 @@ int cdc_cross_bwd(const float* d_out, int64_t ldo, const float* x0, int64_t ld0,
                   float* dw, float* db, float* workspace, int64_t B, int32_t E, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * DCN-v2 element-wise pieces (reference: model/layer.py:339-343 CrossNetV2 `x0 * W(x) + b + x`,
+ * model/layer.py:384-396 CrossNetMix `tanh`, `x_0 * (uv_x + bias)`, and the `moe_out + x_l` residual :403)
+ * The contractions themselves go through cdc_glinear_*.
+ * ---------------------------------------------------------------------------------------- */
+int cdc_tanh_fwd(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int32_t cols, void* stream);
+/* dx (=|+=) dy * (1 - y^2) */
+int cdc_tanh_bwd(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t lddx,
+                 int64_t rows, int32_t cols, int32_t accumulate, void* stream);
+/* out[:, k*P+e] = x0[:, e] * (u[:, k*P+e] + b1[e]) + b2[e] + r[:, k*P+e]   for k < n_rep, e < P = period
+ * (b1, b2 [P] and r [rows, P*n_rep] optional; n_rep > 1 = the experts of one CrossNetMix layer in one launch) */
+int cdc_cross_combine_fwd(const float* x0, int64_t ld0, const float* u, int64_t ldu, const float* b1, const float* b2,
+                          const float* r, int64_t ldr, float* out, int64_t ldo, int64_t rows, int32_t period, int32_t n_rep,
+                          void* stream);
+/* d_u = d_out*x0 ; d_x0 += sum_k d_out*(u+b1) ; d_r (=|+=) d_out ; db1 (=|+=) colsum(d_out*x0) ; db2 (=|+=) colsum(d_out)
+ * workspace >= CDC_ROWDOT_PARTS * 2 * period floats */
+int cdc_cross_combine_bwd(const float* d_out, int64_t lddo, const float* x0, int64_t ld0, const float* u, int64_t ldu,
+                          const float* b1, float* d_u, int64_t lddu, float* d_x0_acc, int64_t lddx0, float* d_r, int64_t lddr,
+                          int32_t accumulate_r, float* db1, int32_t accumulate_b1, float* db2, int32_t accumulate_b2,
+                          float* workspace, int64_t rows, int32_t period, int32_t n_rep, void* stream);
+int cdc_add_out(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
+                int64_t rows, int32_t cols, void* stream);
+int cdc_copy_or_add(float* dst, int64_t ldd, const float* src, int64_t lds, int64_t rows, int32_t cols,
+                    int32_t accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense-parameter Adam, multi-tensor (reference: run.py:720-721 torch.optim.Adam(lr, betas=(0.9,0.99),
  * eps=1e-8, weight_decay=wd) + the L2 term of model/layer.py:96-112 whose gradient is 2*l2*w):
  *   g = grad + 2*l2_i*w + wd*w ; Adam step t ; reg_sum += l2_i * sum(w_old^2) (device double).
@@ -380,6 +415,30 @@ typedef struct {
     cdc_adam_tensor t[CDC_MAX_TENSORS];
 } cdc_adam_args;
 int cdc_adam_multi(const cdc_adam_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * STAR parameter fusion (reference: model/star.py:90-93,100-102,169-176): for every domain g
+ *   out_g = a_g * s   (op 0: weights, BatchNorm gamma)   or   out_g = a_g + s   (op 1: biases, BatchNorm beta)
+ * backward: da_g = d_out_g * s | d_out_g ;  ds = sum_g d_out_g * a_g | sum_g d_out_g  (fixed order over g).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t n;                        /* domains in this launch (<= CDC_MAX_GROUPS) */
+    int32_t op;                       /* 0 = multiply, 1 = add */
+    int64_t size;                     /* elements per tensor */
+    const float* s;                   /* shared tensor */
+    float* ds;                        /* backward: gradient of the shared tensor */
+    int32_t accumulate_ds;            /* backward: ds += (a further chunk of domains) */
+    int32_t pad_;
+    const float* a[CDC_MAX_GROUPS];   /* per-domain tensors */
+    float* out[CDC_MAX_GROUPS];       /* forward outputs / backward: d_out */
+    float* da[CDC_MAX_GROUPS];        /* backward: gradients of the per-domain tensors */
+} cdc_star_fuse_args;
+int cdc_star_fuse_fwd(const cdc_star_fuse_args* a, void* stream);
+int cdc_star_fuse_bwd(const cdc_star_fuse_args* a, void* stream);
+
+/* out[r,c] (=|+=) sum_g in[r, g*cols + c]: fan-in of per-tower gradients of one shared input (fixed order over g) */
+int cdc_sum_slices(const float* in, int64_t ld_in, float* out, int64_t ld_out, int64_t rows, int32_t cols,
+                   int32_t n_slices, int32_t accumulate, void* stream);
 
 /* small utilities used by the step driver */
 int cdc_step_increment(int32_t* step_dev, void* stream);                 /* ++*step_dev */

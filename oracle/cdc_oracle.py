@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+MATMUL_BF16 = False  # True: restate the bf16 MFMA path (operands of every contraction rounded to bf16, fp32 accumulate)
 DROPOUT_P = 0.0     # parity runs use 0; bench.py's cpu_baseline sets the reference default (0.2) to time the same work
 
 
@@ -54,9 +55,30 @@ def embed(table, x_i32, field_dims):
 # --------------------------------------------------------------------------------------------------
 # building blocks
 # --------------------------------------------------------------------------------------------------
-def _lin(x, sd, prefix):
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _Bf16Matmul(torch.autograd.Function):
+    """y = x @ w^T exactly as the bf16 MFMA kernels contract it: operands rounded to bf16 (round-to-nearest-even) in the
+    forward AND in both backward contractions (dX = bf(dY) @ bf(W), dW = bf(dY)^T @ bf(X)), fp32 accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _bf(x) @ _bf(w).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        return _bf(dy) @ _bf(w), _bf(dy).t() @ _bf(x)
+
+
+def _lin(x, sd, prefix, mfma=True):
+    """nn.Linear. `mfma=False` marks the single-output layers the HIP path runs as fp32 row dot products."""
     b = sd.get(prefix + ".bias")
-    y = x @ sd[prefix + ".weight"].t()
+    w = sd[prefix + ".weight"]
+    y = _Bf16Matmul.apply(x, w) if (MATMUL_BF16 and mfma) else x @ w.t()
     return y if b is None else y + b
 
 
@@ -94,8 +116,9 @@ def mlp(x, sd, prefix, training, stats_out=None, output_layer=False):
     lin_pos = [k for k, (_, dim) in enumerate(layers) if dim == 2]
     for n, k in enumerate(lin_pos):
         idx = layers[k][0]
-        y = _lin(x, sd, f"{prefix}.layers.{idx}")
-        if output_layer and n == len(lin_pos) - 1:
+        is_out = output_layer and n == len(lin_pos) - 1
+        y = _lin(x, sd, f"{prefix}.layers.{idx}", mfma=not is_out)
+        if is_out:
             return y
         if k + 1 < len(layers) and layers[k + 1][1] == 1 and x.shape[0] != 1:
             y = _bn(y, sd, f"{prefix}.layers.{layers[k + 1][0]}", training, stats_out)
@@ -107,7 +130,7 @@ def mlp(x, sd, prefix, training, stats_out=None, output_layer=False):
 
 def wide_logit(e, sd):
     """FeaturesLinear (model/layer.py:122-126)."""
-    return _lin(e, sd, "linear.fc")
+    return _lin(e, sd, "linear.fc", mfma=False)
 
 
 def towers(tower_inputs, other_outs, sd, training, stats_out, prefix="towers"):

@@ -77,10 +77,10 @@ def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=No
             assert float(got.abs().max()) <= 1e-3 * max(wscale, 1e-3) + 1e-4, f"pre-BN bias grad {k} not ~0"
             continue
         if bf16:
-            # bf16 operands flip the sign of near-zero pre-activations, so single elements can move by O(1) of their
-            # value; the stated bound for the bf16 path is on the relative L2 error of each gradient tensor
+            # against the oracle's bf16 restatement; a relu unit whose pre-activation sits within fp32 accumulation noise of
+            # zero may still flip, so the bound is on the relative L2 error of each gradient tensor
             gd, wd = got.detach().cpu().double(), g.double()
             rel = float((gd - wd).norm() / max(float(wd.norm()), 1e-12))
-            assert rel < 8e-2 or float((gd - wd).abs().max()) < 1e-4, f"grad {k}: relative L2 error {rel:.3e} (bf16 bound 8e-2)"
+            assert rel < 5e-2 or float((gd - wd).abs().max()) < 1e-5, f"grad {k}: relative L2 error {rel:.3e} vs bf16 restatement"
         else:
             assert_close(got, g, rtol, atol * max(scale, 1.0), f"grad {k}")
