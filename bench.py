@@ -59,7 +59,12 @@ def cpu_baseline(args, model, field_dims, Xc, yc, gc):
     """The oracle restatement of the reference step on the host cores: dense table gradient, whole-table L2,
     dense torch.optim.Adam — exactly what run.py:481-493 makes torch do."""
     from oracle import cdc_oracle as O
-    n_threads = os.cpu_count() or 1
+    # the cores this process may actually run on (a container's CPU share), not the host's core count
+    try:
+        n_threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_threads = os.cpu_count() or 1
+    n_threads = max(1, min(n_threads, int(os.environ.get("CDC_CPU_THREADS", "64"))))
     torch.set_num_threads(n_threads)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
@@ -69,7 +74,10 @@ def cpu_baseline(args, model, field_dims, Xc, yc, gc):
     O.DROPOUT_P = args.dropout
     B = args.batch
     times = []
+    t_begin = time.perf_counter()
     for s in range(1 + args.cpu_steps):
+        if s >= 2 and time.perf_counter() - t_begin > 40.0:      # bounded sample: stop after ~40 s of CPU work
+            break
         x = Xc[s % len(Xc)]
         y = torch.from_numpy(yc[s % len(yc)])
         g = torch.from_numpy(gc[s % len(gc)]).reshape(-1, 1)
@@ -80,14 +88,14 @@ def cpu_baseline(args, model, field_dims, Xc, yc, gc):
         opt.zero_grad()
         loss.sum().backward()
         opt.step()
-        float(loss.sum())                                    # loss.item() as run.py:493
+        float(loss.sum().detach())                           # loss.item() as run.py:493
         for k, v in stats.items():
             sd[k] = v
         times.append(time.perf_counter() - t0)
     O.DROPOUT_P = 0.0
     t = float(np.mean(times[1:]))
     return {"value": B / t, "unit": "samples/s", "cores": n_threads, "kind": "port",
-            "sample": f"{args.cpu_steps} steps of batch {B} after 1 warm-up, same shapes, weights copied from the GPU model "
+            "sample": f"{len(times) - 1} steps of batch {B} after 1 warm-up, same shapes, weights copied from the GPU model "
                       f"({t * 1e3:.0f} ms/step)"}
 
 

@@ -211,13 +211,15 @@ def load():
     if _lib is not None:
         return _lib
     path = _build.LIB_PATH
-    if not os.path.exists(path):
+    if not _build.is_fresh():
+        # missing, or older than csrc/ + include/ (content hash): rebuild in-tree when a compiler is around
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001
-            raise HipExtensionError(
-                f"libcdcmdr.so is missing at {path} and could not be built ({e}); "
-                "run `python __graft_entry__.py build` — there is no CPU fallback") from e
+            if not os.path.exists(path):
+                raise HipExtensionError(
+                    f"libcdcmdr.so is missing at {path} and could not be built ({e}); "
+                    "run `python __graft_entry__.py build` — there is no CPU fallback") from e
     try:
         lib = C.CDLL(path)
     except OSError as e:

@@ -64,7 +64,7 @@ __device__ __forceinline__ float cdc_uniform(uint64_t seed, uint64_t idx) {
 //   g  = g_in + l2_twice*w          (autograd: grad of sum(l2*w^2))
 //   g  = g + wd*w                   (grad.add(param, alpha=wd))
 //   m  = lerp(m, g, 1-beta1)        (exp_avg.lerp_)
-//   v  = v*beta2 + (1-beta2)*g*g    (mul_ then addcmul_)
+//   v  = fma((1-beta2)*g, g, v*beta2) (mul_ then addcmul_)
 //   w -= step_size * m / (sqrt(v)/bc2_sqrt + eps)
 struct AdamConsts {
     float lerp_w, beta2, omb2, eps, wd, l2_twice;
@@ -77,7 +77,8 @@ __device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g_
     g = fmaf(w, c.wd, g);                                   // ATen add(alpha): vec fmadd
     m = fmaf(c.lerp_w, __fsub_rn(g, m), m);                 // ATen lerp, |weight| < 0.5: fmadd
     v = __fmul_rn(v, c.beta2);
-    v = __fadd_rn(v, __fmul_rn(__fmul_rn(c.omb2, g), g));   // addcmul: self + (value*t1)*t2
+    v = fmaf(__fmul_rn(c.omb2, g), g, v);                   // addcmul: fmadd(value*t1, t2, self) — the rounding pattern that
+                                                            // reproduces torch CPU Adam bit for bit (oracle/adam_elem_ref.c)
     float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), c.eps);
     w = __fadd_rn(w, __fdiv_rn(__fmul_rn(-step_size, m), denom));   // addcdiv: self + (value*t1)/t2
 }

@@ -1,0 +1,142 @@
+"""The N>1 exchange pattern of the training step rehearsed on CPU: world_size 2, gloo backend, the package's own
+DataParallel helper, the CPU oracle standing in for the kernels (the HIP path cannot run without a GPU).
+
+Checked: sharded step == single step on the concatenated batch — (1) ONE sum all-reduce of the flat dense-gradient
+arena with the loss carrying 1/global_batch, (2) all-gather of (row index, row gradient) pairs so that every rank forms
+the identical per-row table gradient, (3) the loss all-reduce.  BatchNorm runs on its running statistics here: batch
+statistics under DP are per-rank (as torch DDP without SyncBatchNorm), which DESIGN.md lists as the open item."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FD = [7, 60, 3, 20, 5]
+B_GLOBAL = 24
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    sys.path.insert(0, ROOT)
+    from cdcmdr_amd.model.ple import PLE
+    torch.manual_seed(7)
+    m = PLE(FD, 4, 3, 1, 1, ((8,), (4,)), (4,), dropout=0.0)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(3)
+    X = np.stack([rng.integers(0, d, size=B_GLOBAL) for d in FD], axis=1).astype(np.int32)
+    y = torch.from_numpy(rng.integers(0, 2, size=B_GLOBAL).astype(np.float32))
+    g = torch.from_numpy(rng.integers(0, 3, size=B_GLOBAL).astype(np.int64)).reshape(-1, 1)
+    return sd, X, y, g
+
+
+def _local_grads(sd, X, y, g, inv_count):
+    """sum over the local rows of BCE * inv_count -> dense grads + (row index, row gradient) pairs of the gathered rows."""
+    from oracle import cdc_oracle as O
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    s2 = dict(sd)
+    s2.update(leaves)
+    table = leaves["embedding.embedding_dict.weight"]
+    e = O.embed(table, X, FD)
+    e.retain_grad()
+    # ple_forward gathers from the table itself; route the gradient through `e` by calling the pieces directly
+    inputs = [e] * 4
+    for lvl in range(2):
+        inputs = O.cgc(inputs, s2, f"cgc_layers.{lvl}", 3, False)
+    p = O.towers(inputs[:3], [O.wide_logit(e, s2)], s2, False, None).gather(1, g).squeeze(1)
+    per_row = -(y * torch.clamp(torch.log(p), min=-100) + (1 - y) * torch.clamp(torch.log1p(-p), min=-100))
+    loss = per_row.sum() * inv_count
+    loss.backward()
+    dense = {k: t.grad for k, t in leaves.items() if k != "embedding.embedding_dict.weight" and t.grad is not None}
+    idx = torch.from_numpy(O.gather_index(X, FD).astype(np.int32))
+    return loss.detach(), dense, idx, e.grad.detach()
+
+
+def _table_grad(idx_all, dE_all, R, D):
+    grad = torch.zeros(R, D)
+    F = idx_all.shape[1]
+    grad.index_add_(0, idx_all.reshape(-1).long(), dE_all.reshape(-1, D)[: idx_all.numel()].reshape(idx_all.shape[0] * F, D))
+    return grad
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    from cdcmdr_amd.dist import DataParallel
+    torch.set_num_threads(1)
+    dp = DataParallel(backend="gloo")
+    sd, X, y, g = _problem()
+    lo, hi = dp.shard(B_GLOBAL)
+    loss, dense, idx, dE = _local_grads(sd, X[lo:hi], y[lo:hi], g[lo:hi], 1.0 / B_GLOBAL)
+    # (1) flat arena, one SUM all-reduce
+    names = sorted(dense)
+    arena = torch.cat([dense[k].reshape(-1) for k in names])
+    dp.all_reduce_sum(arena)
+    # (2) table: all-gather of (idx, dE)
+    per = hi - lo
+    idx_all = torch.empty((per * world, len(FD)), dtype=torch.int32)
+    dE_all = torch.empty((per * world, dE.shape[1]), dtype=torch.float32)
+    dp.all_gather_rows(idx_all, idx)
+    dp.all_gather_rows(dE_all, dE)
+    # (3) loss
+    dp.all_reduce_sum(loss)
+    torch.save({"arena": arena, "names": names, "shapes": [tuple(dense[k].shape) for k in names], "idx_all": idx_all, "dE_all": dE_all,
+                "loss": loss}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dp.barrier()
+    dp.close()
+
+
+def test_two_rank_exchange_equals_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    sd, X, y, g = _problem()
+    loss, dense, idx, dE = _local_grads(sd, X, y, g, 1.0 / B_GLOBAL)
+    R, D = sd["embedding.embedding_dict.weight"].shape
+    want_table = _table_grad(idx, dE, R, D)
+    outs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    for o in outs:
+        off = 0
+        for k, shp in zip(o["names"], o["shapes"]):
+            n = int(np.prod(shp))
+            got = o["arena"][off:off + n].reshape(shp)
+            off += n
+            assert torch.allclose(got, dense[k], rtol=1e-5, atol=1e-7), k
+        assert torch.equal(o["idx_all"], idx)                       # rank order == batch order
+        got_table = _table_grad(o["idx_all"], o["dE_all"], R, D)
+        assert torch.allclose(got_table, want_table, rtol=1e-5, atol=1e-7)
+        assert abs(float(o["loss"]) - float(loss)) < 1e-6
+    # both ranks hold identical exchanged data -> identical table update on every replica
+    assert torch.equal(outs[0]["dE_all"], outs[1]["dE_all"]) and torch.equal(outs[0]["arena"], outs[1]["arena"])
+
+
+def test_shard_ranges_partition_the_batch():
+    sys.path.insert(0, ROOT)
+    from cdcmdr_amd.dist import DataParallel
+    old = {k: os.environ.get(k) for k in ("WORLD_SIZE", "RANK")}
+    try:
+        covered = []
+        for r in range(4):
+            os.environ["WORLD_SIZE"], os.environ["RANK"] = "1", "0"
+            dp = DataParallel(backend="gloo")
+            dp.world_size, dp.rank = 4, r
+            covered.append(dp.shard(4096))
+        assert covered == [(0, 1024), (1024, 2048), (2048, 3072), (3072, 4096)]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
