@@ -1,0 +1,4 @@
+from cdcmdr_amd.model.adl import *  # noqa: F401,F403
+from cdcmdr_amd.model import adl as _m
+
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})

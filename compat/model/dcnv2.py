@@ -1,0 +1,4 @@
+from cdcmdr_amd.model.dcnv2 import *  # noqa: F401,F403
+from cdcmdr_amd.model import dcnv2 as _m
+
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})
