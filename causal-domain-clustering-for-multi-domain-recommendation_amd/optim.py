@@ -31,9 +31,11 @@ def step_scalar_table(lr, beta1, beta2, n=4096):
 
 
 class FusedAdam:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode="dense"):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode="dense", frozen=()):
+        """frozen: parameters left untouched by the optimiser (like leaving them out of torch.optim.Adam's list)."""
         assert table_mode in ("dense", "lazy")
         self.model = model
+        self.frozen = {id(p) for p in frozen}
         self.lib = L.load()
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.table_mode = table_mode
@@ -168,7 +170,7 @@ class FusedAdam:
             items = []
             for k, g in param_grads.items():
                 p = param_refs[k]
-                if p is self.table:
+                if p is self.table or id(p) in self.frozen:
                     continue
                 st = self.state.get(k)
                 if st is None:
