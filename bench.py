@@ -28,8 +28,9 @@ METRIC = "train samples/sec + AUC parity, PLE 3-domain batch 4096 at 1/2/4/8 MI3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=2000,
+                    help="default covers the ~1700 steps in which Adam bias corrections still move and lets the lazy table reach its steady state")
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (weak scaling)")
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1_000_000)
@@ -41,7 +42,9 @@ def parse():
     ap.add_argument("--id-dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=4)
-    ap.add_argument("--pool", type=int, default=32, help="resident synthetic batches cycled through")
+    ap.add_argument("--pool", type=int, default=0,
+                    help="resident synthetic batches cycled through; 0 = warmup+steps (max 1024), so that no batch repeats and "
+                         "the lazy table replay sees realistic gaps between two look-ups of a row")
     return ap.parse_args()
 
 
@@ -123,6 +126,8 @@ def main():
     ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dp)
 
     B = args.batch
+    if args.pool <= 0:
+        args.pool = max(8, min(args.warmup + args.steps, 1024))
     n_rows = B * args.pool * world
     X, y = make_dataset(n_rows, field_dims, n_domain=3, domain_idx=10, seed=2000, dist=args.id_dist)
     lo = rank * B * args.pool

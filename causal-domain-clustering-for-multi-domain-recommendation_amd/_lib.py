@@ -29,7 +29,8 @@ c_p = C.c_void_p
 
 class AdamHP(C.Structure):
     _fields_ = [("lerp_w", c_f), ("beta2", c_f), ("one_minus_beta2", c_f), ("eps", c_f),
-                ("weight_decay", c_f), ("l2_twice", c_f), ("step_scalars", c_p), ("n_scalars", c_i32)]
+                ("weight_decay", c_f), ("l2_twice", c_f), ("step_scalars", c_p), ("n_scalars", c_i32), ("fast_replay", c_i32),
+                ("inv_bc2", c_p)]
 
 
 class LinGroup(C.Structure):
@@ -160,7 +161,7 @@ _SIGNATURES = {
     "cdc_embed_adam_patch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_catchup": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_update": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
-    "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_p, c_i32, c_p]),
+    "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_i32, c_p, c_i32, c_p]),
     "cdc_glinear_fwd": (c_i32, [C.POINTER(LinFwdArgs), c_i32, c_p]),
     "cdc_glinear_bwd_x": (c_i32, [C.POINTER(LinBwdxArgs), c_i32, c_p]),
     "cdc_glinear_bwd_w": (c_i32, [C.POINTER(LinBwdwArgs), c_i32, c_p]),

@@ -82,6 +82,49 @@ __device__ __forceinline__ void adam_elem(float& w, float& m, float& v, float g_
     float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), c.eps);
     w = __fadd_rn(w, __fdiv_rn(__fmul_rn(-step_size, m), denom));   // addcdiv: self + (value*t1)/t2
 }
+// The same L2-only step (g_in = 0) with the hardware reciprocal / square root (1 ulp each) instead of the IEEE
+// sequences: ~15 instead of ~90 instructions per element-step.  Used only for the lazy replay of untouched rows.
+__device__ __forceinline__ void adam_elem_fast(float& w, float& m, float& v, const AdamConsts& c, float step_size, float inv_bc2) {
+    float g = __fmul_rn(c.l2_twice, w);
+    g = fmaf(w, c.wd, g);
+    m = fmaf(c.lerp_w, __fsub_rn(g, m), m);
+    v = fmaf(__fmul_rn(c.omb2, g), g, __fmul_rn(v, c.beta2));
+    const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2, c.eps);
+    w = fmaf(__fmul_rn(-step_size, m), __builtin_amdgcn_rcpf(denom), w);
+}
+// replays steps from+1 .. to of the L2-only recurrence for one element.  The per-step scalars come from the host table
+// while the bias corrections still move (t < n_scalars-1, ~1700 steps) and are constants afterwards.  When every lane of
+// the wave replays the same steps (rows not looked up since the last whole-table catch-up) the step index is kept in
+// SGPRs, so the table reads are scalar loads.
+template <bool FAST>
+__device__ __forceinline__ void adam_replay(float& w, float& m, float& v, int from, int to, const AdamConsts& c,
+                                            const cdc_adam_hp& hp) {
+    const int last_i = hp.n_scalars - 1;
+    const float ss_conv = hp.step_scalars[2 * last_i];
+    const float bc_conv = FAST ? hp.inv_bc2[last_i] : hp.step_scalars[2 * last_i + 1];
+    const int from0 = __builtin_amdgcn_readfirstlane(from);
+    if (__all(from == from0)) {
+        for (int s = from0 + 1; s <= to; ++s) {             // s, ss, bc are wave-uniform
+            float ss = ss_conv, bc = bc_conv;
+            if (s < last_i) {
+                ss = hp.step_scalars[2 * s];
+                bc = FAST ? hp.inv_bc2[s] : hp.step_scalars[2 * s + 1];
+            }
+            if (FAST) adam_elem_fast(w, m, v, c, ss, bc);
+            else adam_elem(w, m, v, 0.f, c, ss, bc);
+        }
+        return;
+    }
+    for (int s = from + 1; s <= to; ++s) {
+        float ss = ss_conv, bc = bc_conv;
+        if (s < last_i) {
+            ss = hp.step_scalars[2 * s];
+            bc = FAST ? hp.inv_bc2[s] : hp.step_scalars[2 * s + 1];
+        }
+        if (FAST) adam_elem_fast(w, m, v, c, ss, bc);
+        else adam_elem(w, m, v, 0.f, c, ss, bc);
+    }
+}
 __device__ __forceinline__ AdamConsts make_consts(const cdc_adam_hp& hp) {
     AdamConsts c;
     c.lerp_w = hp.lerp_w; c.beta2 = hp.beta2; c.omb2 = hp.one_minus_beta2;

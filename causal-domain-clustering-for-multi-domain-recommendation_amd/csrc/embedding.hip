@@ -370,6 +370,7 @@ extern "C" int cdc_embed_adam_patch(const float* side, const int32_t* uniq_row, 
 // recurrence (g = 2*l2*w + wd*w) is replayed on demand.  Every element-step is computed exactly once
 // with the same adam_elem as the dense pass, so both forms give identical bits.
 // ------------------------------------------------------------------------------------------------
+template <bool FAST>
 __global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
                                                       float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                       int32_t* __restrict__ last, cdc_adam_hp hp,
@@ -387,11 +388,7 @@ __global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict_
         const int from = last[row];
         if (from >= target) continue;
         float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
-        for (int s = from + 1; s <= target; ++s) {
-            float ss, bc;
-            step_scalars_at(hp.step_scalars, hp.n_scalars, s, ss, bc);
-            adam_elem(wv, mv, vv, 0.f, c, ss, bc);
-        }
+        adam_replay<FAST>(wv, mv, vv, from, target, c, hp);
         w[row * D + d] = wv; m[row * D + d] = mv; v[row * D + d] = vv;
         // last[row] is advanced by k_lazy_mark afterwards: every lane of the row reads it here
     }
@@ -419,8 +416,13 @@ extern "C" int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* un
     CDC_CHECK_ARG(B > 0 && F > 0 && D > 0, CDC_E_BADARG, "embed_lazy_catchup: bad sizes");
     const int64_t total = (int64_t)F * B * D;
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
-    hipLaunchKernelGGL(k_lazy_catchup, dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, w, m, v, last, hp,
-                       step_dev, (int32_t)B, F, D);
+    CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_catchup: fast_replay needs the inv_bc2 table");
+    if (hp.fast_replay)
+        hipLaunchKernelGGL(k_lazy_catchup<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, w, m, v, last, hp,
+                           step_dev, (int32_t)B, F, D);
+    else
+        hipLaunchKernelGGL(k_lazy_catchup<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, w, m, v, last, hp,
+                           step_dev, (int32_t)B, F, D);
     CDC_LAUNCH_CHECK("embed_lazy_catchup");
     int blocks2 = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 256 * 16);
     hipLaunchKernelGGL(k_lazy_mark, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, last, step_dev,
@@ -470,44 +472,48 @@ extern "C" int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_r
     return 0;
 }
 
-// all rows -> step (*step_dev + step_bias)
+// all rows -> step target = *step_dev + step_bias (only when target % period == 0).  Rows not looked up since the last
+// flush share one `last`, so whole waves replay the same steps: no divergence, coalesced float4 traffic.
+template <bool FAST>
 __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
-                                                    int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
-                                                    const int32_t* __restrict__ step_dev, int32_t step_bias) {
-    const AdamConsts c = make_consts(hp);
+                                                    const int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
+                                                    const int32_t* __restrict__ step_dev, int32_t step_bias, int32_t period) {
     const int target = *step_dev + step_bias;
+    if (period > 1 && (target % period) != 0) return;
+    const AdamConsts c = make_consts(hp);
     const int64_t total = R * D;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / D;
         const int from = last[row];
         if (from >= target) continue;
         float wv = w[i], mv = m[i], vv = v[i];
-        for (int s = from + 1; s <= target; ++s) {
-            float ss, bc;
-            step_scalars_at(hp.step_scalars, hp.n_scalars, s, ss, bc);
-            adam_elem(wv, mv, vv, 0.f, c, ss, bc);
-        }
+        adam_replay<FAST>(wv, mv, vv, from, target, c, hp);
         w[i] = wv; m[i] = mv; v[i] = vv;
     }
 }
 __global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ last, int64_t R, const int32_t* __restrict__ step_dev,
-                                                       int32_t step_bias) {
+                                                       int32_t step_bias, int32_t period) {
     const int target = *step_dev + step_bias;
+    if (period > 1 && (target % period) != 0) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x)
         if (last[i] < target) last[i] = target;
 }
 
 extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D, cdc_adam_hp hp,
-                                    const int32_t* step_dev, int32_t step_bias, double* reg_ring, int32_t ring_len,
+                                    const int32_t* step_dev, int32_t step_bias, int32_t period, double* reg_ring, int32_t ring_len,
                                     void* stream) {
     (void)reg_ring; (void)ring_len;
     CDC_CHECK_ARG(w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0, CDC_E_BADARG, "embed_lazy_flush: null pointer");
-    CDC_CHECK_ARG(R > 0 && D > 0, CDC_E_BADARG, "embed_lazy_flush: bad sizes");
+    CDC_CHECK_ARG(R > 0 && D > 0 && period >= 0, CDC_E_BADARG, "embed_lazy_flush: bad sizes");
+    CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_flush: fast_replay needs the inv_bc2 table");
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(R * D, 256), 256 * 16);
-    hipLaunchKernelGGL(k_lazy_flush, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, last, R, D, hp, step_dev, step_bias);
+    if (hp.fast_replay)
+        hipLaunchKernelGGL(k_lazy_flush<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, last, R, D, hp, step_dev, step_bias, period);
+    else
+        hipLaunchKernelGGL(k_lazy_flush<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, last, R, D, hp, step_dev, step_bias, period);
     CDC_LAUNCH_CHECK("embed_lazy_flush");
     int blocks2 = (int)std::min<int64_t>(cdc_ceil_div(R, 256), 256 * 16);
-    hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias);
+    hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias, period);
     CDC_LAUNCH_CHECK("embed_lazy_set_last");
     return 0;
 }

@@ -22,17 +22,26 @@ import torch
 from . import _lib as L
 
 
-def step_scalar_table(lr, beta1, beta2, n=4096):
-    """[n,2] fp32: step_size_t = lr / (1 - beta1^t) and sqrt(1 - beta2^t), formed in double like torch/optim/adam.py."""
+def step_scalar_table(lr, beta1, beta2, n=4096, truncate=False):
+    """[n,2] fp32: step_size_t = lr / (1 - beta1^t) and sqrt(1 - beta2^t), formed in double like torch/optim/adam.py.
+    truncate: cut the table right after both columns have reached their fp32 limits (kernels clamp the index)."""
     rows = [(0.0, 1.0)]
     for t in range(1, n):
         rows.append((lr / (1.0 - beta1 ** t), math.sqrt(1.0 - beta2 ** t)))
-    return torch.tensor(rows, dtype=torch.float64).to(torch.float32)
+    tab = torch.tensor(rows, dtype=torch.float64).to(torch.float32)
+    if truncate:
+        same = (tab == tab[-1]).all(dim=1)
+        first = int(torch.nonzero(~same).max().item()) + 1 if bool((~same).any()) else 0
+        tab = tab[:first + 1].contiguous()
+    return tab
 
 
 class FusedAdam:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode="dense", frozen=()):
-        """frozen: parameters left untouched by the optimiser (like leaving them out of torch.optim.Adam's list)."""
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode="dense", frozen=(),
+                 fast_replay=True, flush_every=64):
+        """frozen: parameters left untouched by the optimiser (like leaving them out of torch.optim.Adam's list).
+        lazy mode: fast_replay = hardware rcp/sqrt in the replay of L2-only steps (False: the exact routine, bit-identical
+        to the dense mode); flush_every = period (steps) of the whole-table catch-up that bounds replay gaps (0 = never)."""
         assert table_mode in ("dense", "lazy")
         self.model = model
         self.frozen = {id(p) for p in frozen}
@@ -45,7 +54,11 @@ class FusedAdam:
             raise L.HipExtensionError("FusedAdam needs the model on a GPU; there is no CPU fallback")
         self.device = dev
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)       # 1-based step of the current update
-        self.scalars = step_scalar_table(lr, betas[0], betas[1]).to(dev).contiguous()
+        tab = step_scalar_table(lr, betas[0], betas[1], n=65536, truncate=True)
+        self.scalars = tab.to(dev).contiguous()
+        self.inv_bc2 = (1.0 / tab[:, 1].double()).to(torch.float32).to(dev).contiguous()
+        self.fast_replay = bool(fast_replay) and table_mode == "lazy"
+        self.flush_every = int(flush_every) if table_mode == "lazy" else 0
         self.reg_sum = torch.zeros(2, dtype=torch.float64, device=dev)       # [0] dense params (l2 applied), [1] table sum(w^2)
         f32 = lambda v: float(torch.tensor(v, dtype=torch.float64).to(torch.float32))  # noqa: E731
         self._lerp_w = f32(1.0 - betas[0])
@@ -80,6 +93,8 @@ class FusedAdam:
         hp.l2_twice = 2.0 * float(torch.tensor(self.l2_table, dtype=torch.float64).to(torch.float32))
         hp.step_scalars = self.scalars.data_ptr()
         hp.n_scalars = self.scalars.shape[0]
+        hp.fast_replay = 1 if self.fast_replay else 0
+        hp.inv_bc2 = self.inv_bc2.data_ptr()
         return hp
 
     def _stream(self):
@@ -118,6 +133,11 @@ class FusedAdam:
         """lazy mode, BEFORE the gather of this step: row indices -> dedupe -> replay the rows up to step t-1."""
         assert self.table_mode == "lazy"
         s = self._stream()
+        if self.flush_every > 1:
+            # every `flush_every` steps the whole table is brought to step t-1 (device-side decision: graph-replay safe)
+            L.launch("cdc_embed_lazy_flush(periodic)", self.lib.cdc_embed_lazy_flush,
+                     (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
+                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every, None, 0), s)
         L.launch("cdc_embed_index", self.lib.cdc_embed_index, (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), B, F), s)
         ws = self.sort_rows(idx, B, F, D)
         L.launch("cdc_embed_lazy_catchup", self.lib.cdc_embed_lazy_catchup,
@@ -158,7 +178,7 @@ class FusedAdam:
             return
         L.launch("cdc_embed_lazy_flush", self.lib.cdc_embed_lazy_flush,
                  (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-                  self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), 0, None, 0), self._stream(),
+                  self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), 0, 0, None, 0), self._stream(),
                  nbytes=24.0 * self.table.numel())
 
     # ------------------------------------------------------------------------------------------

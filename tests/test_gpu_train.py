@@ -76,6 +76,37 @@ def test_three_steps_match_reference_golden(cuda, kind, gold, table_mode):
     assert_close(w3, d["sd3/embedding.embedding_dict.weight"][7 + 301:7 + 400], 1e-6, 1e-7, "untouched rows after 3 steps")
 
 
+def _train_table(cuda, n_steps=12, **opt_kw):
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [50, 3000, 7, 900]
+    torch.manual_seed(11)
+    model = PLE(fd, 8, 3, 1, 1, ((16,), (8,)), (8,), dropout=0.0).to(cuda).set_precision("f32")
+    opt = FusedAdam(model, **opt_kw)
+    ts = TrainStep(model, opt, 128)
+    r = np.random.default_rng(5)
+    for _ in range(n_steps):
+        X = torch.from_numpy(make_ids(r, 128, fd)).to(cuda)
+        y = torch.from_numpy(r.integers(0, 2, size=128).astype(np.int16)).to(cuda)
+        g = torch.from_numpy(r.integers(0, 3, size=128).astype(np.int64)).to(cuda)
+        ts.step(X, y, g)
+    opt.flush_table()
+    return model.embedding.embedding_dict.weight.detach().cpu().clone(), opt.table_m.cpu().clone(), opt.table_v.cpu().clone()
+
+
+def test_lazy_fast_replay_and_periodic_flush_stay_on_the_exact_trajectory(cuda):
+    """Default lazy mode (hardware rcp/sqrt in the replay, whole-table catch-up every few steps) vs the exact dense mode
+    after 40 steps: the table differs by at most a few 1e-7 (fp32 ulp of O(1) weights = 1.2e-7), Adam moments alike."""
+    dense = _train_table(cuda, n_steps=40, table_mode="dense")
+    for kw in (dict(fast_replay=True, flush_every=0), dict(fast_replay=True, flush_every=8), dict(fast_replay=False, flush_every=8)):
+        lazy = _train_table(cuda, n_steps=40, table_mode="lazy", **kw)
+        dw = float((lazy[0] - dense[0]).abs().max())
+        assert dw <= (0.0 if not kw["fast_replay"] else 1e-6), f"{kw}: table differs from the exact trajectory by {dw:.2e}"
+        assert_close(lazy[1], dense[1], 1e-4, 1e-9, f"m {kw}")
+        assert_close(lazy[2], dense[2], 1e-4, 1e-12, f"v {kw}")
+
+
 def test_dense_and_lazy_table_modes_are_bit_identical(cuda):
     from cdcmdr_amd.optim import FusedAdam
     from cdcmdr_amd.trainer import TrainStep
@@ -86,7 +117,7 @@ def test_dense_and_lazy_table_modes_are_bit_identical(cuda):
         from cdcmdr_amd.model.ple import PLE
         torch.manual_seed(11)
         model = PLE(fd, 8, 3, 1, 1, ((16,), (8,)), (8,), dropout=0.0).to(cuda).set_precision("f32")
-        opt = FusedAdam(model, table_mode=mode)
+        opt = FusedAdam(model, table_mode=mode, fast_replay=False, flush_every=0)
         ts = TrainStep(model, opt, 128)
         r = np.random.default_rng(5)
         for _ in range(12):
