@@ -17,7 +17,7 @@ MAX_SEL = 16
 MAX_BN_SEGS = 24
 SORT_MAX_B = 16384
 BN_ROWS_PER_BLOCK = 64
-ROWDOT_PARTS = 64
+ROWDOT_PARTS = 256
 PREC_BF16 = 0
 PREC_F32 = 1
 
@@ -186,6 +186,7 @@ _SIGNATURES = {
     "cdc_sum_slices": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_adam_multi": (c_i32, [C.POINTER(AdamArgs), c_p]),
     "cdc_step_increment": (c_i32, [c_p, c_p]),
+    "cdc_begin_step": (c_i32, [c_p, c_p, c_i32, c_p]),
     "cdc_fill_f32": (c_i32, [c_p, c_f, c_i64, c_p]),
     "cdc_fill_f64": (c_i32, [c_p, C.c_double, c_i64, c_p]),
     "cdc_add_inplace": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_p]),

@@ -177,24 +177,49 @@ __global__ void __launch_bounds__(256) k_sorted_gather(const float* __restrict__
         sorted[i] = d_out[((int64_t)perm[pos] * F + f) * D + d];
     }
 }
+// one wave per unique row: lane = sub * D + d.  Short segments are summed by sub 0 alone in ascending batch order (the CPU
+// order of aten::embedding_dense_backward, so those rows equal torch's to the last bit); segments of >= SEG_SPLIT entries
+// are cut into 64/D contiguous parts summed by the sub-lanes in parallel and combined in part order.
+#define SEG_SPLIT 64
 __global__ void __launch_bounds__(256) k_segment_sum(const float* __restrict__ sorted, const int32_t* __restrict__ seg_start,
                                                      const int32_t* __restrict__ uniq_cnt, float* __restrict__ rowgrad,
-                                                     int32_t B, int32_t F, int32_t D) {
-    const int64_t total = (int64_t)F * B * D;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % D);
-        const int64_t slot = i / D;
-        const int f = (int)(slot / B);
-        const int j = (int)(slot - (int64_t)f * B);
-        if (j >= uniq_cnt[f]) continue;
-        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
-        const int k0 = sst[j], k1 = sst[j + 1];
-        const float* src = sorted + ((int64_t)f * B + k0) * D + d;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < k1 - k0; ++k) acc = __fadd_rn(acc, src[(int64_t)k * D]);
-        rowgrad[i] = acc;
+                                                     int32_t B, int32_t F, int32_t D, int32_t subs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (slot >= (int64_t)F * B) return;
+    const int f = (int)(slot / B);
+    const int j = (int)(slot - (int64_t)f * B);
+    if (j >= uniq_cnt[f]) return;
+    const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+    const int k0 = sst[j], len = sst[j + 1] - k0;
+    const float* base = sorted + ((int64_t)f * B + k0) * D;
+    if (subs <= 1) {                                               // general D: lanes stride over d, serial ascending sum
+        for (int d = lane; d < D; d += 64) {
+            float acc = 0.f;
+#pragma unroll 16
+            for (int k = 0; k < len; ++k) acc = __fadd_rn(acc, base[(int64_t)k * D + d]);
+            rowgrad[slot * D + d] = acc;
+        }
+        return;
     }
+    const int sub = lane / D, d = lane - sub * D;                   // D divides 64: subs = 64 / D lanes per element
+    const bool split = len >= SEG_SPLIT;
+    int begin = 0, end = (sub == 0) ? len : 0;
+    if (split) {
+        const int q = (len + subs - 1) / subs;
+        begin = min(sub * q, len);
+        end = min(begin + q, len);
+    }
+    float acc = 0.f;
+    const float* src = base + (int64_t)begin * D + d;
+#pragma unroll 16
+    for (int k = 0; k < end - begin; ++k) acc = __fadd_rn(acc, src[(int64_t)k * D]);
+    if (split) {
+        float total = __shfl(acc, d, 64);                          // part 0, then the others in order
+        for (int s2 = 1; s2 < subs; ++s2) total = __fadd_rn(total, __shfl(acc, s2 * D + d, 64));
+        acc = total;
+    }
+    if (sub == 0) rowgrad[slot * D + d] = acc;
 }
 
 extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_start, const int32_t* perm,
@@ -206,8 +231,10 @@ extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_star
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 32);
     hipLaunchKernelGGL(k_sorted_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, perm, sorted_scratch, (int32_t)B, F, D);
     CDC_LAUNCH_CHECK("embed_sorted_gather");
-    hipLaunchKernelGGL(k_segment_sum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sorted_scratch, seg_start, uniq_cnt, rowgrad,
-                       (int32_t)B, F, D);
+    const int subs = (D <= 64 && 64 % D == 0) ? 64 / D : 1;
+    const int64_t slots = (int64_t)F * B;
+    hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)cdc_ceil_div(slots, 4)), dim3(256), 0, (hipStream_t)stream, sorted_scratch, seg_start,
+                       uniq_cnt, rowgrad, (int32_t)B, F, D, subs);
     CDC_LAUNCH_CHECK("embed_segment_sum");
     return 0;
 }

@@ -22,6 +22,17 @@ extern "C" int cdc_step_increment(int32_t* step_dev, void* stream) {
     return 0;
 }
 
+__global__ void k_begin_step(int32_t* step, double* acc, int32_t n) {
+    if (threadIdx.x == 0) *step += 1;
+    if ((int)threadIdx.x < n) acc[threadIdx.x] = 0.0;
+}
+extern "C" int cdc_begin_step(int32_t* step_dev, double* accumulators, int32_t n_acc, void* stream) {
+    CDC_CHECK_ARG(step_dev && n_acc >= 0 && n_acc <= 64 && (n_acc == 0 || accumulators), CDC_E_BADARG, "begin_step: bad argument");
+    hipLaunchKernelGGL(k_begin_step, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, accumulators, n_acc);
+    CDC_LAUNCH_CHECK("begin_step");
+    return 0;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_fill(T* p, T value, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = value;

@@ -98,25 +98,30 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd(const cdc_pool_bw
         }
         if (lane < G.n_sel) G.d_logits[row * G.ld_dlogits + lane] = pj_lane * (dpj_lane - dot);
     }
-    // (2) expert gradients: d_expert_e = sum over gates that select e of p * d_out  (then the expert's relu/dropout mask)
-    for (int e = 0; e < a.n_expert; ++e) {
-        for (int h = lane; h < a.H; h += 64) {
-            float acc = 0.f;
-            for (int g = 0; g < a.n_gates; ++g) {
-                const auto& G = a.gate[g];
-                for (int j = 0; j < G.n_sel; ++j)
-                    if (G.sel[j] == e) acc += G.probs[row * G.n_sel + j] * G.d_out[row * G.ld_dout + h];
-            }
-            if (a.mask_relu) acc = ex[(int64_t)e * a.H + h] > 0.f ? acc * a.mask_scale : 0.f;
+    // (2) expert gradients: d_expert_e = sum over (gate, j) with sel == e of p * d_out, then the expert's relu/dropout mask.
+    // Accumulators live in LDS ([expert][lane] per wave) so that the data-dependent expert index costs one ds op, not a
+    // register select chain; each gate's d_out element is read once.
+    __shared__ float sacc[WAVES_PER_BLOCK][2 * CDC_MAX_SEL][64];
+    float (*acc)[64] = sacc[threadIdx.x >> 6];
+    for (int h = lane; h < a.H; h += 64) {
+        for (int e = 0; e < a.n_expert; ++e) acc[e][lane] = 0.f;
+        for (int g = 0; g < a.n_gates; ++g) {
+            const auto& G = a.gate[g];
+            const float d = G.d_out[row * G.ld_dout + h];
+            for (int j = 0; j < G.n_sel; ++j) acc[G.sel[j]][lane] += G.probs[row * G.n_sel + j] * d;
+        }
+        for (int e = 0; e < a.n_expert; ++e) {
+            float v = acc[e][lane];
+            if (a.mask_relu) v = ex[(int64_t)e * a.H + h] > 0.f ? v * a.mask_scale : 0.f;
             float* dst = dex + (int64_t)e * a.H + h;
-            *dst = a.accumulate ? *dst + acc : acc;
+            *dst = a.accumulate ? *dst + v : v;
         }
     }
 }
 
 extern "C" int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream) {
-    CDC_CHECK_ARG(a && a->n_gates > 0 && a->n_gates <= CDC_MAX_GATES && a->n_expert > 0 && a->H > 0 && a->B >= 0 && a->experts &&
-                      a->d_experts, CDC_E_BADARG, "gate_pool_bwd: bad argument");
+    CDC_CHECK_ARG(a && a->n_gates > 0 && a->n_gates <= CDC_MAX_GATES && a->n_expert > 0 && a->n_expert <= 2 * CDC_MAX_SEL && a->H > 0 &&
+                      a->B >= 0 && a->experts && a->d_experts, CDC_E_BADARG, "gate_pool_bwd: bad argument (n_expert <= 32)");
     for (int g = 0; g < a->n_gates; ++g)
         CDC_CHECK_ARG(a->gate[g].d_out && a->gate[g].probs && a->gate[g].d_logits && a->gate[g].n_sel > 0 &&
                           a->gate[g].n_sel <= CDC_MAX_SEL, CDC_E_BADARG, "gate_pool_bwd: gate %d malformed", g);

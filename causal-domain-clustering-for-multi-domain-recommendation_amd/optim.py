@@ -119,8 +119,7 @@ class FusedAdam:
     def begin_step(self):
         """++step and clear the regularisation accumulators (call before the forward of the step)."""
         s = self._stream()
-        L.launch("cdc_step_increment", self.lib.cdc_step_increment, (self.step_dev.data_ptr(),), s)
-        L.launch("cdc_fill_f64", self.lib.cdc_fill_f64, (self.reg_sum.data_ptr(), 0.0, 2), s)
+        L.launch("cdc_begin_step", self.lib.cdc_begin_step, (self.step_dev.data_ptr(), self.reg_sum.data_ptr(), 2), s)
 
     def sort_rows(self, idx, B, F, D):
         ws = self._workspace(B, F, D)

@@ -352,7 +352,7 @@ typedef struct {
     float* workspace;                     /* >= n_groups * CDC_ROWDOT_PARTS * (Kmax+1) floats */
     cdc_rowdot_bgroup g[CDC_MAX_GROUPS];
 } cdc_rowdot_bwd_args;
-#define CDC_ROWDOT_PARTS 64
+#define CDC_ROWDOT_PARTS 256
 int cdc_rowdot_bwd(const cdc_rowdot_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -448,6 +448,7 @@ int cdc_sum_slices(const float* in, int64_t ld_in, float* out, int64_t ld_out, i
 
 /* small utilities used by the step driver */
 int cdc_step_increment(int32_t* step_dev, void* stream);                 /* ++*step_dev */
+int cdc_begin_step(int32_t* step_dev, double* accumulators, int32_t n_acc, void* stream);   /* ++*step_dev and zero n_acc doubles */
 int cdc_fill_f32(float* p, float value, int64_t n, void* stream);
 int cdc_fill_f64(double* p, double value, int64_t n, void* stream);
 /* dst[r*ld_dst + c] += src[r*ld_src + c]  (gradient fan-in where a kernel cannot accumulate itself) */

@@ -49,21 +49,27 @@ def test_gather_golden_g1(cuda):
     assert np.array_equal(holder.emb_op.idx.cpu().numpy(), d["idx"])   # int32 index selection, bit-exact
 
 
-def test_gather_dense_grad_matches_embedding_backward(cuda):
+@pytest.mark.parametrize("fd,B,exact", [([50, 30, 400, 20], 200, True), ([5, 3, 40, 2], 300, False)])
+def test_gather_dense_grad_matches_embedding_backward(cuda, fd, B, exact):
+    """Rows with fewer than 64 duplicates in the batch are summed in ascending batch order — the order of
+    aten::embedding_dense_backward on the CPU — and equal torch's gradient to the last bit; hotter rows (a domain column)
+    are summed in 64/D parallel parts and agree to fp32 rounding."""
     from cdcmdr_amd.model.layer import FeaturesEmbedding
-    fd = [5, 3, 40, 2]                       # small vocab: many duplicate ids inside the batch
     torch.manual_seed(0)
     emb = FeaturesEmbedding(fd, 4).to(cuda)
     rng = np.random.default_rng(0)
-    B = 300
     x = np.stack([rng.integers(0, d, size=B) for d in fd], axis=1).astype(np.int32)
+    if exact:
+        assert max(np.bincount(x[:, f]).max() for f in range(len(fd))) < 64
     out = emb(torch.from_numpy(x).to(cuda), squeeze_dim=True)
     g = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
     out.backward(g.to(cuda))
     table = emb.embedding_dict.weight.detach().cpu().clone().requires_grad_(True)
     O.embed(table, x, fd).backward(g)
-    # same ascending-batch summation order as aten::embedding_dense_backward on the CPU -> equal to the last bit
-    assert torch.equal(emb.embedding_dict.weight.grad.cpu(), table.grad)
+    if exact:
+        assert torch.equal(emb.embedding_dict.weight.grad.cpu(), table.grad)
+    else:
+        assert_close(emb.embedding_dict.weight.grad, table.grad, 1e-5, 1e-5, "dense table gradient, hot rows")
 
 
 def test_gather_out_of_range_sets_flag(cuda):
