@@ -16,6 +16,7 @@ MAX_GATES = 16
 MAX_SEL = 16
 MAX_BN_SEGS = 24
 SORT_MAX_B = 16384
+SORT_MAX_ROWS = 32768
 BN_ROWS_PER_BLOCK = 64
 ROWDOT_PARTS = 256
 PREC_BF16 = 0
@@ -153,7 +154,7 @@ _SIGNATURES = {
     "cdc_last_error": (C.c_char_p, []),
     "cdc_embed_gather_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
     "cdc_embed_index": (c_i32, [c_p, c_p, c_p, c_i64, c_i32, c_p]),
-    "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_segment_sum": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
     "cdc_embed_adam_touched": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32, c_p]),

@@ -75,22 +75,10 @@ extern "C" int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32
 // per-field sort + dedupe: one workgroup per field, bitonic sort of (row<<32 | b) in LDS
 // ------------------------------------------------------------------------------------------------
 #define SORT_THREADS 1024
-__global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __restrict__ idx, int32_t* __restrict__ uniq_row,
-                                                              int32_t* __restrict__ seg_start, int32_t* __restrict__ perm,
-                                                              int32_t* __restrict__ uniq_cnt, int32_t B, int32_t F,
-                                                              int32_t n_pad) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);              // n_pad entries
-    int32_t* scan = reinterpret_cast<int32_t*>(keys + n_pad);            // SORT_THREADS entries
-    const int f = blockIdx.x;
-    const int tid = threadIdx.x;
+#define SORT_CHUNK CDC_SORT_MAX_B        /* keys one workgroup sorts in LDS (16384 x 8 B = 128 KB) */
 
-    for (int i = tid; i < n_pad; i += SORT_THREADS) {
-        uint64_t k = ~0ull;                                               // padding sorts last
-        if (i < B) k = ((uint64_t)(uint32_t)idx[(int64_t)i * F + f] << 32) | (uint32_t)i;
-        keys[i] = k;
-    }
-    __syncthreads();
+// bitonic sort of n_pad 64-bit keys in LDS (n_pad a power of two >= SORT_THREADS)
+__device__ __forceinline__ void lds_bitonic_sort(uint64_t* keys, int n_pad, int tid) {
     for (int k = 2; k <= n_pad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = tid; t < (n_pad >> 1); t += SORT_THREADS) {
@@ -103,11 +91,16 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __r
             __syncthreads();
         }
     }
-    // head flags + block-wide exclusive scan; each thread owns a contiguous chunk
-    const int per = n_pad / SORT_THREADS > 0 ? n_pad / SORT_THREADS : 1;
+}
+
+// head flags + block-wide exclusive scan over n sorted keys (LDS or global): unique rows, segment starts, permutation
+__device__ __forceinline__ void dedupe_sorted(const uint64_t* keys, int n, int32_t* scan, int32_t* __restrict__ urow,
+                                              int32_t* __restrict__ sst, int32_t* __restrict__ prm, int32_t* __restrict__ cnt_out,
+                                              int tid) {
+    const int per = (n + SORT_THREADS - 1) / SORT_THREADS;
     const int begin = tid * per;
     int local = 0;
-    for (int i = begin; i < begin + per && i < B; ++i) {
+    for (int i = begin; i < begin + per && i < n; ++i) {
         const bool head = (i == 0) || ((keys[i] >> 32) != (keys[i - 1] >> 32));
         local += head ? 1 : 0;
     }
@@ -121,10 +114,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __r
     }
     int u = scan[tid] - local;                                           // exclusive prefix
     const int total = scan[SORT_THREADS - 1];
-    int32_t* urow = uniq_row + (int64_t)f * B;
-    int32_t* sst = seg_start + (int64_t)f * (B + 1);
-    int32_t* prm = perm + (int64_t)f * B;
-    for (int i = begin; i < begin + per && i < B; ++i) {
+    for (int i = begin; i < begin + per && i < n; ++i) {
         const uint64_t k = keys[i];
         const bool head = (i == 0) || ((k >> 32) != (keys[i - 1] >> 32));
         if (head) {
@@ -135,28 +125,111 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __r
         prm[i] = (int32_t)(uint32_t)k;
     }
     if (tid == 0) {
-        sst[total] = B;
-        uniq_cnt[f] = total;
+        sst[total] = n;
+        *cnt_out = total;
     }
 }
 
+// B <= SORT_CHUNK: sort + dedupe in one workgroup per field
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __restrict__ idx, int32_t* __restrict__ uniq_row,
+                                                              int32_t* __restrict__ seg_start, int32_t* __restrict__ perm,
+                                                              int32_t* __restrict__ uniq_cnt, int32_t B, int32_t F,
+                                                              int32_t n_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);              // n_pad entries
+    int32_t* scan = reinterpret_cast<int32_t*>(keys + n_pad);            // SORT_THREADS entries
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_pad; i += SORT_THREADS) {
+        uint64_t k = ~0ull;                                               // padding sorts last
+        if (i < B) k = ((uint64_t)(uint32_t)idx[(int64_t)i * F + f] << 32) | (uint32_t)i;
+        keys[i] = k;
+    }
+    __syncthreads();
+    lds_bitonic_sort(keys, n_pad, tid);
+    dedupe_sorted(keys, B, scan, uniq_row + (int64_t)f * B, seg_start + (int64_t)f * (B + 1), perm + (int64_t)f * B, uniq_cnt + f, tid);
+}
+
+// B > SORT_CHUNK (the gathered batch of an 8-GPU step): (1) each chunk of SORT_CHUNK rows is sorted in LDS and written out,
+// (2) the two sorted runs are merged by rank (keys are unique: the batch row is part of the key), (3) dedupe from global.
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_chunk(const int32_t* __restrict__ idx, uint64_t* __restrict__ runs, int32_t B,
+                                                             int32_t F) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
+    const int f = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
+    const int r0 = c * SORT_CHUNK;
+    const int n = min(SORT_CHUNK, B - r0);
+    for (int i = tid; i < SORT_CHUNK; i += SORT_THREADS) {
+        uint64_t k = ~0ull;
+        if (i < n) k = ((uint64_t)(uint32_t)idx[(int64_t)(r0 + i) * F + f] << 32) | (uint32_t)(r0 + i);
+        keys[i] = k;
+    }
+    __syncthreads();
+    lds_bitonic_sort(keys, SORT_CHUNK, tid);
+    uint64_t* out = runs + (int64_t)f * B + r0;
+    for (int i = tid; i < n; i += SORT_THREADS) out[i] = keys[i];
+}
+__global__ void __launch_bounds__(256) k_merge_runs(const uint64_t* __restrict__ runs, uint64_t* __restrict__ merged, int32_t B,
+                                                    int32_t F) {
+    const int64_t total = (int64_t)F * B;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(t / B);
+        const int i = (int)(t - (int64_t)f * B);
+        const uint64_t* a = runs + (int64_t)f * B;             // run 0: [0, n0), run 1: [n0, B)
+        const int n0 = SORT_CHUNK, n1 = B - SORT_CHUNK;
+        const uint64_t* other;
+        int n_other, mine;
+        uint64_t key;
+        if (i < n0) { key = a[i]; other = a + n0; n_other = n1; mine = i; }
+        else        { key = a[i]; other = a; n_other = n0; mine = i - n0; }
+        int lo = 0, hi = n_other;                              // number of keys of the other run that are smaller
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (other[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        merged[(int64_t)f * B + mine + lo] = key;
+    }
+}
+__global__ void __launch_bounds__(SORT_THREADS) k_dedupe_merged(const uint64_t* __restrict__ merged, int32_t* __restrict__ uniq_row,
+                                                                int32_t* __restrict__ seg_start, int32_t* __restrict__ perm,
+                                                                int32_t* __restrict__ uniq_cnt, int32_t B, int32_t F) {
+    __shared__ int32_t scan[SORT_THREADS];
+    const int f = blockIdx.x;
+    dedupe_sorted(merged + (int64_t)f * B, B, scan, uniq_row + (int64_t)f * B, seg_start + (int64_t)f * (B + 1), perm + (int64_t)f * B,
+                  uniq_cnt + f, threadIdx.x);
+}
+
 extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
-                                     int32_t* uniq_cnt, int64_t B, int32_t F, void* stream) {
+                                     int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream) {
     CDC_CHECK_ARG(idx && uniq_row && seg_start && perm && uniq_cnt, CDC_E_BADARG, "embed_sort_dedupe: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0, CDC_E_BADARG, "embed_sort_dedupe: bad sizes");
-    CDC_CHECK_ARG(B <= CDC_SORT_MAX_B, CDC_E_TOOBIG, "embed_sort_dedupe: B=%ld exceeds %d", (long)B, CDC_SORT_MAX_B);
-    int n_pad = SORT_THREADS;   // at least one key per thread keeps the chunking simple
-    while (n_pad < B) n_pad <<= 1;
-    const size_t lds = (size_t)n_pad * 8 + SORT_THREADS * 4;
+    CDC_CHECK_ARG(B <= CDC_SORT_MAX_ROWS, CDC_E_TOOBIG, "embed_sort_dedupe: B=%ld exceeds %d", (long)B, CDC_SORT_MAX_ROWS);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_sort_dedupe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sort_chunk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { cdc_set_error("embed_sort_dedupe: cannot raise LDS limit: %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_sort_dedupe, dim3(F), dim3(SORT_THREADS), lds, (hipStream_t)stream, idx, uniq_row, seg_start, perm,
-                       uniq_cnt, (int32_t)B, F, n_pad);
-    CDC_LAUNCH_CHECK("embed_sort_dedupe");
+    hipStream_t st = (hipStream_t)stream;
+    if (B <= SORT_CHUNK) {
+        int n_pad = SORT_THREADS;   // at least one key per thread keeps the chunking simple
+        while (n_pad < B) n_pad <<= 1;
+        const size_t lds = (size_t)n_pad * 8 + SORT_THREADS * 4;
+        hipLaunchKernelGGL(k_sort_dedupe, dim3(F), dim3(SORT_THREADS), lds, st, idx, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F, n_pad);
+        CDC_LAUNCH_CHECK("embed_sort_dedupe");
+        return 0;
+    }
+    CDC_CHECK_ARG(scratch, CDC_E_BADARG, "embed_sort_dedupe: B > %d needs a scratch buffer of 2*F*B uint64", SORT_CHUNK);
+    uint64_t* runs = scratch;
+    uint64_t* merged = scratch + (int64_t)F * B;
+    hipLaunchKernelGGL(k_sort_chunk, dim3(F, 2), dim3(SORT_THREADS), (size_t)SORT_CHUNK * 8, st, idx, runs, (int32_t)B, F);
+    CDC_LAUNCH_CHECK("embed_sort_chunk");
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 8192);
+    hipLaunchKernelGGL(k_merge_runs, dim3(blocks), dim3(256), 0, st, runs, merged, (int32_t)B, F);
+    CDC_LAUNCH_CHECK("embed_merge_runs");
+    hipLaunchKernelGGL(k_dedupe_merged, dim3(F), dim3(SORT_THREADS), 0, st, merged, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F);
+    CDC_LAUNCH_CHECK("embed_dedupe_merged");
     return 0;
 }
 
@@ -226,7 +299,7 @@ extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_star
                                      const int32_t* uniq_cnt, float* sorted_scratch, float* rowgrad, int64_t B, int32_t F,
                                      int32_t D, void* stream) {
     CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && sorted_scratch && rowgrad, CDC_E_BADARG, "embed_segment_sum: null pointer");
-    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_B, CDC_E_BADARG, "embed_segment_sum: bad sizes");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_segment_sum: bad sizes");
     const int64_t total = (int64_t)F * B * D;
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 32);
     hipLaunchKernelGGL(k_sorted_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, perm, sorted_scratch, (int32_t)B, F, D);
@@ -261,7 +334,7 @@ __global__ void __launch_bounds__(256) k_grad_dense(const float* __restrict__ ro
 extern "C" int cdc_embed_grad_dense(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt, float* grad,
                                     int64_t B, int32_t F, int32_t D, int64_t R, void* stream) {
     CDC_CHECK_ARG(rowgrad && uniq_row && uniq_cnt && grad, CDC_E_BADARG, "embed_grad_dense: null pointer");
-    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_B, CDC_E_BADARG, "embed_grad_dense: bad sizes");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_grad_dense: bad sizes");
     const int64_t total = (int64_t)F * B * D;
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
     hipLaunchKernelGGL(k_grad_dense, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, grad,
@@ -301,7 +374,7 @@ extern "C" int cdc_embed_adam_touched(const float* rowgrad, const int32_t* uniq_
                                       int64_t B, int32_t F, int32_t D, void* stream) {
     CDC_CHECK_ARG(rowgrad && uniq_row && uniq_cnt && w && m && v && side && step_dev && hp.step_scalars, CDC_E_BADARG,
                   "embed_adam_touched: null pointer");
-    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_B && hp.n_scalars > 0, CDC_E_BADARG, "embed_adam_touched: bad sizes");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS && hp.n_scalars > 0, CDC_E_BADARG, "embed_adam_touched: bad sizes");
     const int64_t total = (int64_t)F * B * D;
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
     hipLaunchKernelGGL(k_adam_touched, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, w, m, v, side,

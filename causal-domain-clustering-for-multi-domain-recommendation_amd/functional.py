@@ -38,8 +38,8 @@ def table_dense_grad(plan, emb_op, table):
     a dense [R, D] gradient, rows summed in ascending batch order."""
     lib = plan.lib
     B, F, D = plan.B, emb_op.F, emb_op.D
-    if B > L.SORT_MAX_B:
-        raise RuntimeError(f"batch {B} exceeds the per-field sort limit {L.SORT_MAX_B}")
+    if B > L.SORT_MAX_ROWS:
+        raise RuntimeError(f"batch {B} exceeds the per-field sort limit {L.SORT_MAX_ROWS}")
     dev = plan.device
     uniq = torch.empty((F, B), dtype=torch.int32, device=dev)
     seg = torch.empty((F, B + 1), dtype=torch.int32, device=dev)
@@ -47,8 +47,9 @@ def table_dense_grad(plan, emb_op, table):
     cnt = torch.empty((F,), dtype=torch.int32, device=dev)
     grad = torch.zeros_like(table)
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scratch = torch.empty((2 * F * B,), dtype=torch.int64, device=dev) if B > L.SORT_MAX_B else None
     L.check(lib.cdc_embed_sort_dedupe(emb_op.idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
-                                      B, F, s), "embed_sort_dedupe")
+                                      None if scratch is None else scratch.data_ptr(), B, F, s), "embed_sort_dedupe")
     g = emb_op.out.grad
     assert g.ld == F * D
     scratch = torch.empty((F * B * D,), dtype=torch.float32, device=dev)

@@ -109,6 +109,7 @@ class FusedAdam:
                   "seg": torch.empty((F, B + 1), dtype=torch.int32, device=dev),
                   "perm": torch.empty((F, B), dtype=torch.int32, device=dev),
                   "cnt": torch.zeros((F,), dtype=torch.int32, device=dev),
+                  "scratch": torch.empty((2 * F * B,), dtype=torch.int64, device=dev) if B > L.SORT_MAX_B else None,
                   "sorted": torch.empty((F * B * D,), dtype=torch.float32, device=dev),
                   "rowgrad": torch.empty((F * B * D,), dtype=torch.float32, device=dev),
                   "side": torch.empty((F * B * 3 * D,), dtype=torch.float32, device=dev) if self.table_mode == "dense" else None}
@@ -124,8 +125,8 @@ class FusedAdam:
     def sort_rows(self, idx, B, F, D):
         ws = self._workspace(B, F, D)
         L.launch("cdc_embed_sort_dedupe", self.lib.cdc_embed_sort_dedupe,
-                 (idx.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), B, F),
-                 self._stream())
+                 (idx.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(),
+                  None if ws["scratch"] is None else ws["scratch"].data_ptr(), B, F), self._stream())
         return ws
 
     def table_catchup(self, ids, offsets, idx, B, F, D):

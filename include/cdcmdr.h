@@ -61,17 +61,19 @@ int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, const float
 /* model/layer.py:152 alone: idx_out[b,f] = ids[b,f] + offsets[f] (int32, wrapping). */
 int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out, int64_t B, int32_t F, void* stream);
 
-/* Per-field sort + dedupe of the row indices of one batch (rows of different fields never
- * collide, so each field is sorted on its own in LDS).  B <= CDC_SORT_MAX_B.
- *   idx       [B,F] int32 row indices (from cdc_embed_gather_fwd)
+/* Per-field sort + dedupe of the row indices of one batch (rows of different fields never collide, so each field is
+ * sorted on its own).  B <= CDC_SORT_MAX_B: one workgroup per field sorts (row<<32|b) in LDS.  B <= CDC_SORT_MAX_ROWS
+ * (the gathered batch of an 8-GPU step): two LDS-sorted runs per field, merged by rank; needs `scratch` >= 2*F*B uint64.
+ *   idx       [B,F] int32 row indices (from cdc_embed_gather_fwd / cdc_embed_index)
  *   uniq_row  [F,B] int32 — field f's unique rows, ascending, first uniq_cnt[f] entries valid
  *   seg_start [F,B+1] int32 — uniq j of field f owns sorted positions [seg_start[f][j], seg_start[f][j+1])
  *   perm      [F,B] int32 — batch row b of each sorted position (ascending b inside a segment)
  *   uniq_cnt  [F]   int32
  */
 #define CDC_SORT_MAX_B 16384
+#define CDC_SORT_MAX_ROWS 32768
 int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
-                          int32_t* uniq_cnt, int64_t B, int32_t F, void* stream);
+                          int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream);
 
 /* Per-row gradient of the batch: rowgrad[f, j, :] = sum over unique row j's segment of d_out[b, f*D:(f+1)*D],
  * summed in ascending b (the order aten::embedding_dense_backward uses on the CPU, model/layer.py:140,153).

@@ -76,7 +76,7 @@ def test_limits_match_the_header():
     from cdcmdr_amd import _lib
     src = open(HEADER).read()
     for macro, val in [("CDC_MAX_GROUPS", _lib.MAX_GROUPS), ("CDC_MAX_TENSORS", _lib.MAX_TENSORS), ("CDC_MAX_GATES", _lib.MAX_GATES),
-                       ("CDC_MAX_SEL", _lib.MAX_SEL), ("CDC_MAX_BN_SEGS", _lib.MAX_BN_SEGS), ("CDC_SORT_MAX_B", _lib.SORT_MAX_B),
+                       ("CDC_MAX_SEL", _lib.MAX_SEL), ("CDC_MAX_BN_SEGS", _lib.MAX_BN_SEGS), ("CDC_SORT_MAX_B", _lib.SORT_MAX_B), ("CDC_SORT_MAX_ROWS", _lib.SORT_MAX_ROWS),
                        ("CDC_BN_ROWS_PER_BLOCK", _lib.BN_ROWS_PER_BLOCK), ("CDC_ROWDOT_PARTS", _lib.ROWDOT_PARTS)]:
         m = re.search(rf"#define\s+{macro}\s+(\d+)", src)
         assert m and int(m.group(1)) == val, macro

@@ -297,3 +297,33 @@ def test_bce_golden_g7(cuda):
     L.check(lib.cdc_bce_fwd_bwd(p.data_ptr(), 1, None, None, y.data_ptr(), loss.data_ptr(), dp.data_ptr(), 1, n, 1, 1.0 / n, s), "bce")
     assert_close(loss, d["loss"].reshape(1), 1e-6, 1e-6, "bce loss incl. the -100 clamp")
     assert_close(dp.reshape(-1), d["dp"], 1e-5, 0.0, "bce gradient incl. the 1e-12 clamp")
+
+
+@pytest.mark.parametrize("B", [1, 100, 4096, 16384, 16385, 20000, 32768])
+def test_sort_dedupe_against_numpy(cuda, B):
+    """Per-field sort + dedupe (single-workgroup LDS path up to 16384 rows, two merged runs beyond: the gathered batch
+    of an 8-GPU step) — integer work, bit-exact against numpy's stable sort."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    F = 5
+    rng = np.random.default_rng(B)
+    vocab = [3, 50, 1000, 100000, 7]
+    idx = np.stack([rng.integers(0, v, size=B) + 1000 * f for f, v in enumerate(vocab)], axis=1).astype(np.int32)
+    d_idx = torch.from_numpy(idx).to(cuda)
+    uniq = torch.full((F, B), -1, dtype=torch.int32, device=cuda)
+    seg = torch.full((F, B + 1), -1, dtype=torch.int32, device=cuda)
+    perm = torch.full((F, B), -1, dtype=torch.int32, device=cuda)
+    cnt = torch.zeros(F, dtype=torch.int32, device=cuda)
+    scratch = torch.empty(2 * F * B, dtype=torch.int64, device=cuda) if B > L.SORT_MAX_B else None
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.cdc_embed_sort_dedupe(d_idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
+                                      None if scratch is None else scratch.data_ptr(), B, F, s), "sort")
+    uniq, seg, perm, cnt = uniq.cpu().numpy(), seg.cpu().numpy(), perm.cpu().numpy(), cnt.cpu().numpy()
+    for f in range(F):
+        order = np.argsort(idx[:, f], kind="stable")                     # ascending row, ascending batch position inside
+        assert np.array_equal(perm[f], order)
+        rows, starts = np.unique(idx[order, f], return_index=True)
+        n = len(rows)
+        assert cnt[f] == n and np.array_equal(uniq[f, :n], rows)
+        assert np.array_equal(seg[f, :n], starts) and seg[f, n] == B
