@@ -119,9 +119,7 @@ def main():
 
     model, field_dims = build_model(args, device)
     table_mode = args.table_mode
-    use_graph = bool(args.graph) and world == 1
-    if world > 1 and table_mode == "lazy":
-        table_mode = "dense"                                   # lazy replay under DP is a next-round item
+    use_graph = bool(args.graph)        # under DP the three launch stages between the collectives are graphs
     opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode)
     ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dp)
 

@@ -31,20 +31,42 @@ class DataParallel:
                 dist.init_process_group(backend)
         self.device = device
 
+    def _staged(self, t):
+        """gloo moves host memory: device tensors are staged through the CPU (rehearsal / tests only; RCCL is direct)."""
+        return self.backend == "gloo" and t.is_cuda
+
     def all_reduce_sum(self, t):
         if self.world_size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if self._staged(t):
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
     def all_reduce_max(self, t):
         if self.world_size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if self._staged(t):
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t
 
     def all_gather_rows(self, out, local):
         """out [world*B, C] <- concat over ranks of local [B, C] (rank order)."""
         if self.world_size > 1:
-            dist.all_gather_into_tensor(out, local.contiguous())
+            if self._staged(out):
+                parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(self.world_size)]
+                dist.all_gather(parts, local.detach().cpu().contiguous())
+                out.copy_(torch.cat(parts, dim=0))
+            elif self.backend == "gloo":
+                parts = list(out.chunk(self.world_size, dim=0))
+                dist.all_gather(parts, local.contiguous())
+            else:
+                dist.all_gather_into_tensor(out, local.contiguous())
         else:
             out.copy_(local)
         return out

@@ -129,6 +129,23 @@ class FusedAdam:
                   None if ws["scratch"] is None else ws["scratch"].data_ptr(), B, F), self._stream())
         return ws
 
+    def table_index(self, ids, offsets, idx, B, F):
+        """row indices of the local batch (needed before the gather in lazy mode, and for the all-gather under DP)."""
+        L.launch("cdc_embed_index", self.lib.cdc_embed_index, (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), B, F), self._stream())
+
+    def table_catchup_rows(self, idx, B, F, D):
+        """lazy mode, BEFORE the gather of this step, on already computed row indices [B,F] (the gathered batch under DP)."""
+        assert self.table_mode == "lazy"
+        s = self._stream()
+        if self.flush_every > 1:
+            L.launch("cdc_embed_lazy_flush(periodic)", self.lib.cdc_embed_lazy_flush,
+                     (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
+                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every, None, 0), s)
+        ws = self.sort_rows(idx, B, F, D)
+        L.launch("cdc_embed_lazy_catchup", self.lib.cdc_embed_lazy_catchup,
+                 (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(), self.table_m.data_ptr(),
+                  self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D), s)
+
     def table_catchup(self, ids, offsets, idx, B, F, D):
         """lazy mode, BEFORE the gather of this step: row indices -> dedupe -> replay the rows up to step t-1."""
         assert self.table_mode == "lazy"

@@ -41,6 +41,7 @@ class TrainStep:
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.use_graph = use_graph
         self.graph = None
+        self._stage_graphs = {}
         self._warm = 0
         if self.world > 1:
             F, D = self.emb.F, self.emb.D
@@ -65,34 +66,69 @@ class TrainStep:
         return model._cache().get(model, ("train_step", id(opt)), B, build)
 
     # ------------------------------------------------------------------------------------------
-    def _launch_all(self):
-        opt, plan, emb = self.opt, self.plan, self.emb
-        B, F, D = self.B, emb.F, emb.D
-        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        opt.begin_step()
-        if opt.table_mode == "lazy":
-            if self.world > 1:
-                raise NotImplementedError("lazy table mode under data parallelism")
-            opt.table_catchup(emb.ids, emb.offsets, emb.idx, B, F, D)
-        plan.forward()
+    def _bce(self):
         og = self.out.grad
-        n_col = self.out.cols
         L.launch("cdc_bce_fwd_bwd", self.lib.cdc_bce_fwd_bwd,
                  (self.out.ptr, self.out.ld, None if self.group is None else self.group.data_ptr(), self.y.data_ptr(), None,
-                  self.loss.data_ptr(), og.ptr, og.ld, B, n_col, 1.0 / self.global_B), s)
+                  self.loss.data_ptr(), og.ptr, og.ld, self.B, self.out.cols, 1.0 / self.global_B),
+                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    def _launch_all(self):
+        """single GPU: the whole step is one launch sequence (one hipGraph when use_graph)."""
+        opt, plan, emb = self.opt, self.plan, self.emb
+        B, F, D = self.B, emb.F, emb.D
+        opt.begin_step()
+        if opt.table_mode == "lazy":
+            opt.table_catchup(emb.ids, emb.offsets, emb.idx, B, F, D)
+        plan.forward()
+        self._bce()
         plan.backward()
-        dE = emb.out.grad
-        if self.world > 1:
-            # dense gradients: one SUM all-reduce of the flat arena (the loss already carries 1/global_batch);
-            # table: every rank applies the identical update from the all-gathered (row index, row gradient) pairs
-            self.dist.all_reduce_sum(opt.grad_arena[:max(plan._arena_used, 1)])
-            self.dist.all_gather_rows(self.idx_all, emb.idx)
-            self.dist.all_gather_rows(self.dE_all, dE.root)
-            self.dist.all_reduce_sum(self.loss)
-            opt.table_step(self.idx_all, self.dE_all, self.global_B, F, D)
-        else:
-            opt.table_step(emb.idx, dE.root, B, F, D)
+        opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
         opt.dense_step(plan.param_grads, plan._param_refs)
+
+    # ---- data parallel: three launch stages separated by the collectives (each stage replayable as a graph) -------------
+    def _stage0(self):
+        opt, emb = self.opt, self.emb
+        opt.begin_step()
+        opt.table_index(emb.ids, emb.offsets, emb.idx, self.B, emb.F)
+
+    def _stage1(self):
+        opt, plan, emb = self.opt, self.plan, self.emb
+        if opt.table_mode == "lazy":
+            opt.table_catchup_rows(self.idx_all, self.global_B, emb.F, emb.D)
+        plan.forward()
+        self._bce()
+        plan.backward()
+
+    def _stage2(self):
+        opt, plan, emb = self.opt, self.plan, self.emb
+        opt.table_step(self.idx_all, self.dE_all, self.global_B, emb.F, emb.D)
+        opt.dense_step(plan.param_grads, plan._param_refs)
+
+    def _run_stage(self, i, fn):
+        if self.use_graph and self._warm >= 2:
+            g = self._stage_graphs.get(i)
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+                self._stage_graphs[i] = g
+            g.replay()
+        else:
+            fn()
+
+    def _step_dp(self):
+        """dense gradients: ONE sum all-reduce of the flat arena (the loss already carries 1/global_batch); table: every rank
+        applies the identical update from the all-gathered (row index, row gradient) pairs of the global batch."""
+        opt, emb, dp = self.opt, self.emb, self.dist
+        self._run_stage(0, self._stage0)
+        dp.all_gather_rows(self.idx_all, emb.idx)
+        self._run_stage(1, self._stage1)
+        dp.all_reduce_sum(opt.grad_arena[:max(self.plan._arena_used, 1)])
+        dp.all_gather_rows(self.dE_all, emb.out.grad.root)
+        dp.all_reduce_sum(self.loss)
+        self._run_stage(2, self._stage2)
+        self._warm += 1
 
     def step(self, X, y, group=None):
         """One training step. X int32 [B,F]; y int16/float [B] or [B,1]; group int64 [B] or [B,1] (multi mode).
@@ -101,7 +137,9 @@ class TrainStep:
         self.y.copy_(y.reshape(-1))
         if self.group is not None:
             self.group.copy_(group.reshape(-1))
-        if self.use_graph and self._warm >= 2:
+        if self.world > 1:
+            self._step_dp()
+        elif self.use_graph and self._warm >= 2:
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
