@@ -98,7 +98,8 @@ class BnSeg(C.Structure):
 class BnFwdArgs(C.Structure):
     _fields_ = [("n_seg", c_i32), ("training", c_i32), ("relu", c_i32), ("skip_le1", c_i32), ("eps", c_f), ("momentum", c_f),
                 ("drop_p", c_f), ("seed", C.c_uint64), ("seed_offset_dev", c_p), ("M", c_i64),
-                ("row_offsets", c_p), ("workspace", c_p), ("s", BnSeg * MAX_BN_SEGS)]
+                ("row_offsets", c_p), ("workspace", c_p), ("phase", c_i32), ("pad_", c_i32), ("exchange", c_p),
+                ("s", BnSeg * MAX_BN_SEGS)]
 
 
 class BnBSeg(C.Structure):
@@ -109,7 +110,8 @@ class BnBSeg(C.Structure):
 
 class BnBwdArgs(C.Structure):
     _fields_ = [("n_seg", c_i32), ("training", c_i32), ("relu", c_i32), ("eps", c_f), ("mask_scale", c_f),
-                ("M", c_i64), ("row_offsets", c_p), ("workspace", c_p), ("s", BnBSeg * MAX_BN_SEGS)]
+                ("M", c_i64), ("row_offsets", c_p), ("workspace", c_p), ("phase", c_i32), ("pad_", c_i32), ("exchange", c_p),
+                ("s", BnBSeg * MAX_BN_SEGS)]
 
 
 class RowdotGroup(C.Structure):

@@ -189,27 +189,35 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
     const cdc_bn_seg& S = a.s[t.seg];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = t.c0 + lane;
+    // rows the statistics are over: this launch's rows, or (phase 2, data parallel) the all-reduced global count
+    const bool global_stats = a.training && a.phase == 2 && a.exchange;
+    const int Ms = global_stats ? (int)(a.exchange[2 * (int64_t)total_c + t.seg] + 0.5) : t.M;
     // the reference skips BN when the (group's) batch has one row (MLP / MDR_BatchNorm) or at most one row (DNN)
-    const bool skip_norm = (t.M == 1) || (a.skip_le1 && t.M <= 1);
+    const bool skip_norm = (Ms == 1) || (a.skip_le1 && Ms <= 1);
     float mean = 0.f, invstd = 1.f;
     if (c < S.C && !skip_norm) {
         if (a.training) {
             double s1 = 0.0, s2 = 0.0;
-            const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
-            for (int k = 0; k < used; ++k) {
-                const double* ws = a.workspace + ((int64_t)k * total_c + t.col_base + c) * 2;
-                s1 += ws[0]; s2 += ws[1];
+            if (global_stats) {
+                s1 = a.exchange[2 * (int64_t)(t.col_base + c)];
+                s2 = a.exchange[2 * (int64_t)(t.col_base + c) + 1];
+            } else {
+                const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
+                for (int k = 0; k < used; ++k) {
+                    const double* ws = a.workspace + ((int64_t)k * total_c + t.col_base + c) * 2;
+                    s1 += ws[0]; s2 += ws[1];
+                }
             }
-            const double mu = t.M > 0 ? s1 / t.M : 0.0;
-            double var = t.M > 0 ? s2 / t.M - mu * mu : 0.0;
+            const double mu = Ms > 0 ? s1 / Ms : 0.0;
+            double var = Ms > 0 ? s2 / Ms - mu * mu : 0.0;
             if (var < 0.0) var = 0.0;
             mean = (float)mu;
             invstd = (float)(1.0 / sqrt(var + (double)a.eps));
             if (t.chunk == 0 && wave == 0) {
                 if (S.save_mean) S.save_mean[c] = mean;
                 if (S.save_invstd) S.save_invstd[c] = invstd;
-                if (S.running_mean && t.M > 0) {
-                    const double unbiased = t.M > 1 ? var * ((double)t.M / (double)(t.M - 1)) : var;
+                if (S.running_mean && Ms > 0) {
+                    const double unbiased = Ms > 1 ? var * ((double)Ms / (double)(Ms - 1)) : var;
                     S.running_mean[c] = (1.f - a.momentum) * S.running_mean[c] + a.momentum * mean;
                     S.running_var[c] = (1.f - a.momentum) * S.running_var[c] + a.momentum * (float)unbiased;
                 }
@@ -241,6 +249,31 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
     }
 }
 
+// data parallel, between the two phases: per-column sums over the row chunks (fixed order) + the segment's row count go to
+// the exchange buffer [2*total_c | n_seg] that the caller all-reduces (SUM) across ranks
+template <typename Args>
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_collect(const Args a, int n_chunks, int total_c) {
+    const int gc = blockIdx.x * ROW_THREADS + threadIdx.x;
+    if (gc < a.n_seg) {
+        int M = (int)a.M;
+        if (a.row_offsets) { const int rg = a.s[gc].row_group; M = a.row_offsets[rg + 1] - a.row_offsets[rg]; }
+        a.exchange[2 * (int64_t)total_c + gc] = (double)M;
+    }
+    if (gc >= total_c) return;
+    int s = 0, base = 0;
+    for (; s < a.n_seg; ++s) { if (gc < base + a.s[s].C) break; base += a.s[s].C; }
+    int M = (int)a.M;
+    if (a.row_offsets) { const int rg = a.s[s].row_group; M = a.row_offsets[rg + 1] - a.row_offsets[rg]; }
+    const int used = (M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < used; ++k) {
+        const double* ws = a.workspace + ((int64_t)k * total_c + gc) * 2;
+        s1 += ws[0]; s2 += ws[1];
+    }
+    a.exchange[2 * (int64_t)gc] = s1;
+    a.exchange[2 * (int64_t)gc + 1] = s2;
+}
+
 extern "C" int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream) {
     CDC_CHECK_ARG(a && a->n_seg > 0 && a->n_seg <= CDC_MAX_BN_SEGS && a->M >= 0, CDC_E_BADARG, "bn_fwd: bad argument");
     CDC_CHECK_ARG(!a->training || a->workspace, CDC_E_BADARG, "bn_fwd: training needs a workspace");
@@ -252,13 +285,21 @@ extern "C" int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream) {
         total_c += S.C;
         col_tiles += (S.C + 63) / 64;
     }
+    CDC_CHECK_ARG(a->phase >= 0 && a->phase <= 2 && (a->phase == 0 || (a->exchange && a->training)), CDC_E_BADARG,
+                  "bn_fwd: phases 1/2 need training mode and an exchange buffer");
     if (a->M == 0) return 0;
     const int n_chunks = (int)cdc_ceil_div(a->M, CDC_BN_ROWS_PER_BLOCK);
     const int64_t grid = (int64_t)col_tiles * n_chunks;
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "bn_fwd: grid too large");
-    if (a->training) {
+    if (a->training && a->phase != 2) {
         hipLaunchKernelGGL(k_bn_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
         CDC_LAUNCH_CHECK("bn_stats");
+    }
+    if (a->phase == 1) {
+        hipLaunchKernelGGL(k_bn_collect<cdc_bn_fwd_args>, dim3(cdc_ceil_div(std::max(total_c, a->n_seg), ROW_THREADS)), dim3(ROW_THREADS), 0,
+                           (hipStream_t)stream, *a, n_chunks, total_c);
+        CDC_LAUNCH_CHECK("bn_collect");
+        return 0;
     }
     hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
     CDC_LAUNCH_CHECK("bn_apply");
@@ -303,7 +344,9 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = t.c0 + lane;
     if (c >= S.C) return;
-    const bool skip_norm = (t.M == 1);
+    const bool global_stats = a.training && a.phase == 2 && a.exchange;
+    const int Ms = global_stats ? (int)(a.exchange[2 * (int64_t)total_c + t.seg] + 0.5) : t.M;
+    const bool skip_norm = (Ms == 1);
     double s1 = 0.0, s2 = 0.0;
     if (!skip_norm) {
         const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
@@ -313,13 +356,18 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
         }
     }
     if (t.chunk == 0 && wave == 0) {
+        // parameter gradients stay LOCAL sums: the data-parallel all-reduce of the gradient arena adds the ranks up
         if (S.dbeta) S.dbeta[c] = (float)s1;
         if (S.dgamma) S.dgamma[c] = (float)s2;
+    }
+    if (global_stats && !skip_norm) {          // the input gradient needs the sums over the GLOBAL batch
+        s1 = a.exchange[2 * (int64_t)(t.col_base + c)];
+        s2 = a.exchange[2 * (int64_t)(t.col_base + c) + 1];
     }
     const float gam = (skip_norm || !S.gamma) ? 1.f : S.gamma[c];
     const float mean = skip_norm ? 0.f : S.save_mean[c];
     const float invstd = skip_norm ? 1.f : S.save_invstd[c];
-    const float invM = t.M > 0 ? 1.f / (float)t.M : 0.f;
+    const float invM = Ms > 0 ? 1.f / (float)Ms : 0.f;
     const float db = (float)s1, dg = (float)s2;
     const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
     const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
@@ -347,12 +395,22 @@ extern "C" int cdc_bn_bwd(const cdc_bn_bwd_args* a, void* stream) {
         total_c += S.C;
         col_tiles += (S.C + 63) / 64;
     }
+    CDC_CHECK_ARG(a->phase >= 0 && a->phase <= 2 && (a->phase == 0 || (a->exchange && a->training)), CDC_E_BADARG,
+                  "bn_bwd: phases 1/2 need training mode and an exchange buffer");
     if (a->M == 0) return 0;
     const int n_chunks = (int)cdc_ceil_div(a->M, CDC_BN_ROWS_PER_BLOCK);
     const int64_t grid = (int64_t)col_tiles * n_chunks;
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "bn_bwd: grid too large");
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
-    CDC_LAUNCH_CHECK("bn_bwd_stats");
+    if (a->phase != 2) {
+        hipLaunchKernelGGL(k_bn_bwd_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+        CDC_LAUNCH_CHECK("bn_bwd_stats");
+    }
+    if (a->phase == 1) {
+        hipLaunchKernelGGL(k_bn_collect<cdc_bn_bwd_args>, dim3(cdc_ceil_div(std::max(total_c, a->n_seg), ROW_THREADS)), dim3(ROW_THREADS), 0,
+                           (hipStream_t)stream, *a, n_chunks, total_c);
+        CDC_LAUNCH_CHECK("bn_bwd_collect");
+        return 0;
+    }
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
     CDC_LAUNCH_CHECK("bn_bwd_apply");
     return 0;

@@ -142,7 +142,7 @@ class _GradState:
 
 
 class Plan:
-    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0, step_dev=None, grad_arena=None):
+    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0, step_dev=None, grad_arena=None, dist=None):
         assert precision in ("bf16", "f32")
         self.lib = L.load()
         self.device = torch.device(device)
@@ -168,6 +168,9 @@ class Plan:
         # optional flat fp32 arena the dense-parameter gradients are carved from (one all-reduce under DP)
         self.grad_arena = grad_arena
         self._arena_used = 0
+        # data parallel: BatchNorm statistics are exchanged between ranks (global-batch statistics, like the reference's
+        # single process); the exchange steps are marked so the step driver can cut its launch graphs around them
+        self.dist = dist if (dist is not None and dist.world_size > 1) else None
         self._bn_ws = None
         self._bn_ws_need = 0
         self._rowdot_ws = None
@@ -257,6 +260,25 @@ class Plan:
         for op in reversed(self.ops):
             op.build_bwd(self, gs)
         self.finalized = True
+
+    def comm(self, fn):
+        """a collective between launches (runs eagerly; never part of a captured graph)"""
+        def run(stream):
+            fn()
+        run.is_comm = True
+        return run
+
+    @staticmethod
+    def segments(steps):
+        """[(is_comm, [steps...])]: maximal runs of launches, cut at every collective"""
+        out = []
+        for st in steps:
+            c = bool(getattr(st, "is_comm", False))
+            if out and out[-1][0] == c and not c:
+                out[-1][1].append(st)
+            else:
+                out.append((c, [st]))
+        return out
 
     def forward(self):
         s = _stream()
@@ -599,7 +621,19 @@ class BatchNorm:
                 S.C = s["x"].cols
                 S.row_group = s.get("row_group", 0)
             self._keep.append(a)
-            plan.fwd_steps.append(plan.call("cdc_bn_fwd", C.byref(a)))
+            if plan.dist is not None and plan.training:
+                # global-batch statistics: partial sums -> all-reduce -> normalise
+                total_c = sum(s["x"].cols for s in chunk)
+                ex = torch.zeros(2 * total_c + len(chunk), dtype=torch.float64, device=plan.device)
+                a.phase, a.exchange = 1, ex.data_ptr()
+                a2 = L.BnFwdArgs.from_buffer_copy(a)
+                a2.phase = 2
+                self._keep += [ex, a2]
+                plan.fwd_steps.append(plan.call("cdc_bn_fwd", C.byref(a), what="cdc_bn_fwd(stats)"))
+                plan.fwd_steps.append(plan.comm(lambda ex=ex: plan.dist.all_reduce_sum(ex)))
+                plan.fwd_steps.append(plan.call("cdc_bn_fwd", C.byref(a2), what="cdc_bn_fwd(apply)"))
+            else:
+                plan.fwd_steps.append(plan.call("cdc_bn_fwd", C.byref(a)))
 
     def build_bwd(self, plan, gs):
         # segments that normalise the SAME input over the same rows (STAR all-towers: every domain_norm reads the
@@ -663,7 +697,18 @@ class BatchNorm:
                 S.row_group = s.get("row_group", 0)
             self._keep.append(a)
             plan.bwd_steps.extend(pre)
-            plan.bwd_steps.append(plan.call("cdc_bn_bwd", C.byref(a)))
+            if plan.dist is not None and plan.training:
+                total_c = sum(s["x"].cols for s in chunk)
+                ex = torch.zeros(2 * total_c + len(chunk), dtype=torch.float64, device=plan.device)
+                a.phase, a.exchange = 1, ex.data_ptr()
+                a2 = L.BnBwdArgs.from_buffer_copy(a)
+                a2.phase = 2
+                self._keep += [ex, a2]
+                plan.bwd_steps.append(plan.call("cdc_bn_bwd", C.byref(a), what="cdc_bn_bwd(stats)"))
+                plan.bwd_steps.append(plan.comm(lambda ex=ex: plan.dist.all_reduce_sum(ex)))
+                plan.bwd_steps.append(plan.call("cdc_bn_bwd", C.byref(a2), what="cdc_bn_bwd(apply)"))
+            else:
+                plan.bwd_steps.append(plan.call("cdc_bn_bwd", C.byref(a)))
         if fan_in is not None:
             x = self.segs[0]["x"]
             if x.mask is not None:

@@ -22,10 +22,13 @@ class TrainStep:
          "single"  DCN / DCNv2: pred = model(X)                                                   (run.py:486-488)
     """
 
-    def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None):
+    def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None, sync_bn=True):
+        """sync_bn (data parallel only): BatchNorm statistics over the GLOBAL batch, as the reference's single process
+        computes them — two small all-reduces per BatchNorm launch; False = per-rank statistics."""
         self.model, self.opt, self.B, self.mode = model, optimizer, int(batch_size), mode
         self.lib = L.load()
         self.dist = dist
+        self.sync_bn = bool(sync_bn)
         self.world = 1 if dist is None else dist.world_size
         self.global_B = self.B * self.world
         dev = optimizer.device
@@ -42,6 +45,7 @@ class TrainStep:
         self.use_graph = use_graph
         self.graph = None
         self._stage_graphs = {}
+        self._dp_seq = None
         self._warm = 0
         if self.world > 1:
             F, D = self.emb.F, self.emb.D
@@ -57,7 +61,8 @@ class TrainStep:
 
         def build():
             plan = P.Plan(dev, B, precision=model.precision, training=True, dropout=float(getattr(model, "dropout_p", 0.0)),
-                          seed=int(getattr(model, "seed", 0)), step_dev=opt.step_dev, grad_arena=opt.grad_arena)
+                          seed=int(getattr(model, "seed", 0)), step_dev=opt.step_dev, grad_arena=opt.grad_arena,
+                          dist=self.dist if self.sync_bn else None)
             emb = model.embedding.describe(plan)
             outs, ins, extra = model.describe(plan, emb)
             plan.finalize(outs)
@@ -86,48 +91,69 @@ class TrainStep:
         opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
         opt.dense_step(plan.param_grads, plan._param_refs)
 
-    # ---- data parallel: three launch stages separated by the collectives (each stage replayable as a graph) -------------
-    def _stage0(self):
-        opt, emb = self.opt, self.emb
-        opt.begin_step()
-        opt.table_index(emb.ids, emb.offsets, emb.idx, self.B, emb.F)
+    # ---- data parallel: launch segments separated by the collectives (each segment replayable as a graph) ---------------
+    def _dp_sequence(self):
+        """[(is_comm, fn)]: dense gradients: ONE sum all-reduce of the flat arena (the loss already carries
+        1/global_batch); table: every rank applies the identical update from the all-gathered (row index, row gradient)
+        pairs of the global batch; BatchNorm: statistics all-reduced inside the plan (sync_bn)."""
+        opt, plan, emb, dp = self.opt, self.plan, self.emb, self.dist
+        F, D = emb.F, emb.D
 
-    def _stage1(self):
-        opt, plan, emb = self.opt, self.plan, self.emb
-        if opt.table_mode == "lazy":
-            opt.table_catchup_rows(self.idx_all, self.global_B, emb.F, emb.D)
-        plan.forward()
-        self._bce()
-        plan.backward()
+        def stage0():
+            opt.begin_step()
+            opt.table_index(emb.ids, emb.offsets, emb.idx, self.B, F)
 
-    def _stage2(self):
-        opt, plan, emb = self.opt, self.plan, self.emb
-        opt.table_step(self.idx_all, self.dE_all, self.global_B, emb.F, emb.D)
-        opt.dense_step(plan.param_grads, plan._param_refs)
+        def catchup():
+            if opt.table_mode == "lazy":
+                opt.table_catchup_rows(self.idx_all, self.global_B, F, D)
 
-    def _run_stage(self, i, fn):
-        if self.use_graph and self._warm >= 2:
+        def exchange():
+            dp.all_reduce_sum(opt.grad_arena[:max(plan._arena_used, 1)])
+            dp.all_gather_rows(self.dE_all, emb.out.grad.root)
+            dp.all_reduce_sum(self.loss)
+
+        def update():
+            opt.table_step(self.idx_all, self.dE_all, self.global_B, F, D)
+            opt.dense_step(plan.param_grads, plan._param_refs)
+
+        def run_steps(steps):
+            def fn():
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                for s_ in steps:
+                    s_(st)
+            return fn
+
+        seq = [(False, stage0), (True, lambda: dp.all_gather_rows(self.idx_all, emb.idx)), (False, catchup)]
+        for is_comm, steps in plan.segments(plan.fwd_steps):
+            seq.append((is_comm, run_steps(steps)))
+        seq.append((False, self._bce))
+        for is_comm, steps in plan.segments(plan.bwd_steps):
+            seq.append((is_comm, run_steps(steps)))
+        seq += [(True, exchange), (False, update)]
+        merged = []                                   # fuse neighbouring launch pieces into one segment
+        for is_comm, fn in seq:
+            if merged and not is_comm and not merged[-1][0]:
+                merged[-1][1].append(fn)
+            else:
+                merged.append((is_comm, [fn]))
+        return merged
+
+    def _step_dp(self):
+        if self._dp_seq is None:
+            self._dp_seq = self._dp_sequence()
+        for i, (is_comm, fns) in enumerate(self._dp_seq):
+            if is_comm or not (self.use_graph and self._warm >= 2):
+                for fn in fns:
+                    fn()
+                continue
             g = self._stage_graphs.get(i)
             if g is None:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    fn()
+                    for fn in fns:
+                        fn()
                 self._stage_graphs[i] = g
             g.replay()
-        else:
-            fn()
-
-    def _step_dp(self):
-        """dense gradients: ONE sum all-reduce of the flat arena (the loss already carries 1/global_batch); table: every rank
-        applies the identical update from the all-gathered (row index, row gradient) pairs of the global batch."""
-        opt, emb, dp = self.opt, self.emb, self.dist
-        self._run_stage(0, self._stage0)
-        dp.all_gather_rows(self.idx_all, emb.idx)
-        self._run_stage(1, self._stage1)
-        dp.all_reduce_sum(opt.grad_arena[:max(self.plan._arena_used, 1)])
-        dp.all_gather_rows(self.dE_all, emb.out.grad.root)
-        dp.all_reduce_sum(self.loss)
-        self._run_stage(2, self._stage2)
         self._warm += 1
 
     def step(self, X, y, group=None):

@@ -280,6 +280,11 @@ typedef struct {
     int64_t M;                        /* rows (upper bound when ragged) */
     const int32_t* row_offsets;       /* device, or NULL: every segment covers rows [0,M) */
     double* workspace;                /* >= 2 * ceil(M/64) * sum(C) doubles (training) */
+    int32_t phase;                    /* 0: statistics + normalisation in one call.  Data parallel (global-batch statistics, as
+                                         the reference's single process sees them): 1 = statistics only -> `exchange`;
+                                         the caller all-reduces (SUM) `exchange` across ranks; 2 = normalise from `exchange` */
+    int32_t pad_;
+    double* exchange;                 /* phases 1/2: [2*sum(C) column sums (x, x^2) | n_seg row counts] doubles */
     cdc_bn_seg s[CDC_MAX_BN_SEGS];
 } cdc_bn_fwd_args;
 int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream);
@@ -307,6 +312,9 @@ typedef struct {
     int64_t M;
     const int32_t* row_offsets;
     double* workspace;                /* >= 2 * ceil(M/64) * sum(C) doubles */
+    int32_t phase;                    /* as in cdc_bn_fwd_args; exchange = [2*sum(C) sums (dz, dz*xhat) | n_seg row counts] */
+    int32_t pad_;
+    double* exchange;
     cdc_bn_bseg s[CDC_MAX_BN_SEGS];
 } cdc_bn_bwd_args;
 int cdc_bn_bwd(const cdc_bn_bwd_args* a, void* stream);
