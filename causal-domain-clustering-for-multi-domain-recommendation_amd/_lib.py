@@ -45,7 +45,7 @@ class LinFwdArgs(C.Structure):
 
 
 class BwdxSeg(C.Structure):
-    _fields_ = [("dz", c_p), ("lddz", c_i64), ("w", c_p), ("ldw", c_i64), ("N", c_i32), ("out", c_i32)]
+    _fields_ = [("dz", c_p), ("lddz", c_i64), ("w", c_p), ("ldw", c_i64), ("wt", c_p), ("ldwt", c_i64), ("N", c_i32), ("out", c_i32)]
 
 
 class BwdxOut(C.Structure):
@@ -56,6 +56,14 @@ class BwdxOut(C.Structure):
 class LinBwdxArgs(C.Structure):
     _fields_ = [("n_out", c_i32), ("n_seg", c_i32), ("mask_scale", c_f), ("row_offsets", c_p),
                 ("o", BwdxOut * MAX_GROUPS), ("s", BwdxSeg * MAX_GROUPS)]
+
+
+class TransposeItem(C.Structure):
+    _fields_ = [("src", c_p), ("dst", c_p), ("rows", c_i32), ("cols", c_i32)]
+
+
+class TransposeArgs(C.Structure):
+    _fields_ = [("n", c_i32), ("pad_", c_i32), ("t", TransposeItem * MAX_TENSORS)]
 
 
 class BwdwGroup(C.Structure):
@@ -167,6 +175,7 @@ _SIGNATURES = {
     "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_i32, c_p, c_i32, c_p]),
     "cdc_glinear_fwd": (c_i32, [C.POINTER(LinFwdArgs), c_i32, c_p]),
     "cdc_glinear_bwd_x": (c_i32, [C.POINTER(LinBwdxArgs), c_i32, c_p]),
+    "cdc_transpose_multi": (c_i32, [C.POINTER(TransposeArgs), c_p]),
     "cdc_glinear_bwd_w": (c_i32, [C.POINTER(LinBwdwArgs), c_i32, c_p]),
     "cdc_gate_pool_fwd": (c_i32, [C.POINTER(PoolFwdArgs), c_p]),
     "cdc_gate_pool_bwd": (c_i32, [C.POINTER(PoolBwdArgs), c_p]),

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_
 // =================================================================================================
 // grad-input: dX_o = sum_s dZ_s · W_s  (+ activation mask of the producing layer)
 // =================================================================================================
-template <bool BF16, int BM, int BN>
+template <bool BF16, int BM, int BN, bool WT>
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bwdx_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -254,8 +254,13 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bw
         if (a.s[s].out != o) continue;
         const cdc_bwdx_seg& S = a.s[s];
         Operand A{S.dz + (int64_t)row_lo * S.lddz, S.lddz, 1, M, S.N};   // (i=row, r=n)  r contiguous
-        Operand B{S.w, 1, S.ldw, O.K, S.N};                               // (j=k,  r=n)  j contiguous
-        gemm_accumulate<BF16, BM, BN, true, false, false>(A, B, i0, j0, smem, acc, nullptr);
+        if (WT) {
+            Operand B{S.wt, S.ldwt, 1, O.K, S.N};                         // W^T [K,N]: (j=k, r=n)  r contiguous
+            gemm_accumulate<BF16, BM, BN, true, true, false>(A, B, i0, j0, smem, acc, nullptr);
+        } else {
+            Operand B{S.w, 1, S.ldw, O.K, S.N};                           // W [N,K]:   (j=k, r=n)  j contiguous
+            gemm_accumulate<BF16, BM, BN, true, false, false>(A, B, i0, j0, smem, acc, nullptr);
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -433,6 +438,17 @@ extern "C" int cdc_glinear_fwd(const cdc_lin_fwd_args* a, int32_t prec, void* st
     return 0;
 }
 
+template <bool WT>
+static void launch_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, bool big, int64_t grid, hipStream_t st) {
+    if (prec == CDC_PREC_BF16) {
+        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<true, 128, 128, WT>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_bwd_x<true, 64, 64, WT>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
+    } else {
+        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<false, 128, 128, WT>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_bwd_x<false, 64, 64, WT>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
+    }
+}
+
 extern "C" int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void* stream) {
     CDC_CHECK_ARG(a && a->n_out > 0 && a->n_out <= CDC_MAX_GROUPS && a->n_seg > 0 && a->n_seg <= CDC_MAX_GROUPS, CDC_E_BADARG,
                   "glinear_bwd_x: bad counts");
@@ -444,24 +460,57 @@ extern "C" int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void*
         t64 += cdc_ceil_div(O.M, 64) * cdc_ceil_div(O.K, 64);
         t128 += cdc_ceil_div(O.M, 128) * cdc_ceil_div(O.K, 128);
     }
+    bool all_wt = true;
     for (int s = 0; s < a->n_seg; ++s) {
         const cdc_bwdx_seg& S = a->s[s];
         CDC_CHECK_ARG(S.dz && S.w && S.N > 0 && S.out >= 0 && S.out < a->n_out && S.lddz >= S.N && S.ldw >= a->o[S.out].K,
                       CDC_E_BADARG, "glinear_bwd_x: segment %d malformed", s);
+        CDC_CHECK_ARG(!S.wt || S.ldwt >= S.N, CDC_E_BADARG, "glinear_bwd_x: segment %d transposed copy malformed", s);
+        all_wt = all_wt && S.wt != nullptr;
     }
     if (t64 == 0) return 0;
     const bool big = pick_big_tiles(t64);
     const int64_t grid = big ? t128 : t64;
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "glinear_bwd_x: grid too large");
-    hipStream_t st = (hipStream_t)stream;
-    if (prec == CDC_PREC_BF16) {
-        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<true, 128, 128>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 128, 128>()), st, *a);
-        else     hipLaunchKernelGGL((k_glinear_bwd_x<true, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
-    } else {
-        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<false, 128, 128>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 128, 128>()), st, *a);
-        else     hipLaunchKernelGGL((k_glinear_bwd_x<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
-    }
+    if (all_wt) launch_bwd_x<true>(a, prec, big, grid, (hipStream_t)stream);
+    else launch_bwd_x<false>(a, prec, big, grid, (hipStream_t)stream);
     CDC_LAUNCH_CHECK("glinear_bwd_x");
+    return 0;
+}
+
+// dst[c, r] = src[r, c] for a list of matrices: 32x32 tiles through LDS (padded), one launch for the whole list
+__global__ void __launch_bounds__(256) k_transpose_multi(const cdc_transpose_args a) {
+    __shared__ float tile[32][33];
+    int blk = blockIdx.x, ti = 0, tc = 1;
+    for (; ti < a.n; ++ti) {
+        tc = (a.t[ti].cols + 31) / 32;
+        const int nb = ((a.t[ti].rows + 31) / 32) * tc;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    if (ti >= a.n) return;
+    const int rows = a.t[ti].rows, cols = a.t[ti].cols;
+    const int r0 = (blk / tc) * 32, c0 = (blk % tc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < rows && c < cols) ? a.t[ti].src[(int64_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < cols && r < rows) a.t[ti].dst[(int64_t)c * rows + r] = tile[tx][k];
+    }
+}
+extern "C" int cdc_transpose_multi(const cdc_transpose_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->n > 0 && a->n <= CDC_MAX_TENSORS, CDC_E_BADARG, "transpose_multi: bad count");
+    int64_t blocks = 0;
+    for (int i = 0; i < a->n; ++i) {
+        CDC_CHECK_ARG(a->t[i].src && a->t[i].dst && a->t[i].rows > 0 && a->t[i].cols > 0, CDC_E_BADARG, "transpose_multi: tensor %d malformed", i);
+        blocks += cdc_ceil_div(a->t[i].rows, 32) * cdc_ceil_div(a->t[i].cols, 32);
+    }
+    hipLaunchKernelGGL(k_transpose_multi, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("transpose_multi");
     return 0;
 }
 

@@ -177,6 +177,8 @@ class Plan:
         self._rowdot_ws_need = 0
         self._gemm_ws = None
         self._gemm_ws_need = 0
+        self._wt = {}                     # weight key -> (weight object, transposed copy [K,N]) refreshed at the start of backward
+        self._deferred_dw = []            # grad-weight groups of every layer, launched together at the end of backward
         self.finalized = False
         self.loss_inputs = None
 
@@ -234,6 +236,64 @@ class Plan:
     def need_bn_ws(self, rows, total_c):
         self._bn_ws_need = max(self._bn_ws_need, 2 * math.ceil(rows / L.BN_ROWS_PER_BLOCK) * total_c)
 
+    def wt_of(self, w):
+        """per-step transposed copy [K,N] of a linear weight [N,K]: grad-input then streams both operands with the
+        reduction index contiguous (no transposing LDS stores)"""
+        key = (id(w.param), w.index) if isinstance(w, PView) else (id(w.tensor) if isinstance(w, TView) else id(w))
+        hit = self._wt.get(key)
+        if hit is None:
+            N, K = w.shape
+            hit = (w, torch.empty((K, N), dtype=torch.float32, device=self.device))
+            self._wt[key] = hit
+        return hit[1]
+
+    def _emit_transposes(self):
+        items = list(self._wt.values())
+        steps = []
+        for c0 in range(0, len(items), L.MAX_TENSORS):
+            a = L.TransposeArgs()
+            chunk = items[c0:c0 + L.MAX_TENSORS]
+            a.n = len(chunk)
+            for i, (w, wt) in enumerate(chunk):
+                a.t[i].src, a.t[i].dst = w.data_ptr(), wt.data_ptr()
+                a.t[i].rows, a.t[i].cols = w.shape[0], w.shape[1]
+            self._keep_args = getattr(self, "_keep_args", []) + [a]
+            steps.append(self.call("cdc_transpose_multi", C.byref(a)))
+        return steps
+
+    def _emit_deferred_dw(self):
+        """All layers' grad-weight contractions are independent of the rest of backward once their dZ exists: they go out
+        together at the end, in launches that fill the chip (instead of one under-filled launch per layer)."""
+        groups = self._deferred_dw
+        launches, cur = [], []
+        for g in groups:
+            if cur and (len(cur) >= L.MAX_GROUPS or g["accumulate"]):
+                launches.append(cur)
+                cur = []
+            cur.append(g)
+        if cur:
+            launches.append(cur)
+        steps = []
+        for chunk in launches:
+            a = L.LinBwdwArgs()
+            a.n_groups = len(chunk)
+            tiles = sum(math.ceil(g["N"] / 64) * math.ceil(g["K"] / 64) for g in chunk)
+            Mmax = max(g["M"] for g in chunk)
+            S = max(1, min(1536 // max(tiles, 1), max(Mmax // 128, 1), 64))
+            a.split_k = S
+            if S > 1:
+                self.need_gemm_ws(S * sum(g["N"] * g["K"] + g["N"] for g in chunk))
+            a.row_offsets = None
+            for i, g in enumerate(chunk):
+                G = a.g[i]
+                G.dz, G.lddz, G.x, G.ldx = g["dz"], g["lddz"], g["x"], g["ldx"]
+                G.dw, G.lddw, G.db = g["dw"], g["lddw"], g["db"]
+                G.M, G.N, G.K, G.accumulate = g["M"], g["N"], g["K"], g["accumulate"]
+            self._keep_args = getattr(self, "_keep_args", []) + [a]
+            fl = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
+            steps.append((a, fl))
+        return steps
+
     def need_gemm_ws(self, n):
         self._gemm_ws_need = max(self._gemm_ws_need, n)
 
@@ -259,6 +319,13 @@ class Plan:
             op.build_fwd(self)
         for op in reversed(self.ops):
             op.build_bwd(self, gs)
+        dw = self._emit_deferred_dw()
+        if self._gemm_ws.numel() < self._gemm_ws_need:
+            self._gemm_ws = torch.empty(self._gemm_ws_need, dtype=torch.float32, device=self.device)
+        for a, fl in dw:
+            a.workspace = self._gemm_ws.data_ptr()
+            self.bwd_steps.append(self.call("cdc_glinear_bwd_w", C.byref(a), self.prec, flops=fl))
+        self.bwd_steps[0:0] = self._emit_transposes()
         self.finalized = True
 
     def comm(self, fn):
@@ -397,7 +464,24 @@ class GLinear:
         for g in self.groups:
             plan.ensure_grad(g["y"], gs)
         # ---- grad-weight / grad-bias
-        for c0 in range(0, len(self.groups), L.MAX_GROUPS):
+        # leaf weights (parameters): deferred to one launch with every other layer's at the end of backward.
+        # fused weights (STAR's W_d*W_s: their gradient feeds a further backward op) and ragged groups: right here.
+        defer = self.row_offsets is None and not any(isinstance(g["w"], TView) or isinstance(g.get("b"), TView) for g in self.groups)
+        if defer:
+            for g in self.groups:
+                N, K = g["w"].shape
+                dz = g["y"].grad
+                gw = plan.param_grad(g["w"])
+                acc_w = plan._claim_param(g["w"])
+                db = None
+                if g.get("b") is not None:
+                    gb = plan.param_grad(g["b"])
+                    acc_b = plan._claim_param(g["b"])
+                    assert acc_b == acc_w
+                    db = gb.data_ptr()
+                plan._deferred_dw.append({"dz": dz.ptr, "lddz": dz.ld, "x": g["x"].ptr, "ldx": g["x"].ld, "dw": gw.data_ptr(), "lddw": K,
+                                          "db": db, "M": self.M, "N": N, "K": K, "accumulate": 1 if acc_w else 0})
+        for c0 in (range(0, len(self.groups), L.MAX_GROUPS) if not defer else []):
             chunk = self.groups[c0:c0 + L.MAX_GROUPS]
             a = L.LinBwdwArgs()
             a.n_groups = len(chunk)
@@ -489,6 +573,8 @@ class GLinear:
                     dz = g["y"].grad
                     S.dz, S.lddz = dz.ptr, dz.ld
                     S.w, S.ldw = g["w"].data_ptr(), g["w"].shape[1]
+                    wt = plan.wt_of(g["w"])
+                    S.wt, S.ldwt = wt.data_ptr(), g["w"].shape[0]
                     S.N = g["w"].shape[0]
                     S.out = oi
                     si += 1

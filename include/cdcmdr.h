@@ -172,6 +172,8 @@ int cdc_glinear_fwd(const cdc_lin_fwd_args* a, int32_t prec, void* stream);
 typedef struct {
     const float* dz; int64_t lddz;   /* [M,N] */
     const float* w;  int64_t ldw;    /* [N,K] */
+    const float* wt; int64_t ldwt;   /* optional [K,N] transposed copy of w (cdc_transpose_multi): when every segment of a
+                                        launch has one, both operands stream with the reduction index contiguous */
     int32_t N;
     int32_t out;                     /* index of the output this segment reduces into */
 } cdc_bwdx_seg;
@@ -190,6 +192,14 @@ typedef struct {
     cdc_bwdx_seg s[CDC_MAX_GROUPS];
 } cdc_lin_bwdx_args;
 int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void* stream);
+
+/* dst_i[c,r] = src_i[r,c] for up to CDC_MAX_TENSORS row-major matrices in one launch (per-step W^T copies for grad-input). */
+typedef struct {
+    int32_t n;
+    int32_t pad_;
+    struct { const float* src; float* dst; int32_t rows, cols; } t[CDC_MAX_TENSORS];
+} cdc_transpose_args;
+int cdc_transpose_multi(const cdc_transpose_args* a, void* stream);
 
 /* dW_g[N,K] = dZ_gᵀ · X_g ; db_g[N] = column sums of dZ_g (fp32, exact order-fixed reduction). */
 typedef struct {
