@@ -372,19 +372,14 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
 }
 
 __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a, int64_t slab_stride) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < slab_stride; e += (int64_t)gridDim.x * blockDim.x) {
-        int g = 0;
-        int64_t local = e;
-        for (; g < a.n_groups; ++g) {
-            const int64_t sz = (int64_t)a.g[g].N * a.g[g].K + a.g[g].N;
-            if (local < sz) break;
-            local -= sz;
-        }
-        if (g >= a.n_groups) return;
-        const cdc_bwdw_group& G = a.g[g];
+    const int g = blockIdx.y;
+    const cdc_bwdw_group& G = a.g[g];
+    int64_t g_off = 0;
+    for (int i = 0; i < g; ++i) g_off += (int64_t)a.g[i].N * a.g[i].K + a.g[i].N;
+    const int64_t nk = (int64_t)G.N * G.K, sz = nk + G.N;
+    for (int64_t local = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; local < sz; local += (int64_t)gridDim.x * blockDim.x) {
         float sum = 0.f;
-        for (int s = 0; s < a.split_k; ++s) sum += a.workspace[(int64_t)s * slab_stride + e];
-        const int64_t nk = (int64_t)G.N * G.K;
+        for (int s = 0; s < a.split_k; ++s) sum += a.workspace[(int64_t)s * slab_stride + g_off + local];
         if (local < nk) {
             float* dst = G.dw + (local / G.K) * G.lddw + (local % G.K);
             *dst = G.accumulate ? *dst + sum : sum;
@@ -393,6 +388,159 @@ __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a,
             *dst = G.accumulate ? *dst + sum : sum;
         }
     }
+}
+
+// =================================================================================================
+// grad-weight on bf16 MFMA without transposing stores: both operands are staged in their NATURAL layout
+// ([batch row][column], coalesced 16-B loads, 8-B LDS stores) and the MFMA fragments — which need the reduction
+// (batch-row) index contiguous — are fetched with the CDNA4 transposing LDS read ds_read_b64_tr_b16.
+// k-order inside one MFMA is a permutation of the 32 staged rows (same for A and B, so the sum is unchanged):
+// lane group g, element j  <->  row 4g + j (j < 4) | 16 + 4g + (j - 4): each half-wave then reads 8 consecutive rows,
+// which the 160-byte row stride spreads over all 64 banks.
+// =================================================================================================
+#define TR_BK 64
+#define TR_STRIDE 80                 /* bf16 elements per LDS row: 64 + 16 pad = 160 B */
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8_t tr_fragment(const __bf16* tile, int row_base, int col0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const __bf16* a0 = tile + (row_base + 4 * g + q) * TR_STRIDE + col0 + 4 * p;
+    const __bf16* a1 = a0 + 16 * TR_STRIDE;
+    typedef s16x4_t __attribute__((address_space(3))) * lds_ptr;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a1);
+    union { s16x4_t h[2]; bf16x8_t v; } u;
+    u.h[0] = lo; u.h[1] = hi;
+    return u.v;
+}
+
+__global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w_tr(const cdc_lin_bwdw_args a, int64_t slab_stride) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[TR_BK * TR_STRIDE];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[TR_BK * TR_STRIDE];
+    const int S = a.split_k > 1 ? a.split_k : 1;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = id % S;
+    int tile = id / S;
+    int g = 0, tn_cnt = 1;
+    int64_t g_off = 0;
+    for (; g < a.n_groups; ++g) {
+        tn_cnt = (a.g[g].K + 63) / 64;
+        const int t = ((a.g[g].N + 63) / 64) * tn_cnt;
+        if (tile < t) break;
+        tile -= t;
+        g_off += (int64_t)a.g[g].N * a.g[g].K + a.g[g].N;
+    }
+    if (g >= a.n_groups) return;
+    const cdc_bwdw_group& G = a.g[g];
+    int row_lo = 0, M = G.M;
+    if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
+    int chunk = ((M + S - 1) / S + TR_BK - 1) / TR_BK * TR_BK;
+    if (chunk < TR_BK) chunk = TR_BK;
+    const int r0 = split * chunk;
+    int rn = M - r0;
+    if (rn > chunk) rn = chunk;
+    if (rn < 0) rn = 0;
+    const int i0 = (tile / tn_cnt) * 64, j0 = (tile % tn_cnt) * 64;    // i over N (dW rows), j over K (dW cols)
+    const float* dz = G.dz + (int64_t)(row_lo + r0) * G.lddz;
+    const float* x = G.x + (int64_t)(row_lo + r0) * G.ldx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    // staging: thread -> 4 consecutive columns (c4) of rows r_, r_+16, r_+32, r_+48
+    const int c4 = (tid & 15) * 4, rr = tid >> 4;
+    const bool vec_a = (G.lddz % 4 == 0) && ((((uintptr_t)dz) & 15) == 0) && (i0 + c4 + 3 < G.N);
+    const bool vec_b = (G.ldx % 4 == 0) && ((((uintptr_t)x) & 15) == 0) && (j0 + c4 + 3 < G.K);
+    f32x4_t ra[4], rb[4];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = k0 + rr + 16 * p;
+            f32x4_t va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (r < rn) {
+                const float* pa = dz + (int64_t)r * G.lddz + i0 + c4;
+                const float* pb = x + (int64_t)r * G.ldx + j0 + c4;
+                if (vec_a) va = *reinterpret_cast<const f32x4_t*>(pa);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (i0 + c4 + q < G.N) va[q] = pa[q];
+                }
+                if (vec_b) vb = *reinterpret_cast<const f32x4_t*>(pb);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (j0 + c4 + q < G.K) vb[q] = pb[q];
+                }
+            }
+            ra[p] = va; rb[p] = vb;
+        }
+    };
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    f32x4_t colsum = {0.f, 0.f, 0.f, 0.f};
+    const bool want_db = (G.db != nullptr) && (j0 == 0);
+    const int nk = (rn + TR_BK - 1) / TR_BK;
+    if (nk > 0) load(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (want_db) colsum += ra[p];                               // bias gradient in fp32, before the bf16 rounding
+            const int r = rr + 16 * p;
+            *reinterpret_cast<bf16x4_t*>(As + r * TR_STRIDE + c4) = __builtin_convertvector(ra[p], bf16x4_t);
+            *reinterpret_cast<bf16x4_t*>(Bs + r * TR_STRIDE + c4) = __builtin_convertvector(rb[p], bf16x4_t);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load((kt + 1) * TR_BK);
+#pragma unroll
+        for (int ks = 0; ks < TR_BK / 32; ++ks) {
+            bf16x8_t fa[2], fb[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) fa[mt] = tr_fragment(As, ks * 32, wm + mt * 16, lane);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) fb[nt] = tr_fragment(Bs, ks * 32, wn + nt * 16, lane);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* slab = S > 1 ? a.workspace + (int64_t)split * slab_stride + g_off : nullptr;
+    if (want_db) {
+        __shared__ float red[GEMM_THREADS * 4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[tid * 4 + q] = colsum[q];
+        __syncthreads();
+        if (tid < 64) {
+            const int cc = tid / 4, q = tid % 4;
+            float sum = 0.f;
+            for (int t = cc; t < GEMM_THREADS; t += 16) sum += red[t * 4 + q];
+            const int n = i0 + tid;
+            if (n < G.N) {
+                if (slab) slab[(int64_t)G.N * G.K + n] = sum;
+                else G.db[n] = G.accumulate ? G.db[n] + sum : sum;
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = j0 + wn + nt * 16 + (lane & 15);
+            if (col >= G.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
+                if (row >= G.N) continue;
+                const float val = acc[mt][nt][r];
+                if (slab) slab[(int64_t)row * G.K + col] = val;
+                else {
+                    float* dst = G.dw + (int64_t)row * G.lddw + col;
+                    *dst = G.accumulate ? *dst + val : val;
+                }
+            }
+        }
 }
 
 // =================================================================================================
@@ -532,13 +680,15 @@ extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void*
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "glinear_bwd_w: grid too large");
     hipStream_t st = (hipStream_t)stream;
     if (prec == CDC_PREC_BF16)
-        hipLaunchKernelGGL((k_glinear_bwd_w<true, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a, slab);
+        hipLaunchKernelGGL(k_glinear_bwd_w_tr, dim3(grid), dim3(GEMM_THREADS), 0, st, *a, slab);
     else
         hipLaunchKernelGGL((k_glinear_bwd_w<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a, slab);
     CDC_LAUNCH_CHECK("glinear_bwd_w");
     if (S > 1) {
-        int blocks = (int)std::min<int64_t>(cdc_ceil_div(slab, 256), 4096);
-        hipLaunchKernelGGL(k_bwd_w_reduce, dim3(blocks), dim3(256), 0, st, *a, slab);
+        int64_t biggest = 0;
+        for (int g = 0; g < a->n_groups; ++g) biggest = std::max<int64_t>(biggest, (int64_t)a->g[g].N * a->g[g].K + a->g[g].N);
+        int blocks = (int)std::min<int64_t>(cdc_ceil_div(biggest, 256), 512);
+        hipLaunchKernelGGL(k_bwd_w_reduce, dim3(blocks, a->n_groups), dim3(256), 0, st, *a, slab);
         CDC_LAUNCH_CHECK("bwd_w_reduce");
     }
     return 0;
