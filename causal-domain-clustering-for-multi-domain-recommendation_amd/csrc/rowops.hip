@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
                 s2 = a.exchange[2 * (int64_t)(t.col_base + c) + 1];
             } else {
                 const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
+#pragma unroll 8
                 for (int k = 0; k < used; ++k) {
                     const double* ws = a.workspace + ((int64_t)k * total_c + t.col_base + c) * 2;
                     s1 += ws[0]; s2 += ws[1];
@@ -350,6 +351,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
     double s1 = 0.0, s2 = 0.0;
     if (!skip_norm) {
         const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
+#pragma unroll 8
         for (int k = 0; k < used; ++k) {
             const double* ws = a.workspace + ((int64_t)k * total_c + t.col_base + c) * 2;
             s1 += ws[0]; s2 += ws[1];
@@ -656,7 +658,7 @@ extern "C" int cdc_cross_bwd(const float* d_out, int64_t ldo, const float* x0, i
 // =================================================================================================
 // dense-parameter Adam, multi-tensor (run.py:720-721 + the L2 term of model/layer.py:96-112)
 // =================================================================================================
-#define ADAM_CHUNK 4096
+#define ADAM_CHUNK 1024
 __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args a) {
     int chunk = blockIdx.x, ti = 0;
     for (; ti < a.n_tensors; ++ti) {
