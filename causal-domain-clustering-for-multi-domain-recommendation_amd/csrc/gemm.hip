@@ -17,14 +17,12 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 #define GEMM_THREADS 256
-#define BK 32
-// LDS row strides chosen so the 16 lanes of a ds_read_b128 group land on disjoint bank quads
-#define LDS_STRIDE_BF16 40   // elements: 80 bytes
-#define LDS_STRIDE_F32 33    // elements
-
-template <bool BF16> struct LdsElem;
-template <> struct LdsElem<true> { typedef __bf16 type; static constexpr int stride = LDS_STRIDE_BF16; };
-template <> struct LdsElem<false> { typedef float type; static constexpr int stride = LDS_STRIDE_F32; };
+#define GEMM_BK 32           // reduction depth staged per barrier pair (64 measured slower: register pressure halves occupancy)
+// LDS row strides chosen so the 16 lanes of a ds_read_b128 group land on disjoint bank quads:
+// bf16: BK + 8 elements (80 B at BK 32, 144 B at BK 64); fp32: BK + 1
+template <bool BF16, int BK> struct LdsElem;
+template <int BK> struct LdsElem<true, BK> { typedef __bf16 type; static constexpr int stride = BK + 8; };
+template <int BK> struct LdsElem<false, BK> { typedef float type; static constexpr int stride = BK + 1; };
 
 // A tile operand: element (i, r) lives at p[i*s_i + r*s_r]; i in [0,I) (tile rows), r in [0,Rn) (reduction).
 struct Operand {
@@ -36,7 +34,7 @@ struct Operand {
 // ---- staging: global -> registers (fp32) -------------------------------------------------------
 // RC = true : reduction index contiguous in memory (s_r == 1): thread loads 4 consecutive r
 // RC = false: tile-row index contiguous (s_i == 1): thread loads 4 consecutive i at one r
-template <int ROWS, bool RC>
+template <int ROWS, bool RC, int BK>
 struct Stage {
     static constexpr int PER = ROWS * BK / 4 / GEMM_THREADS;   // float4 loads per thread
     f32x4_t v[PER];
@@ -96,22 +94,25 @@ struct Stage {
 };
 
 // ---- one K-slab of MFMAs for this wave ------------------------------------------------------------
-template <bool BF16, int MT, int NT>
-__device__ __forceinline__ void mma_slab(const typename LdsElem<BF16>::type* As, const typename LdsElem<BF16>::type* Bs,
+template <bool BF16, int MT, int NT, int BK>
+__device__ __forceinline__ void mma_slab(const typename LdsElem<BF16, BK>::type* As, const typename LdsElem<BF16, BK>::type* Bs,
                                          int wm, int wn, int lane, f32x4_t (&acc)[MT][NT]) {
-    constexpr int S = LdsElem<BF16>::stride;
+    constexpr int S = LdsElem<BF16, BK>::stride;
     const int lr = lane & 15, lk = lane >> 4;
     if constexpr (BF16) {
-        bf16x8_t a[MT], b[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8_t*>(As + (wm + mt * 16 + lr) * S + lk * 8);
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8_t a[MT], b[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn + nt * 16 + lr) * S + lk * 8);
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const bf16x8_t*>(As + (wm + mt * 16 + lr) * S + ks * 32 + lk * 8);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + (wn + nt * 16 + lr) * S + ks * 32 + lk * 8);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
     } else {
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
@@ -133,27 +134,28 @@ __device__ __forceinline__ void mma_slab(const typename LdsElem<BF16>::type* As,
 template <bool BF16, int BM, int BN, bool A_RC, bool B_RC, bool COLSUM>
 __device__ __forceinline__ void gemm_accumulate(const Operand& A, const Operand& B, int i0, int j0, unsigned char* smem,
                                                 f32x4_t (&acc)[BM / 32][BN / 32], f32x4_t* colsum) {
-    typedef typename LdsElem<BF16>::type T;
-    constexpr int S = LdsElem<BF16>::stride;
+    constexpr int BK = GEMM_BK;
+    typedef typename LdsElem<BF16, BK>::type T;
+    constexpr int S = LdsElem<BF16, BK>::stride;
     T* As = reinterpret_cast<T*>(smem);
     T* Bs = As + BM * S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     const int nk = (A.Rn + BK - 1) / BK;
-    Stage<BM, A_RC> sa;
-    Stage<BN, B_RC> sb;
+    Stage<BM, A_RC, BK> sa;
+    Stage<BN, B_RC, BK> sb;
     if (nk > 0) { sa.load(A, i0, 0, tid); sb.load(B, j0, 0, tid); }
     for (int kt = 0; kt < nk; ++kt) {
         if (COLSUM) {
             // bias gradient: column sums of the A operand (dZ) in fp32, taken before the bf16 rounding
 #pragma unroll
-            for (int p = 0; p < Stage<BM, A_RC>::PER; ++p) colsum[0] += sa.v[p];
+            for (int p = 0; p < Stage<BM, A_RC, BK>::PER; ++p) colsum[0] += sa.v[p];
         }
         sa.store(As, S, tid);
         sb.store(Bs, S, tid);
         __syncthreads();
         if (kt + 1 < nk) { sa.load(A, i0, (kt + 1) * BK, tid); sb.load(B, j0, (kt + 1) * BK, tid); }
-        mma_slab<BF16, BM / 32, BN / 32>(As, Bs, wm, wn, lane, acc);
+        mma_slab<BF16, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
         __syncthreads();
     }
 }
@@ -310,8 +312,8 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
     int row_lo = 0, M = G.M;
     if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
     // this workgroup's slice of the batch rows (multiple of BK so every slice but the last is whole K-slabs)
-    int chunk = ((M + S - 1) / S + BK - 1) / BK * BK;
-    if (chunk < BK) chunk = BK;
+    int chunk = ((M + S - 1) / S + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    if (chunk < GEMM_BK) chunk = GEMM_BK;
     const int r0 = split * chunk;
     int rn = M - r0;
     if (rn > chunk) rn = chunk;
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w_tr(const cdc_lin
 // =================================================================================================
 template <bool BF16, int BM, int BN>
 static constexpr size_t lds_bytes() {
-    size_t tiles = (size_t)(BM + BN) * LdsElem<BF16>::stride * sizeof(typename LdsElem<BF16>::type);
+    size_t tiles = (size_t)(BM + BN) * LdsElem<BF16, GEMM_BK>::stride * sizeof(typename LdsElem<BF16, GEMM_BK>::type);
     size_t red = (size_t)GEMM_THREADS * 4 * sizeof(float);
     return tiles > red ? tiles : red;
 }

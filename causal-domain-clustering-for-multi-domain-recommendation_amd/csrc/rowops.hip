@@ -502,6 +502,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd_final(const cdc_rowd
     if (k > kmax) return;
     const float* ws = a.workspace + (int64_t)g * CDC_ROWDOT_PARTS * (kmax + 1);
     float s = 0.f;
+#pragma unroll 16
     for (int p = 0; p < CDC_ROWDOT_PARTS; ++p) s += ws[(int64_t)p * (kmax + 1) + k];
     if (k < G.K) { if (G.dw) G.dw[k] = s; }
     else if (k == kmax && G.dbias) G.dbias[0] = s;
@@ -637,6 +638,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_cross_bwd_final(const float* __
     const int k = blockIdx.x * ROW_THREADS + threadIdx.x;
     if (k >= 2 * E) return;
     float s = 0.f;
+#pragma unroll 16
     for (int p = 0; p < CDC_ROWDOT_PARTS; ++p) s += workspace[(int64_t)p * 2 * E + k];
     if (k < E) dw[k] = s; else db[k - E] = s;
 }
@@ -822,6 +824,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_cross_combine_bwd_final(const f
     const int c = blockIdx.x * ROW_THREADS + threadIdx.x;
     if (c >= period) return;
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 16
     for (int p = 0; p < CDC_ROWDOT_PARTS; ++p) {
         s1 += workspace[((int64_t)p * 2 + 0) * period + c];
         s2 += workspace[((int64_t)p * 2 + 1) * period + c];
