@@ -92,38 +92,38 @@ __device__ __forceinline__ void adam_elem_fast(float& w, float& m, float& v, con
     const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2, c.eps);
     w = fmaf(__fmul_rn(-step_size, m), __builtin_amdgcn_rcpf(denom), w);
 }
-// replays steps from+1 .. to of the L2-only recurrence for one element.  The per-step scalars come from the host table
+// replays steps from+1 .. to of the L2-only recurrence for N elements of one row in lockstep (N independent dependency
+// chains per thread hide the ~10-deep latency chain of one element-step).  The per-step scalars come from the host table
 // while the bias corrections still move (t < n_scalars-1, ~1700 steps) and are constants afterwards.  When every lane of
 // the wave replays the same steps (rows not looked up since the last whole-table catch-up) the step index is kept in
 // SGPRs, so the table reads are scalar loads.
-template <bool FAST>
-__device__ __forceinline__ void adam_replay(float& w, float& m, float& v, int from, int to, const AdamConsts& c,
+template <bool FAST, int N>
+__device__ __forceinline__ void adam_replay(float (&w)[N], float (&m)[N], float (&v)[N], int from, int to, const AdamConsts& c,
                                             const cdc_adam_hp& hp) {
     const int last_i = hp.n_scalars - 1;
     const float ss_conv = hp.step_scalars[2 * last_i];
     const float bc_conv = FAST ? hp.inv_bc2[last_i] : hp.step_scalars[2 * last_i + 1];
     const int from0 = __builtin_amdgcn_readfirstlane(from);
-    if (__all(from == from0)) {
-        for (int s = from0 + 1; s <= to; ++s) {             // s, ss, bc are wave-uniform
-            float ss = ss_conv, bc = bc_conv;
-            if (s < last_i) {
-                ss = hp.step_scalars[2 * s];
-                bc = FAST ? hp.inv_bc2[s] : hp.step_scalars[2 * s + 1];
-            }
-            if (FAST) adam_elem_fast(w, m, v, c, ss, bc);
-            else adam_elem(w, m, v, 0.f, c, ss, bc);
-        }
-        return;
-    }
-    for (int s = from + 1; s <= to; ++s) {
+    const bool uniform = __all(from == from0);
+    for (int s = (uniform ? from0 : from) + 1; s <= to; ++s) {      // uniform: s, ss, bc live in SGPRs
         float ss = ss_conv, bc = bc_conv;
         if (s < last_i) {
             ss = hp.step_scalars[2 * s];
             bc = FAST ? hp.inv_bc2[s] : hp.step_scalars[2 * s + 1];
         }
-        if (FAST) adam_elem_fast(w, m, v, c, ss, bc);
-        else adam_elem(w, m, v, 0.f, c, ss, bc);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (FAST) adam_elem_fast(w[k], m[k], v[k], c, ss, bc);
+            else adam_elem(w[k], m[k], v[k], 0.f, c, ss, bc);
+        }
     }
+}
+template <bool FAST>
+__device__ __forceinline__ void adam_replay(float& w, float& m, float& v, int from, int to, const AdamConsts& c,
+                                            const cdc_adam_hp& hp) {
+    float wa[1] = {w}, ma[1] = {m}, va[1] = {v};
+    adam_replay<FAST, 1>(wa, ma, va, from, to, c, hp);
+    w = wa[0]; m = ma[0]; v = va[0];
 }
 __device__ __forceinline__ AdamConsts make_consts(const cdc_adam_hp& hp) {
     AdamConsts c;

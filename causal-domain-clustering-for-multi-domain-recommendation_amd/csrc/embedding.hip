@@ -574,21 +574,37 @@ extern "C" int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_r
 
 // all rows -> step target = *step_dev + step_bias (only when target % period == 0).  Rows not looked up since the last
 // flush share one `last`, so whole waves replay the same steps: no divergence, coalesced float4 traffic.
-template <bool FAST>
+template <bool FAST, int VEC>
 __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                     const int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
                                                     const int32_t* __restrict__ step_dev, int32_t step_bias, int32_t period) {
     const int target = *step_dev + step_bias;
     if (period > 1 && (target % period) != 0) return;
     const AdamConsts c = make_consts(hp);
-    const int64_t total = R * D;
+    const int64_t total = R * D / VEC;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / D;
+        const int64_t e0 = i * VEC;
+        const int64_t row = e0 / D;
         const int from = last[row];
         if (from >= target) continue;
-        float wv = w[i], mv = m[i], vv = v[i];
-        adam_replay<FAST>(wv, mv, vv, from, target, c, hp);
-        w[i] = wv; m[i] = mv; v[i] = vv;
+        float wv[VEC], mv[VEC], vv[VEC];
+        if (VEC == 4) {
+            const float4 a4 = reinterpret_cast<const float4*>(w)[i], b4 = reinterpret_cast<const float4*>(m)[i],
+                         c4 = reinterpret_cast<const float4*>(v)[i];
+            wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
+            mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
+            vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
+        } else {
+            wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0];
+        }
+        adam_replay<FAST, VEC>(wv, mv, vv, from, target, c, hp);
+        if (VEC == 4) {
+            reinterpret_cast<float4*>(w)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            reinterpret_cast<float4*>(m)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+            w[e0] = wv[0]; m[e0] = mv[0]; v[e0] = vv[0];
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ last, int64_t R, const int32_t* __restrict__ step_dev,
@@ -606,11 +622,16 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
     CDC_CHECK_ARG(w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0, CDC_E_BADARG, "embed_lazy_flush: null pointer");
     CDC_CHECK_ARG(R > 0 && D > 0 && period >= 0, CDC_E_BADARG, "embed_lazy_flush: bad sizes");
     CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_flush: fast_replay needs the inv_bc2 table");
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div(R * D, 256), 256 * 16);
-    if (hp.fast_replay)
-        hipLaunchKernelGGL(k_lazy_flush<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, last, R, D, hp, step_dev, step_bias, period);
-    else
-        hipLaunchKernelGGL(k_lazy_flush<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, m, v, last, R, D, hp, step_dev, step_bias, period);
+    const bool vec = (D % 4 == 0) && ((((uintptr_t)w | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(R * D / (vec ? 4 : 1), 256), 256 * 16);
+    hipStream_t st = (hipStream_t)stream;
+    if (hp.fast_replay) {
+        if (vec) hipLaunchKernelGGL((k_lazy_flush<true, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period);
+        else     hipLaunchKernelGGL((k_lazy_flush<true, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_lazy_flush<false, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period);
+        else     hipLaunchKernelGGL((k_lazy_flush<false, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period);
+    }
     CDC_LAUNCH_CHECK("embed_lazy_flush");
     int blocks2 = (int)std::min<int64_t>(cdc_ceil_div(R, 256), 256 * 16);
     hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias, period);
