@@ -148,10 +148,21 @@ class TrainStep:
                 continue
             g = self._stage_graphs.get(i)
             if g is None:
+                # thread-local capture mode: the RCCL watchdog thread keeps querying events while we capture
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        for fn in fns:
+                            fn()
+                except Exception as e:  # noqa: BLE001  (capture refused: run this and every later segment eagerly)
+                    import warnings
+                    warnings.warn(f"hipGraph capture of launch segment {i} failed ({e}); continuing without graphs")
+                    torch.cuda.synchronize()
+                    self.use_graph = False
+                    self._stage_graphs.clear()
                     for fn in fns:
                         fn()
+                    continue
                 self._stage_graphs[i] = g
             g.replay()
         self._warm += 1
