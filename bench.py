@@ -126,10 +126,8 @@ def main():
     B = args.batch
     if args.pool <= 0:
         args.pool = max(8, min(args.warmup + args.steps, 1024))
-    n_rows = B * args.pool * world
-    X, y = make_dataset(n_rows, field_dims, n_domain=3, domain_idx=10, seed=2000, dist=args.id_dist)
-    lo = rank * B * args.pool
-    Xr, yr = X[lo:lo + B * args.pool], y[lo:lo + B * args.pool]
+    # every rank draws its own shard of the synthetic stream (same generator, rank-offset seed)
+    Xr, yr = make_dataset(B * args.pool, field_dims, n_domain=3, domain_idx=10, seed=2000 + rank, dist=args.id_dist)
     gr = Xr[:, 10].astype(np.int64)                            # identity domain -> tower map (3-domain PLE)
     Xd = torch.from_numpy(Xr).to(device).view(args.pool, B, -1)
     yd = torch.from_numpy(yr).to(device).view(args.pool, B)
