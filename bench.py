@@ -42,6 +42,14 @@ def parse():
     ap.add_argument("--id-dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--sync-bn", type=int, default=0,
+                    help="N>1: 1 = BatchNorm statistics over the global batch (bit-for-bit the single-process semantics of the "
+                         "concatenated batch, ~18 small all-reduces per step); 0 = per-rank statistics over the local 4096 rows "
+                         "(the population the reference's BatchNorm sees at its batch size)")
+    ap.add_argument("--table-dist", default=None, choices=["sharded", "replicated"], help="N>1: default sharded (lazy table)")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="diagnostic, single process: run ONE rank's launch work of a W-rank step with the collectives replaced "
+                         "by local copies (timing of the compute side only; the numbers it trains on are meaningless)")
     ap.add_argument("--pool", type=int, default=0,
                     help="resident synthetic batches cycled through; 0 = warmup+steps (max 1024), so that no batch repeats and "
                          "the lazy table replay sees realistic gaps between two look-ups of a row")
@@ -102,6 +110,36 @@ def cpu_baseline(args, model, field_dims, Xc, yc, gc):
                       f"({t * 1e3:.0f} ms/step)"}
 
 
+class Loopback:
+    """--simulate-world: the DataParallel interface with every collective a local copy."""
+
+    def __init__(self, world):
+        self.world_size, self.rank, self.backend = world, 0, "loopback"
+
+    def all_reduce_sum(self, t):
+        return t
+
+    all_reduce_max = all_reduce_sum
+
+    def all_to_all(self, out, inp):
+        if inp.dtype == torch.int32:     # row ids: fold them onto rows this rank owns, so that its rows see the look-up
+            w = self.world_size          # rate (and the ownership-filtered flush) of a real W-rank run
+            out.copy_(torch.where(inp >= 0, inp // w * w, inp))
+        else:
+            out.copy_(inp)
+        return out
+
+    def all_gather_rows(self, out, local):
+        out.view(self.world_size, *local.shape).copy_(local.unsqueeze(0).expand(self.world_size, *local.shape))
+        return out
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,6 +150,9 @@ def main():
     from cdcmdr_amd.synth import make_dataset
     from cdcmdr_amd.trainer import TrainStep
     dp = DataParallel() if world > 1 else None
+    sim = None
+    if args.simulate_world > 1 and world == 1:
+        sim = Loopback(args.simulate_world)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rank = int(os.environ.get("RANK", "0"))
     device = torch.device("cuda", local_rank)
@@ -121,7 +162,8 @@ def main():
     table_mode = args.table_mode
     use_graph = bool(args.graph)        # under DP the three launch stages between the collectives are graphs
     opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode)
-    ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dp)
+    ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dp or sim, sync_bn=bool(args.sync_bn),
+                   table_dist=args.table_dist)
 
     B = args.batch
     if args.pool <= 0:
@@ -165,6 +207,13 @@ def main():
         opt.flush_table()
         cpu = cpu_baseline(args, model, field_dims, Xc, yc, gc)
 
+    if sim is not None:
+        top = sorted(roof["breakdown_all"].items(), key=lambda kv: -kv[1])
+        print(json.dumps({"simulated_world": sim.world_size, "table_dist": ts.table_dist, "sync_bn": bool(args.sync_bn),
+                          "one_rank_compute_ms_per_step": elapsed / args.steps * 1e3,
+                          "kernel_ms_per_step_sum": roof["kernel_ms_per_step_sum"], "launch_ms_per_step": dict(top)}), flush=True)
+        return
+    roof.pop("breakdown_all", None)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
@@ -176,6 +225,8 @@ def main():
                                    f"{args.fields} fields x vocab {args.vocab}, emb_dim={args.embed_dim}, batch {B}/GPU",
                        "global_batch": B * world, "dropout": args.dropout, "table_mode": table_mode,
                        "hip_graph": use_graph, "id_dist": args.id_dist, "parallelism": f"dp{world}",
+                       "table_dist": ts.table_dist if world > 1 else None,
+                       "bn_stats": None if world == 1 else ("global batch (sync)" if args.sync_bn else "per rank"),
                        "last_bce_loss": loss_val},
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -193,6 +244,7 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
     top = sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])
     name, d = top[0]
     breakdown = {k: round(v["ms_per_step"], 4) for k, v in top[:8]}
+    breakdown_all = {k: round(v["ms_per_step"], 4) for k, v in top}
     per_launch_ms = d["ms_per_step"] / max(d["launches_per_step"], 1e-9)
     if d["flops_per_step"] > 0:
         achieved = d["flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12
@@ -204,7 +256,7 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
         roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": nbytes}
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": None,
-                 "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown})
+                 "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown, "breakdown_all": breakdown_all})
     # all MFMA launches together (north-star figure: expert GEMMs vs bf16 peak)
     gm = [v for k, v in prof.items() if "glinear" in k]
     if gm:

@@ -163,7 +163,7 @@ _SIGNATURES = {
     "cdc_abi_version": (c_i32, []),
     "cdc_last_error": (C.c_char_p, []),
     "cdc_embed_gather_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
-    "cdc_embed_index": (c_i32, [c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "cdc_embed_index": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i64, c_p]),
     "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_segment_sum": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
@@ -172,7 +172,11 @@ _SIGNATURES = {
     "cdc_embed_adam_patch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_catchup": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_update": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
-    "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_i32, c_p, c_i32, c_p]),
+    "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "cdc_embed_merge_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
+    "cdc_shard_bucket": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_p]),
+    "cdc_shard_expand": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "cdc_shard_pack": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p]),
     "cdc_glinear_fwd": (c_i32, [C.POINTER(LinFwdArgs), c_i32, c_p]),
     "cdc_glinear_bwd_x": (c_i32, [C.POINTER(LinBwdxArgs), c_i32, c_p]),
     "cdc_transpose_multi": (c_i32, [C.POINTER(TransposeArgs), c_p]),

@@ -23,8 +23,8 @@ __global__ void __launch_bounds__(256) k_gather_fwd(const int32_t* __restrict__ 
         const int f = (int)(pos % F);
         // model/layer.py:152 — the sum is formed in x's dtype (int32): wraps like torch's int32 add
         const int32_t row = (int32_t)((uint32_t)ids[pos] + (uint32_t)offsets[f]);
-        if (c == 0 && idx_out) idx_out[pos] = row;
         const bool ok = row >= 0 && (int64_t)row < R;
+        if (c == 0 && idx_out) idx_out[pos] = ok ? row : -1;    // -1: skipped by every kernel that walks row lists
         if (!ok && c == 0 && err_flag) atomicMax(err_flag, (int32_t)(pos < 0x7ffffffe ? pos + 1 : 0x7fffffff));
         if (VEC == 4) {
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -59,14 +59,20 @@ extern "C" int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, 
 
 // row indices only (the lazy table optimiser needs them BEFORE the gather to bring the rows up to date)
 __global__ void __launch_bounds__(256) k_embed_index(const int32_t* __restrict__ ids, const int32_t* __restrict__ offsets,
-                                                     int32_t* __restrict__ idx_out, int64_t n_pos, int32_t F) {
-    for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n_pos; pos += (int64_t)gridDim.x * blockDim.x)
-        idx_out[pos] = (int32_t)((uint32_t)ids[pos] + (uint32_t)offsets[pos % F]);
+                                                     int32_t* __restrict__ idx_out, int32_t* __restrict__ err_flag, int64_t n_pos,
+                                                     int32_t F, int64_t R) {
+    for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < n_pos; pos += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t row = (int32_t)((uint32_t)ids[pos] + (uint32_t)offsets[pos % F]);
+        const bool ok = row >= 0 && (int64_t)row < R;
+        if (!ok && err_flag) atomicMax(err_flag, (int32_t)(pos < 0x7ffffffe ? pos + 1 : 0x7fffffff));
+        idx_out[pos] = ok ? row : -1;
+    }
 }
-extern "C" int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out, int64_t B, int32_t F, void* stream) {
-    CDC_CHECK_ARG(ids && offsets && idx_out && B > 0 && F > 0, CDC_E_BADARG, "embed_index: bad argument");
+extern "C" int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out, int32_t* err_flag, int64_t B, int32_t F,
+                               int64_t R, void* stream) {
+    CDC_CHECK_ARG(ids && offsets && idx_out && B > 0 && F > 0 && R > 0, CDC_E_BADARG, "embed_index: bad argument");
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(B * F, 256), 4096);
-    hipLaunchKernelGGL(k_embed_index, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, idx_out, B * F, F);
+    hipLaunchKernelGGL(k_embed_index, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, idx_out, err_flag, B * F, F, R);
     CDC_LAUNCH_CHECK("embed_index");
     return 0;
 }
@@ -233,6 +239,43 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
     return 0;
 }
 
+// Same result as cdc_embed_sort_dedupe for a batch that already consists of n_runs runs of run_len rows, each ascending
+// per field (as unsigned: -1 padding last) — the row lists an owner receives from the ranks.  No sort: every key's final
+// position is the sum over the runs of the number of smaller keys (binary searches), then the usual dedupe.
+__global__ void __launch_bounds__(256) k_merge_n(const int32_t* __restrict__ idx, uint64_t* __restrict__ merged, int32_t B, int32_t F,
+                                                 int32_t n_runs, int32_t run_len) {
+    const int64_t total = (int64_t)F * B;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(t / B);
+        const int i = (int)(t - (int64_t)f * B);
+        const uint32_t row = (uint32_t)idx[(int64_t)i * F + f];
+        const int r = i / run_len;
+        int pos = i - r * run_len;
+        for (int q = 0; q < n_runs; ++q) {
+            if (q == r) continue;
+            const int32_t* col = idx + (int64_t)q * run_len * F + f;
+            int lo = 0, hi = run_len;
+            if (q < r) { while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)col[(int64_t)mid * F] <= row) lo = mid + 1; else hi = mid; } }
+            else       { while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)col[(int64_t)mid * F] <  row) lo = mid + 1; else hi = mid; } }
+            pos += lo;
+        }
+        merged[(int64_t)f * B + pos] = ((uint64_t)row << 32) | (uint32_t)i;
+    }
+}
+extern "C" int cdc_embed_merge_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm, int32_t* uniq_cnt,
+                                      uint64_t* scratch, int64_t B, int32_t F, int32_t n_runs, void* stream) {
+    CDC_CHECK_ARG(idx && uniq_row && seg_start && perm && uniq_cnt && scratch, CDC_E_BADARG, "embed_merge_dedupe: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && n_runs > 0 && B % n_runs == 0, CDC_E_BADARG, "embed_merge_dedupe: bad sizes");
+    CDC_CHECK_ARG(B <= CDC_SORT_MAX_ROWS, CDC_E_TOOBIG, "embed_merge_dedupe: B=%ld exceeds %d", (long)B, CDC_SORT_MAX_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 8192);
+    hipLaunchKernelGGL(k_merge_n, dim3(blocks), dim3(256), 0, st, idx, scratch, (int32_t)B, F, n_runs, (int32_t)(B / n_runs));
+    CDC_LAUNCH_CHECK("embed_merge_n");
+    hipLaunchKernelGGL(k_dedupe_merged, dim3(F), dim3(SORT_THREADS), 0, st, scratch, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F);
+    CDC_LAUNCH_CHECK("embed_dedupe_merged");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-row gradient: rowgrad[f, j, :] = sum over the segment of unique row j of d_out[b, f*D:(f+1)*D]
 // Two launches so that skewed fields (a domain column has a handful of rows, each thousands of entries long)
@@ -362,6 +405,7 @@ __global__ void __launch_bounds__(256) k_adam_touched(const float* __restrict__ 
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
         const int64_t row = uniq_row[slot];
+        if (row < 0) continue;
         float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
         adam_elem(wv, mv, vv, rowgrad[i], c, step_size, bc2s);
         float* s = side + slot * 3 * D;
@@ -446,6 +490,7 @@ __global__ void __launch_bounds__(256) k_adam_patch(const float* __restrict__ si
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
         const int64_t row = uniq_row[(int64_t)f * B + j];
+        if (row < 0) continue;
         const float* s = side + slot * 3 * D;
         w[row * D + d] = s[d];
         m[row * D + d] = s[D + d];
@@ -485,6 +530,7 @@ __global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict_
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
         const int64_t row = uniq_row[(int64_t)f * B + j];
+        if (row < 0) continue;                                   // padding entry of an exchanged row list
         const int from = last[row];
         if (from >= target) continue;
         float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
@@ -503,6 +549,7 @@ __global__ void __launch_bounds__(256) k_lazy_mark(const int32_t* __restrict__ u
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
         const int64_t row = uniq_row[slot];
+        if (row < 0) continue;
         if (last[row] < target) last[row] = target;
     }
 }
@@ -550,6 +597,7 @@ __global__ void __launch_bounds__(256) k_lazy_update(const float* __restrict__ r
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
         const int64_t row = uniq_row[slot];
+        if (row < 0) continue;
         float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
         adam_elem(wv, mv, vv, rowgrad[i], c, step_size, bc2s);
         w[row * D + d] = wv; m[row * D + d] = mv; v[row * D + d] = vv;
@@ -577,7 +625,8 @@ extern "C" int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_r
 template <bool FAST, int VEC>
 __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                     const int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
-                                                    const int32_t* __restrict__ step_dev, int32_t step_bias, int32_t period) {
+                                                    const int32_t* __restrict__ step_dev, int32_t step_bias, int32_t period,
+                                                    int32_t own_mod, int32_t own_rem) {
     const int target = *step_dev + step_bias;
     if (period > 1 && (target % period) != 0) return;
     const AdamConsts c = make_consts(hp);
@@ -585,6 +634,7 @@ __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e0 = i * VEC;
         const int64_t row = e0 / D;
+        if (own_mod > 1 && (row % own_mod) != own_rem) continue;   // row-sharded table: only the rows this rank owns
         const int from = last[row];
         if (from >= target) continue;
         float wv[VEC], mv[VEC], vv[VEC];
@@ -608,33 +658,197 @@ __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float
     }
 }
 __global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ last, int64_t R, const int32_t* __restrict__ step_dev,
-                                                       int32_t step_bias, int32_t period) {
+                                                       int32_t step_bias, int32_t period, int32_t own_mod, int32_t own_rem) {
     const int target = *step_dev + step_bias;
     if (period > 1 && (target % period) != 0) return;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
+        if (own_mod > 1 && (i % own_mod) != own_rem) continue;
         if (last[i] < target) last[i] = target;
+    }
 }
 
 extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D, cdc_adam_hp hp,
-                                    const int32_t* step_dev, int32_t step_bias, int32_t period, double* reg_ring, int32_t ring_len,
+                                    const int32_t* step_dev, int32_t step_bias, int32_t period, int32_t own_mod, int32_t own_rem,
                                     void* stream) {
-    (void)reg_ring; (void)ring_len;
     CDC_CHECK_ARG(w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0, CDC_E_BADARG, "embed_lazy_flush: null pointer");
-    CDC_CHECK_ARG(R > 0 && D > 0 && period >= 0, CDC_E_BADARG, "embed_lazy_flush: bad sizes");
+    CDC_CHECK_ARG(R > 0 && D > 0 && period >= 0 && own_mod >= 0 && (own_mod <= 1 || (own_rem >= 0 && own_rem < own_mod)), CDC_E_BADARG,
+                  "embed_lazy_flush: bad sizes");
     CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_flush: fast_replay needs the inv_bc2 table");
     const bool vec = (D % 4 == 0) && ((((uintptr_t)w | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(R * D / (vec ? 4 : 1), 256), 256 * 16);
     hipStream_t st = (hipStream_t)stream;
     if (hp.fast_replay) {
-        if (vec) hipLaunchKernelGGL((k_lazy_flush<true, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period);
-        else     hipLaunchKernelGGL((k_lazy_flush<true, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period);
+        if (vec) hipLaunchKernelGGL((k_lazy_flush<true, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
+        else     hipLaunchKernelGGL((k_lazy_flush<true, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
     } else {
-        if (vec) hipLaunchKernelGGL((k_lazy_flush<false, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period);
-        else     hipLaunchKernelGGL((k_lazy_flush<false, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period);
+        if (vec) hipLaunchKernelGGL((k_lazy_flush<false, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
+        else     hipLaunchKernelGGL((k_lazy_flush<false, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
     }
     CDC_LAUNCH_CHECK("embed_lazy_flush");
     int blocks2 = (int)std::min<int64_t>(cdc_ceil_div(R, 256), 256 * 16);
-    hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias, period);
+    hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias, period, own_mod, own_rem);
     CDC_LAUNCH_CHECK("embed_lazy_set_last");
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Row-sharded table under data parallelism (row r is owned by rank r % n_rank).  The per-field unique rows of the local
+// batch are bucketed by owner into fixed-capacity send lists [n_rank][cap][F] (row id, -1 = padding); slots are assigned
+// in ascending row order (the unique rows are already sorted), so the layout is deterministic.  After the all-to-all an
+// owner treats the received lists as a batch of n_rank*cap "rows" per field and reuses the sort / catch-up / segment-sum /
+// update kernels above unchanged.
+// ------------------------------------------------------------------------------------------------
+#define SHARD_MAX_RANKS 16
+__global__ void __launch_bounds__(SORT_THREADS) k_shard_bucket(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
+                                                               int32_t* __restrict__ send_ids, int32_t* __restrict__ slot_of,
+                                                               int32_t* __restrict__ overflow, int32_t B, int32_t F, int32_t n_rank,
+                                                               int32_t cap) {
+    __shared__ int32_t cnt[SHARD_MAX_RANKS][SORT_THREADS];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = uniq_cnt[f];
+    for (int o = 0; o < n_rank; ++o)
+        for (int s_ = tid; s_ < cap; s_ += SORT_THREADS) send_ids[((int64_t)o * cap + s_) * F + f] = -1;
+    const int per = (B + SORT_THREADS - 1) / SORT_THREADS;
+    const int begin = tid * per;
+    int local[SHARD_MAX_RANKS];
+#pragma unroll
+    for (int o = 0; o < SHARD_MAX_RANKS; ++o) local[o] = 0;
+    const int32_t* ur = uniq_row + (int64_t)f * B;
+    for (int j = begin; j < begin + per && j < n; ++j) {
+        const int32_t row = ur[j];
+        if (row < 0) continue;
+        const int o = row % n_rank;
+#pragma unroll
+        for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) local[k]++;
+    }
+    for (int o = 0; o < n_rank; ++o) {
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) v = local[k];
+        cnt[o][tid] = v;
+    }
+    __syncthreads();
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+        int add[SHARD_MAX_RANKS];
+        for (int o = 0; o < n_rank; ++o) add[o] = (tid >= off) ? cnt[o][tid - off] : 0;
+        __syncthreads();
+        for (int o = 0; o < n_rank; ++o) cnt[o][tid] += add[o];
+        __syncthreads();
+    }
+    int next[SHARD_MAX_RANKS];
+#pragma unroll
+    for (int k = 0; k < SHARD_MAX_RANKS; ++k) next[k] = 0;
+    for (int o = 0; o < n_rank; ++o) {
+        int lv = 0;
+#pragma unroll
+        for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) lv = local[k];
+        const int ex = cnt[o][tid] - lv;                           // exclusive prefix for this owner
+#pragma unroll
+        for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) next[k] = ex;
+    }
+    for (int j = begin; j < begin + per && j < n; ++j) {
+        const int32_t row = ur[j];
+        int slot = -1;
+        if (row >= 0) {
+            const int o = row % n_rank;
+#pragma unroll
+            for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) slot = next[k]++;
+            if (slot < cap) send_ids[((int64_t)o * cap + slot) * F + f] = row;
+            else { atomicMax(overflow, slot + 1); slot = -1; }
+        }
+        slot_of[(int64_t)f * B + j] = slot;
+    }
+}
+extern "C" int cdc_shard_bucket(const int32_t* uniq_row, const int32_t* uniq_cnt, int32_t* send_ids, int32_t* slot_of,
+                                int32_t* overflow, int64_t B, int32_t F, int32_t n_rank, int32_t cap, void* stream) {
+    CDC_CHECK_ARG(uniq_row && uniq_cnt && send_ids && slot_of && overflow && B > 0 && F > 0 && cap > 0 && n_rank > 0 &&
+                      n_rank <= SHARD_MAX_RANKS && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "shard_bucket: bad argument");
+    hipLaunchKernelGGL(k_shard_bucket, dim3(F), dim3(SORT_THREADS), 0, (hipStream_t)stream, uniq_row, uniq_cnt, send_ids, slot_of, overflow,
+                       (int32_t)B, F, n_rank, cap);
+    CDC_LAUNCH_CHECK("shard_bucket");
+    return 0;
+}
+
+// requester, forward: rows_recv [n_rank (owner)][cap][F][D] -> out[b, f*D:(f+1)*D] for every batch position of every unique row
+template <int VEC>
+__global__ void __launch_bounds__(256) k_shard_expand(const float* __restrict__ rows_recv, const int32_t* __restrict__ uniq_row,
+                                                      const int32_t* __restrict__ uniq_cnt, const int32_t* __restrict__ seg_start,
+                                                      const int32_t* __restrict__ perm, const int32_t* __restrict__ slot_of,
+                                                      float* __restrict__ out, int32_t B, int32_t F, int32_t D, int32_t n_rank,
+                                                      int32_t cap) {
+    // one thread per (sorted batch position, chunk of the row): the unique row a position belongs to is found by a
+    // binary search in the field's segment starts (a loop over a segment would serialise the few-distinct-values fields)
+    const int chunks = D / VEC;
+    const int64_t total = (int64_t)F * B * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const int64_t fk = i / chunks;
+        const int f = (int)(fk / B);
+        const int k = (int)(fk - (int64_t)f * B);
+        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+        int lo = 0, hi = uniq_cnt[f];                              // largest j with sst[j] <= k
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (sst[mid] <= k) lo = mid; else hi = mid;
+        }
+        const int64_t slotj = (int64_t)f * B + lo;
+        const int32_t row = uniq_row[slotj];
+        const int s_ = slot_of[slotj];
+        const bool ok = row >= 0 && s_ >= 0;
+        const int64_t src = ok ? ((((int64_t)(row % n_rank)) * cap + s_) * F + f) * D + c * VEC : 0;
+        const int64_t dst = ((int64_t)perm[fk] * F + f) * D + c * VEC;
+        if (VEC == 4) {
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) val = *reinterpret_cast<const float4*>(rows_recv + src);
+            *reinterpret_cast<float4*>(out + dst) = val;
+        } else {
+            out[dst] = ok ? rows_recv[src] : 0.f;
+        }
+    }
+}
+extern "C" int cdc_shard_expand(const float* rows_recv, const int32_t* uniq_row, const int32_t* uniq_cnt, const int32_t* seg_start,
+                                const int32_t* perm, const int32_t* slot_of, float* out, int64_t B, int32_t F, int32_t D,
+                                int32_t n_rank, int32_t cap, void* stream) {
+    CDC_CHECK_ARG(rows_recv && uniq_row && uniq_cnt && seg_start && perm && slot_of && out && B > 0 && F > 0 && D > 0 && cap > 0 &&
+                      n_rank > 0, CDC_E_BADARG, "shard_expand: bad argument");
+    const bool vec = (D % 4 == 0) && (((uintptr_t)rows_recv | (uintptr_t)out) % 16 == 0);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
+    if (vec)
+        hipLaunchKernelGGL(k_shard_expand<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows_recv, uniq_row, uniq_cnt, seg_start,
+                           perm, slot_of, out, (int32_t)B, F, D, n_rank, cap);
+    else
+        hipLaunchKernelGGL(k_shard_expand<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows_recv, uniq_row, uniq_cnt, seg_start,
+                           perm, slot_of, out, (int32_t)B, F, D, n_rank, cap);
+    CDC_LAUNCH_CHECK("shard_expand");
+    return 0;
+}
+
+// requester, backward: rowgrad [F][B][D] (per unique row) -> send_grads [n_rank (owner)][cap][F][D]
+__global__ void __launch_bounds__(256) k_shard_pack(const float* __restrict__ rowgrad, const int32_t* __restrict__ uniq_row,
+                                                    const int32_t* __restrict__ uniq_cnt, const int32_t* __restrict__ slot_of,
+                                                    float* __restrict__ send, int32_t B, int32_t F, int32_t D, int32_t n_rank,
+                                                    int32_t cap) {
+    const int64_t total = (int64_t)F * B * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D);
+        const int64_t slotj = i / D;
+        const int f = (int)(slotj / B);
+        const int j = (int)(slotj - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        const int32_t row = uniq_row[slotj];
+        const int s_ = slot_of[slotj];
+        if (row < 0 || s_ < 0) continue;
+        send[((((int64_t)(row % n_rank)) * cap + s_) * F + f) * D + d] = rowgrad[i];
+    }
+}
+extern "C" int cdc_shard_pack(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt, const int32_t* slot_of,
+                              float* send, int64_t B, int32_t F, int32_t D, int32_t n_rank, int32_t cap, void* stream) {
+    CDC_CHECK_ARG(rowgrad && uniq_row && uniq_cnt && slot_of && send && B > 0 && F > 0 && D > 0 && cap > 0 && n_rank > 0, CDC_E_BADARG,
+                  "shard_pack: bad argument");
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * D, 256), 8192);
+    hipLaunchKernelGGL(k_shard_pack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, slot_of, send,
+                       (int32_t)B, F, D, n_rank, cap);
+    CDC_LAUNCH_CHECK("shard_pack");
     return 0;
 }

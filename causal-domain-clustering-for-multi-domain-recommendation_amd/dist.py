@@ -4,8 +4,11 @@
 The reference has no multi-device code at all; the exchange pattern is this build's:
   * samples shard across ranks (global batch = world_size x local batch, BCE mean over the GLOBAL batch);
   * dense gradients: ONE sum all-reduce of the flat gradient arena per step;
-  * embedding table (replicated): all-gather of the (row index, row gradient) pairs, then every rank applies the
-    identical table update — no divergence, no table broadcast.
+  * embedding table, "sharded" (default with the lazy table optimiser): row r is owned by rank r % world_size; per step
+    three equal-split all-to-alls move (row ids -> owners), (rows -> requesters), (row gradients -> owners); the owner
+    alone replays / updates its rows.  Per-rank table work and traffic are those of the LOCAL batch, whatever the world size;
+  * embedding table, "replicated": all-gather of the (row index, row gradient) pairs, then every rank applies the
+    identical table update — no divergence, no table broadcast, but table work grows with the global batch.
 """
 import os
 
@@ -69,6 +72,20 @@ class DataParallel:
                 dist.all_gather_into_tensor(out, local.contiguous())
         else:
             out.copy_(local)
+        return out
+
+    def all_to_all(self, out, inp):
+        """equal-split exchange along dim 0: chunk r of `inp` goes to rank r; chunk r of `out` came from rank r."""
+        if self.world_size > 1:
+            if self._staged(out):
+                h_in = inp.detach().cpu().contiguous()
+                h_out = torch.empty_like(h_in)
+                dist.all_to_all_single(h_out, h_in)
+                out.copy_(h_out)
+            else:
+                dist.all_to_all_single(out, inp)
+        else:
+            out.copy_(inp)
         return out
 
     def barrier(self):

@@ -78,6 +78,7 @@ class FusedAdam:
         self.table_m = torch.zeros_like(self.table.data)
         self.table_v = torch.zeros_like(self.table.data)
         self.table_last = torch.zeros(self.table.shape[0], dtype=torch.int32, device=dev) if table_mode == "lazy" else None
+        self.own_mod, self.own_rem = 0, 0     # row-sharded table (trainer sets them): this rank maintains rows r % own_mod == own_rem
         self._dense_args = None
         self._dense_sig = None
         self._ws = {}
@@ -100,8 +101,8 @@ class FusedAdam:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def _workspace(self, B, F, D):
-        key = (B, F, D)
+    def _workspace(self, B, F, D, tag=""):
+        key = (B, F, D, tag)
         ws = self._ws.get(key)
         if ws is None:
             dev = self.device
@@ -122,26 +123,37 @@ class FusedAdam:
         s = self._stream()
         L.launch("cdc_begin_step", self.lib.cdc_begin_step, (self.step_dev.data_ptr(), self.reg_sum.data_ptr(), 2), s)
 
-    def sort_rows(self, idx, B, F, D):
-        ws = self._workspace(B, F, D)
+    def sort_rows(self, idx, B, F, D, tag="", runs=0):
+        """runs > 0: idx consists of `runs` runs that are already ascending per field (an owner's received row lists)."""
+        ws = self._workspace(B, F, D, tag)
+        if runs > 0:
+            if ws.get("merge") is None:
+                ws["merge"] = torch.empty((F * B,), dtype=torch.int64, device=self.device)
+            L.launch("cdc_embed_merge_dedupe", self.lib.cdc_embed_merge_dedupe,
+                     (idx.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(),
+                      ws["merge"].data_ptr(), B, F, runs), self._stream())
+            return ws
         L.launch("cdc_embed_sort_dedupe", self.lib.cdc_embed_sort_dedupe,
                  (idx.data_ptr(), ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(),
                   None if ws["scratch"] is None else ws["scratch"].data_ptr(), B, F), self._stream())
         return ws
 
-    def table_index(self, ids, offsets, idx, B, F):
-        """row indices of the local batch (needed before the gather in lazy mode, and for the all-gather under DP)."""
-        L.launch("cdc_embed_index", self.lib.cdc_embed_index, (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), B, F), self._stream())
+    def table_index(self, ids, offsets, idx, B, F, err=None):
+        """row indices of the local batch (needed before the gather in lazy mode, and for the exchanges under DP)."""
+        L.launch("cdc_embed_index", self.lib.cdc_embed_index,
+                 (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), None if err is None else err.data_ptr(), B, F,
+                  self.table.shape[0]), self._stream())
 
-    def table_catchup_rows(self, idx, B, F, D):
+    def table_catchup_rows(self, idx, B, F, D, tag="", runs=0):
         """lazy mode, BEFORE the gather of this step, on already computed row indices [B,F] (the gathered batch under DP)."""
         assert self.table_mode == "lazy"
         s = self._stream()
         if self.flush_every > 1:
             L.launch("cdc_embed_lazy_flush(periodic)", self.lib.cdc_embed_lazy_flush,
                      (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every, None, 0), s)
-        ws = self.sort_rows(idx, B, F, D)
+                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every,
+                      self.own_mod, self.own_rem), s)
+        ws = self.sort_rows(idx, B, F, D, tag, runs)
         L.launch("cdc_embed_lazy_catchup", self.lib.cdc_embed_lazy_catchup,
                  (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(), self.table_m.data_ptr(),
                   self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D), s)
@@ -154,14 +166,16 @@ class FusedAdam:
             # every `flush_every` steps the whole table is brought to step t-1 (device-side decision: graph-replay safe)
             L.launch("cdc_embed_lazy_flush(periodic)", self.lib.cdc_embed_lazy_flush,
                      (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every, None, 0), s)
-        L.launch("cdc_embed_index", self.lib.cdc_embed_index, (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), B, F), s)
+                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every,
+                      self.own_mod, self.own_rem), s)
+        L.launch("cdc_embed_index", self.lib.cdc_embed_index,
+                 (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), None, B, F, self.table.shape[0]), s)
         ws = self.sort_rows(idx, B, F, D)
         L.launch("cdc_embed_lazy_catchup", self.lib.cdc_embed_lazy_catchup,
                  (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(), self.table_m.data_ptr(),
                   self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D), s)
 
-    def table_step(self, idx, d_out, B, F, D):
+    def table_step(self, idx, d_out, B, F, D, tag=""):
         """Adam step t on the table from the batch's row indices [B,F] and the gradient of the gathered rows [B,F*D]."""
         s = self._stream()
         hp = self._hp()
@@ -178,7 +192,7 @@ class FusedAdam:
             L.launch("cdc_embed_adam_patch", self.lib.cdc_embed_adam_patch,
                      (ws["side"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), w, m, v, B, F, D), s)
         else:
-            ws = self._workspace(B, F, D)        # rows were sorted by table_catchup of this step
+            ws = self._workspace(B, F, D, tag)   # rows were sorted by table_catchup of this step
             self._segment_sum(ws, d_out, B, F, D, s)
             L.launch("cdc_embed_lazy_update", self.lib.cdc_embed_lazy_update,
                      (ws["rowgrad"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(),
@@ -195,8 +209,8 @@ class FusedAdam:
             return
         L.launch("cdc_embed_lazy_flush", self.lib.cdc_embed_lazy_flush,
                  (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-                  self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), 0, 0, None, 0), self._stream(),
-                 nbytes=24.0 * self.table.numel())
+                  self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), 0, 0, self.own_mod, self.own_rem),
+                 self._stream(), nbytes=24.0 * self.table.numel())
 
     # ------------------------------------------------------------------------------------------
     def dense_step(self, param_grads, param_refs):

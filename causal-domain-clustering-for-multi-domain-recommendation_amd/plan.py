@@ -384,9 +384,9 @@ class EmbedGather:
 
     def build_fwd(self, plan):
         R = self.table.shape[0]
-        plan.fwd_steps.append(plan.call("cdc_embed_gather_fwd", _p(self.ids), _p(self.offsets), _p(self.table.data),
-                                        self.out.cptr(), _p(self.idx), _p(self.err), C.c_int64(plan.B), self.F, self.D,
-                                        C.c_int64(R)))
+        self.fwd_step = plan.call("cdc_embed_gather_fwd", _p(self.ids), _p(self.offsets), _p(self.table.data),
+                                  self.out.cptr(), _p(self.idx), _p(self.err), C.c_int64(plan.B), self.F, self.D, C.c_int64(R))
+        plan.fwd_steps.append(self.fwd_step)     # (a row-sharded trainer replaces this launch by its exchange)
 
     def build_bwd(self, plan, gs):
         # the gradient w.r.t. the gathered rows stays in self.out.grad; the table optimiser (optim.py) or the

@@ -22,9 +22,13 @@ class TrainStep:
          "single"  DCN / DCNv2: pred = model(X)                                                   (run.py:486-488)
     """
 
-    def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None, sync_bn=True):
+    def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None, sync_bn=True,
+                 table_dist=None, shard_slack=1.5):
         """sync_bn (data parallel only): BatchNorm statistics over the GLOBAL batch, as the reference's single process
-        computes them — two small all-reduces per BatchNorm launch; False = per-rank statistics."""
+        computes them — two small all-reduces per BatchNorm launch; False = per-rank statistics.
+        table_dist (data parallel only): "sharded" (row r owned by rank r % world; default with the lazy table optimiser)
+        or "replicated" (every rank applies the global batch's table update).  shard_slack: capacity of the per-owner,
+        per-field row lists as a multiple of the even share B/world (an overflow raises in check_ids())."""
         self.model, self.opt, self.B, self.mode = model, optimizer, int(batch_size), mode
         self.lib = L.load()
         self.dist = dist
@@ -47,10 +51,33 @@ class TrainStep:
         self._stage_graphs = {}
         self._dp_seq = None
         self._warm = 0
-        if self.world > 1:
+        if table_dist is None:
+            table_dist = "sharded" if optimizer.table_mode == "lazy" else "replicated"
+        assert table_dist in ("sharded", "replicated")
+        self.table_dist = table_dist if self.world > 1 else "replicated"
+        if self.world > 1 and self.table_dist == "replicated":
             F, D = self.emb.F, self.emb.D
             self.idx_all = torch.empty((self.global_B, F), dtype=torch.int32, device=dev)
             self.dE_all = torch.empty((self.global_B, F * D), dtype=torch.float32, device=dev)
+        if self.world > 1 and self.table_dist == "sharded":
+            if optimizer.table_mode != "lazy":
+                raise ValueError("the row-sharded table needs table_mode='lazy'")
+            F, D, N = self.emb.F, self.emb.D, self.world
+            cap = min(self.B, int(-(-self.B // N) * float(shard_slack)) + 16)
+            if N * cap > L.SORT_MAX_ROWS:
+                raise ValueError(f"world {N} x list capacity {cap} exceeds the per-field sort limit {L.SORT_MAX_ROWS}")
+            self.cap, self.Bv = cap, N * cap                          # Bv: rows of the owner-side batch
+            z = dict(device=dev)
+            self.send_ids = torch.full((N, cap, F), -1, dtype=torch.int32, **z)
+            self.recv_ids = torch.full((N, cap, F), -1, dtype=torch.int32, **z)
+            self.slot_of = torch.zeros((F, self.B), dtype=torch.int32, **z)
+            self.overflow = torch.zeros(1, dtype=torch.int32, **z)
+            self.rows_send = torch.zeros((N, cap, F * D), dtype=torch.float32, **z)
+            self.rows_recv = torch.zeros((N, cap, F * D), dtype=torch.float32, **z)
+            self.grads_send = torch.zeros((N, cap, F * D), dtype=torch.float32, **z)
+            self.grads_recv = torch.zeros((N, cap, F * D), dtype=torch.float32, **z)
+            self.zero_offsets = torch.zeros(F, dtype=torch.int32, **z)
+            optimizer.own_mod, optimizer.own_rem = N, dist.rank
 
     def _build_plan(self):
         model, opt = self.model, self.opt
@@ -138,9 +165,95 @@ class TrainStep:
                 merged.append((is_comm, [fn]))
         return merged
 
+    def _dp_sequence_sharded(self):
+        """Row-sharded table: [(is_comm, [fn...])].  Per step and rank the table work is that of the LOCAL batch:
+            sort local rows -> bucket by owner | a2a ids | owner: periodic flush of its rows, sort, catch-up, gather |
+            a2a rows | expand, forward, BCE, backward, per-row gradient sums, pack | all-reduce arena, a2a grads |
+            owner: per-row sums over the senders, Adam update of its rows; dense Adam."""
+        opt, plan, emb, dp = self.opt, self.plan, self.emb, self.dist
+        B, F, D, N, cap, Bv = self.B, emb.F, emb.D, self.world, self.cap, self.Bv
+        lib = self.lib
+
+        def st():
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def stage0():
+            opt.begin_step()
+            opt.table_index(emb.ids, emb.offsets, emb.idx, B, F, err=emb.err)
+            ws = opt.sort_rows(emb.idx, B, F, D, "local")
+            L.launch("cdc_shard_bucket", lib.cdc_shard_bucket,
+                     (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.send_ids.data_ptr(), self.slot_of.data_ptr(),
+                      self.overflow.data_ptr(), B, F, N, cap), st())
+
+        def serve():
+            opt.table_catchup_rows(self.recv_ids, Bv, F, D, "owner", runs=N)      # each sender's list is already sorted
+            L.launch("cdc_embed_gather_fwd(owner)", lib.cdc_embed_gather_fwd,
+                     (self.recv_ids.data_ptr(), self.zero_offsets.data_ptr(), opt.table.data_ptr(), self.rows_send.data_ptr(),
+                      None, None, Bv, F, D, opt.table.shape[0]), st())
+
+        def expand():
+            ws = opt._workspace(B, F, D, "local")
+            L.launch("cdc_shard_expand", lib.cdc_shard_expand,
+                     (self.rows_recv.data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), ws["seg"].data_ptr(),
+                      ws["perm"].data_ptr(), self.slot_of.data_ptr(), emb.out.ptr, B, F, D, N, cap), st())
+
+        def pack():
+            ws = opt._workspace(B, F, D, "local")
+            opt._segment_sum(ws, emb.out.grad.root, B, F, D, st())
+            L.launch("cdc_shard_pack", lib.cdc_shard_pack,
+                     (ws["rowgrad"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.slot_of.data_ptr(),
+                      self.grads_send.data_ptr(), B, F, D, N, cap), st())
+
+        def exchange():
+            dp.all_to_all(self.grads_recv, self.grads_send)
+            dp.all_reduce_sum(opt.grad_arena[:max(plan._arena_used, 1)])
+            dp.all_reduce_sum(self.loss)
+
+        def update():
+            opt.table_step(self.recv_ids, self.grads_recv, Bv, F, D, "owner")
+            opt.dense_step(plan.param_grads, plan._param_refs)
+
+        def run_steps(steps):
+            def fn():
+                s_ = st()
+                for step in steps:
+                    step(s_)
+            return fn
+
+        seq = [(False, stage0), (True, lambda: dp.all_to_all(self.recv_ids, self.send_ids)), (False, serve),
+               (True, lambda: dp.all_to_all(self.rows_recv, self.rows_send)), (False, expand)]
+        fwd = [s_ for s_ in plan.fwd_steps if s_ is not emb.fwd_step]
+        for is_comm, steps in plan.segments(fwd):
+            seq.append((is_comm, run_steps(steps)))
+        seq.append((False, self._bce))
+        for is_comm, steps in plan.segments(plan.bwd_steps):
+            seq.append((is_comm, run_steps(steps)))
+        seq += [(False, pack), (True, exchange), (False, update)]
+        merged = []
+        for is_comm, fn in seq:
+            if merged and not is_comm and not merged[-1][0]:
+                merged[-1][1].append(fn)
+            else:
+                merged.append((is_comm, [fn]))
+        return merged
+
+    def gather_table(self):
+        """Row-sharded table: bring every owner's rows up to date and give every rank the whole table (and its Adam
+        moments) — before state_dict(), evaluation, or a switch to another trainer.  Host-synchronising collectives."""
+        opt = self.opt
+        opt.flush_table()
+        if self.world == 1 or self.table_dist != "sharded":
+            return
+        R = opt.table.shape[0]
+        own = (torch.arange(R, device=self.device) % self.world == self.dist.rank).to(torch.float32).unsqueeze(1)
+        for t in (opt.table.data, opt.table_m, opt.table_v):
+            t.mul_(own)                                   # x + 0 + ... + 0 is exact: the all-reduce is a row broadcast
+            self.dist.all_reduce_sum(t)
+        opt.table_last.fill_(int(opt.step_dev.item()))
+
     def _step_dp(self):
         if self._dp_seq is None:
-            self._dp_seq = self._dp_sequence()
+            self._dp_seq = self._dp_sequence_sharded() if self.table_dist == "sharded" else self._dp_sequence()
         for i, (is_comm, fns) in enumerate(self._dp_seq):
             if is_comm or not (self.use_graph and self._warm >= 2):
                 for fn in fns:
@@ -221,3 +334,9 @@ class TrainStep:
         if bad:
             self.emb.err.zero_()
             raise IndexError(f"index out of range in self (flat position {bad - 1})")
+        if self.world > 1 and self.table_dist == "sharded":
+            over = int(self.overflow.item())
+            if over:
+                self.overflow.zero_()
+                raise RuntimeError(f"row-sharded table: a per-owner row list needed {over} slots but holds {self.cap}; "
+                                   f"raise shard_slack (rows beyond the capacity were dropped from that step)")

@@ -59,7 +59,8 @@ int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, const float
                          int64_t B, int32_t F, int32_t D, int64_t R, void* stream);
 
 /* model/layer.py:152 alone: idx_out[b,f] = ids[b,f] + offsets[f] (int32, wrapping). */
-int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out, int64_t B, int32_t F, void* stream);
+int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out, int32_t* err_flag, int64_t B, int32_t F,
+                    int64_t R, void* stream);   /* out-of-range ids: idx_out = -1 (+ err_flag), skipped downstream */
 
 /* Per-field sort + dedupe of the row indices of one batch (rows of different fields never collide, so each field is
  * sorted on its own).  B <= CDC_SORT_MAX_B: one workgroup per field sorts (row<<32|b) in LDS.  B <= CDC_SORT_MAX_ROWS
@@ -136,7 +137,27 @@ int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_row, const i
  * gaps the per-batch catch-up sees and runs divergence-free; decided on the device, so it sits in a replayed graph). */
 int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D,
                          cdc_adam_hp hp, const int32_t* step_dev, int32_t step_bias, int32_t period,
-                         double* reg_ring, int32_t ring_len, void* stream);
+                         int32_t own_mod, int32_t own_rem, void* stream);   /* own_mod > 1: only rows r with r % own_mod == own_rem */
+
+/* Row-sharded table under data parallelism (no counterpart in the reference, which is single-process): row r belongs to
+ * rank r % n_rank.  Every kernel that walks unique-row lists skips entries < 0, so an owner can treat the row lists it
+ * receives (padded with -1) as a batch and reuse sort / catch-up / segment-sum / update unchanged.
+ *   bucket: unique rows of the local batch [F,B] -> send_ids [n_rank][cap][F] (row id or -1), slot_of [F,B]; slots in
+ *           ascending row order (deterministic); *overflow (device int32) = max slot+1 that did not fit (0 = fine)
+ *   expand: rows received from the owners [n_rank][cap][F][D] -> gathered embeddings out [B, F*D]
+ *   pack:   per-unique-row gradients [F][B][D] -> send_grads [n_rank][cap][F][D]
+ * (the wire layout [sender][cap][F] read as [n_rank*cap, F] IS the owner's batch: no repacking on either side) */
+/* sort_dedupe for a batch made of n_runs runs of B/n_runs rows, each already ascending per field (as unsigned, -1 last):
+ * merge by rank + dedupe, no sort.  scratch: F*B uint64. */
+int cdc_embed_merge_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm, int32_t* uniq_cnt,
+                           uint64_t* scratch, int64_t B, int32_t F, int32_t n_runs, void* stream);
+int cdc_shard_bucket(const int32_t* uniq_row, const int32_t* uniq_cnt, int32_t* send_ids, int32_t* slot_of, int32_t* overflow,
+                     int64_t B, int32_t F, int32_t n_rank, int32_t cap, void* stream);
+int cdc_shard_expand(const float* rows_recv, const int32_t* uniq_row, const int32_t* uniq_cnt, const int32_t* seg_start,
+                     const int32_t* perm, const int32_t* slot_of, float* out, int64_t B, int32_t F, int32_t D,
+                     int32_t n_rank, int32_t cap, void* stream);
+int cdc_shard_pack(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt, const int32_t* slot_of, float* send,
+                   int64_t B, int32_t F, int32_t D, int32_t n_rank, int32_t cap, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Grouped linear layers on MFMA (reference: every nn.Linear on the path —

@@ -1,7 +1,8 @@
 """The data-parallel training step on the HIP path with two ranks sharing the one GPU of the test box (collectives go
 through gloo with host staging here; on a multi-GPU node the same DataParallel calls are RCCL).  Checks (1) that the
 replicas stay bit-identical (every rank applies the same table and dense updates from the exchanged global batch) in
-both table modes and with the launch segments replayed as graphs, and (2) SURVEY.md §8e's parity definition: the 2-rank
+both table modes, with the table replicated or row-sharded (ids / rows / row gradients exchanged with the owning rank by
+all-to-all), and with the launch segments replayed as graphs, and (2) SURVEY.md §8e's parity definition: the 2-rank
 step on shards == the 1-rank step on the concatenated batch (global-batch BatchNorm statistics, global-batch BCE mean)."""
 import os
 import socket
@@ -57,7 +58,7 @@ def _single_process_reference(table_mode):
     return {k: v.cpu() for k, v in model.state_dict().items()}, losses
 
 
-def _worker(rank, world, port, out_dir, table_mode, use_graph):
+def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     sys.path.insert(0, ROOT)
     from cdcmdr_amd.dist import DataParallel
@@ -69,7 +70,8 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph):
     torch.manual_seed(5)
     model = MMoE(FD, 8, 3, 4, (32, 16), (8,), dropout=0.0).to(dev).set_precision("f32")
     opt = FusedAdam(model, table_mode=table_mode, flush_every=2)
-    ts = TrainStep(model, opt, B_LOCAL, use_graph=use_graph, dist=dp)
+    ts = TrainStep(model, opt, B_LOCAL, use_graph=use_graph, dist=dp, table_dist=table_dist)
+    assert ts.table_dist == (table_dist or ("sharded" if table_mode == "lazy" else "replicated"))
     X, y, g = _data(world)
     gb = B_LOCAL * world
     losses = []
@@ -78,17 +80,20 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph):
         sl = slice(lo, lo + B_LOCAL)
         bce, _ = ts.step(torch.from_numpy(X[sl]).to(dev), torch.from_numpy(y[sl]).to(dev), torch.from_numpy(g[sl]).to(dev))
         losses.append(float(bce.item()))
-    opt.flush_table()
+    ts.check_ids()
+    ts.gather_table()                 # flush + (row-sharded table) every owner's rows to every rank
     torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "m": opt.table_m.cpu(), "losses": losses},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dp.barrier()
     dp.close()
 
 
-@pytest.mark.parametrize("table_mode,use_graph", [("dense", False), ("lazy", False), ("lazy", True)])
-def test_two_ranks_stay_identical(cuda, tmp_path, table_mode, use_graph):
+@pytest.mark.parametrize("table_mode,use_graph,table_dist", [("dense", False, None), ("lazy", False, "replicated"),
+                                                             ("lazy", True, "replicated"), ("lazy", False, "sharded"),
+                                                             ("lazy", True, "sharded")])
+def test_two_ranks_stay_identical(cuda, tmp_path, table_mode, use_graph, table_dist):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), table_mode, use_graph), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), table_mode, use_graph, table_dist), nprocs=world, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
     assert r0["losses"] == r1["losses"]                              # the all-reduced global-batch loss

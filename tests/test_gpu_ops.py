@@ -327,3 +327,106 @@ def test_sort_dedupe_against_numpy(cuda, B):
         n = len(rows)
         assert cnt[f] == n and np.array_equal(uniq[f, :n], rows)
         assert np.array_equal(seg[f, :n], starts) and seg[f, n] == B
+
+
+@pytest.mark.parametrize("B,N,cap", [(64, 2, 64), (4096, 8, 832), (1000, 3, 400), (512, 4, 20)])
+def test_shard_bucket_expand_pack(cuda, B, N, cap):
+    """Row-sharded table exchange helpers (include/cdcmdr.h cdc_shard_*): bucket the unique rows of a batch by owner
+    (row % N) into [N][cap][F] lists, expand the rows the owners return into the gathered batch, pack per-row gradients
+    for the way back.  Integer/copy work: bit-exact against numpy; ids < 0 (out of range upstream) are skipped."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    F, D = 5, 8
+    rng = np.random.default_rng(B + N)
+    vocab = [3, 50, 1000, 100000, 7]
+    idx = np.stack([rng.integers(0, v, size=B) + 1000 * f for f, v in enumerate(vocab)], axis=1).astype(np.int32)
+    idx[rng.integers(0, B, size=3), 2] = -1                              # what cdc_embed_index writes for a bad id
+    d_idx = torch.from_numpy(idx).to(cuda)
+    uniq = torch.full((F, B), -7, dtype=torch.int32, device=cuda)
+    seg = torch.zeros((F, B + 1), dtype=torch.int32, device=cuda)
+    perm = torch.zeros((F, B), dtype=torch.int32, device=cuda)
+    cnt = torch.zeros(F, dtype=torch.int32, device=cuda)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.cdc_embed_sort_dedupe(d_idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(), None, B, F, s), "sort")
+    send = torch.full((N, cap, F), -5, dtype=torch.int32, device=cuda)
+    slot_of = torch.full((F, B), -9, dtype=torch.int32, device=cuda)
+    over = torch.zeros(1, dtype=torch.int32, device=cuda)
+    L.check(lib.cdc_shard_bucket(uniq.data_ptr(), cnt.data_ptr(), send.data_ptr(), slot_of.data_ptr(), over.data_ptr(), B, F, N, cap, s), "bucket")
+    send_h, slot_h, over_h = send.cpu().numpy(), slot_of.cpu().numpy(), int(over.item())
+    want_over = 0
+    for f in range(F):
+        rows = np.unique(idx[:, f])
+        rows = rows[rows >= 0]
+        for o in range(N):
+            mine = rows[rows % N == o]                                   # ascending
+            kept = mine[:cap]
+            if len(mine) > cap:
+                want_over = max(want_over, len(mine))
+            got = send_h[o, :, f]
+            assert np.array_equal(got[:len(kept)], kept) and np.all(got[len(kept):] == -1)
+    assert over_h == want_over
+    if want_over:
+        return
+    # owners answer with a function of the row id; the expansion must equal a plain gather of that "table"
+    def row_vec(rows):
+        return (rows[..., None].astype(np.float32) * 0.5 + np.arange(D, dtype=np.float32)) * (rows[..., None] >= 0)
+    rows_recv = torch.from_numpy(row_vec(send_h.astype(np.int64))).to(cuda).contiguous()        # [N, cap, F, D]
+    out = torch.full((B, F * D), 123.0, dtype=torch.float32, device=cuda)
+    L.check(lib.cdc_shard_expand(rows_recv.data_ptr(), uniq.data_ptr(), cnt.data_ptr(), seg.data_ptr(), perm.data_ptr(),
+                                 slot_of.data_ptr(), out.data_ptr(), B, F, D, N, cap, s), "expand")
+    assert np.array_equal(out.cpu().numpy().reshape(B, F, D), row_vec(idx.astype(np.int64)))
+    # way back: per-unique-row gradients land in the slot their row id was sent in
+    rowgrad = torch.randn((F, B, D), dtype=torch.float32, device=cuda)
+    gsend = torch.zeros((N, cap, F, D), dtype=torch.float32, device=cuda)
+    L.check(lib.cdc_shard_pack(rowgrad.data_ptr(), uniq.data_ptr(), cnt.data_ptr(), slot_of.data_ptr(), gsend.data_ptr(), B, F, D, N, cap, s), "pack")
+    g_h, rg_h, uniq_h, cnt_h = gsend.cpu().numpy(), rowgrad.cpu().numpy(), uniq.cpu().numpy(), cnt.cpu().numpy()
+    want = np.zeros_like(g_h)
+    for f in range(F):
+        for j in range(cnt_h[f]):
+            r = uniq_h[f, j]
+            if r >= 0:
+                want[r % N, slot_h[f, j], f] = rg_h[f, j]
+    assert np.array_equal(g_h, want)
+
+
+@pytest.mark.parametrize("n_runs,run_len", [(2, 64), (8, 832), (3, 100), (1, 50)])
+def test_merge_dedupe_equals_sort_dedupe(cuda, n_runs, run_len):
+    """cdc_embed_merge_dedupe (rank merge of already sorted runs, used by the owner of a row shard) gives exactly what the
+    general sort gives on the same batch, -1 padding included."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    F, B = 4, n_runs * run_len
+    rng = np.random.default_rng(n_runs * 1000 + run_len)
+    idx = np.full((n_runs, run_len, F), -1, dtype=np.int32)
+    for r in range(n_runs):
+        for f, v in enumerate([5, 300, 100000, 40]):
+            n = int(rng.integers(0, run_len + 1))
+            idx[r, :n, f] = np.sort(rng.choice(max(v, n), size=n, replace=False) if v >= n else rng.integers(0, v, size=n))
+            if v < n:                       # duplicates inside a run cannot come from the bucket kernel; keep them unique
+                u = np.unique(idx[r, :n, f])
+                idx[r, :, f] = -1
+                idx[r, :len(u), f] = u
+    d_idx = torch.from_numpy(idx.reshape(B, F)).to(cuda)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for merge in (False, True):
+        uniq = torch.full((F, B), -7, dtype=torch.int32, device=cuda)
+        seg = torch.full((F, B + 1), -7, dtype=torch.int32, device=cuda)
+        perm = torch.full((F, B), -7, dtype=torch.int32, device=cuda)
+        cnt = torch.zeros(F, dtype=torch.int32, device=cuda)
+        scratch = torch.empty(2 * F * B, dtype=torch.int64, device=cuda)
+        if merge:
+            L.check(lib.cdc_embed_merge_dedupe(d_idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
+                                               scratch.data_ptr(), B, F, n_runs, s), "merge")
+        else:
+            L.check(lib.cdc_embed_sort_dedupe(d_idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
+                                              scratch.data_ptr(), B, F, s), "sort")
+        c = cnt.cpu().numpy()
+        outs.append((c, [uniq[f, :c[f]].cpu().numpy() for f in range(F)], [seg[f, :c[f] + 1].cpu().numpy() for f in range(F)],
+                     perm.cpu().numpy()))
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+    for f in range(F):
+        assert np.array_equal(a[1][f], b[1][f]) and np.array_equal(a[2][f], b[2][f])
