@@ -149,11 +149,14 @@ def main():
     from cdcmdr_amd.optim import FusedAdam
     from cdcmdr_amd.synth import make_dataset
     from cdcmdr_amd.trainer import TrainStep
-    dp = DataParallel() if world > 1 else None
+    # CDC_BENCH_REHEARSAL=1: all ranks on cuda:0 with gloo (host-staged) collectives — exercises the N>1 code path of this
+    # script on a one-GPU box; the throughput it prints is meaningless
+    rehearsal = os.environ.get("CDC_BENCH_REHEARSAL") == "1"
+    dp = (DataParallel(backend="gloo") if rehearsal else DataParallel()) if world > 1 else None
     sim = None
     if args.simulate_world > 1 and world == 1:
         sim = Loopback(args.simulate_world)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0"))
     rank = int(os.environ.get("RANK", "0"))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)

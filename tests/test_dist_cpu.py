@@ -2,9 +2,10 @@
 DataParallel helper, the CPU oracle standing in for the kernels (the HIP path cannot run without a GPU).
 
 Checked: sharded step == single step on the concatenated batch — (1) ONE sum all-reduce of the flat dense-gradient
-arena with the loss carrying 1/global_batch, (2) all-gather of (row index, row gradient) pairs so that every rank forms
-the identical per-row table gradient, (3) the loss all-reduce.  BatchNorm runs on its running statistics here: batch
-statistics under DP are per-rank (as torch DDP without SyncBatchNorm), which DESIGN.md lists as the open item."""
+arena with the loss carrying 1/global_batch, (2) replicated table: all-gather of (row index, row gradient) pairs so that
+every rank forms the identical per-row table gradient; row-sharded table: ids / rows / row gradients exchanged with the
+owning rank (row % world) by all-to-all, (3) the loss all-reduce.  BatchNorm runs on its running statistics here; the
+global-batch statistics exchange is covered on the GPU (tests/test_gpu_dist.py)."""
 import os
 import socket
 import sys
@@ -120,6 +121,95 @@ def test_two_rank_exchange_equals_single_process(tmp_path):
         assert abs(float(o["loss"]) - float(loss)) < 1e-6
     # both ranks hold identical exchanged data -> identical table update on every replica
     assert torch.equal(outs[0]["dE_all"], outs[1]["dE_all"]) and torch.equal(outs[0]["arena"], outs[1]["arena"])
+
+
+# ---- the row-sharded table protocol (trainer._dp_sequence_sharded) rehearsed with numpy standing in for the kernels -------
+def _bucket(idx, world, cap):
+    """numpy restatement of cdc_shard_bucket: per field, the ascending unique rows go to owner row % world, slot = rank
+    among that owner's rows.  Returns send_ids [world, cap, F] (-1 padded) and {(f, row): slot}."""
+    B, F = idx.shape
+    send = np.full((world, cap, F), -1, dtype=np.int32)
+    slot = {}
+    for f in range(F):
+        nxt = [0] * world
+        for row in np.unique(idx[:, f]):
+            o = int(row) % world
+            assert nxt[o] < cap
+            send[o, nxt[o], f] = row
+            slot[(f, int(row))] = nxt[o]
+            nxt[o] += 1
+    return send, slot
+
+
+def _worker_sharded(rank, world, port, out_dir):
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    from cdcmdr_amd.dist import DataParallel
+    from oracle import cdc_oracle as O
+    torch.set_num_threads(1)
+    dp = DataParallel(backend="gloo")
+    sd, X, y, g = _problem()
+    table = sd["embedding.embedding_dict.weight"]
+    R, D = table.shape
+    F = len(FD)
+    lo, hi = dp.shard(B_GLOBAL)
+    idx = O.gather_index(X[lo:hi], FD).astype(np.int32)
+    cap = hi - lo
+    # the owner's copy: only rows it owns are valid (poison the others: a stale read would show)
+    mine = table.clone()
+    mine[torch.arange(R) % world != rank] = float("nan")
+    # (1) ids to the owners
+    send_ids, slot = _bucket(idx, world, cap)
+    recv_ids = torch.empty((world, cap, F), dtype=torch.int32)
+    dp.all_to_all(recv_ids, torch.from_numpy(send_ids))
+    assert all(int(r) % world == rank for r in recv_ids.reshape(-1).tolist() if r >= 0)
+    # (2) rows back
+    rows_send = torch.zeros((world, cap, F, D))
+    ok = recv_ids >= 0
+    rows_send[ok] = mine[recv_ids[ok].long()]
+    rows_recv = torch.empty_like(rows_send)
+    dp.all_to_all(rows_recv, rows_send)
+    e = torch.stack([torch.stack([rows_recv[int(idx[b, f]) % world, slot[(f, int(idx[b, f]))], f] for f in range(F)]) for b in range(hi - lo)])
+    # (3) per-unique-row gradient sums to the owners, who add the senders' contributions in rank order
+    _, _, _, dE = _local_grads(sd, X[lo:hi], y[lo:hi], g[lo:hi], 1.0 / B_GLOBAL)
+    dE = dE.reshape(hi - lo, F, D)
+    grads_send = torch.zeros((world, cap, F, D))
+    for b in range(hi - lo):
+        for f in range(F):
+            r = int(idx[b, f])
+            grads_send[r % world, slot[(f, r)], f] += dE[b, f]
+    grads_recv = torch.empty_like(grads_send)
+    dp.all_to_all(grads_recv, grads_send)
+    owned_grad = torch.zeros(R, D)
+    sel = recv_ids >= 0
+    owned_grad.index_add_(0, recv_ids[sel].long(), grads_recv[sel])
+    torch.save({"e": e.reshape(hi - lo, F * D), "owned_grad": owned_grad}, os.path.join(out_dir, f"shard{rank}.pt"))
+    dp.barrier()
+    dp.close()
+
+
+def test_two_rank_row_sharded_table_exchange(tmp_path):
+    """ids -> owners, rows -> requesters, row gradients -> owners (three equal-split all-to-alls): every rank sees exactly
+    the rows a plain gather gives, and the owners' gradients together are the single-process table gradient."""
+    world = 2
+    mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from oracle import cdc_oracle as O
+    sd, X, y, g = _problem()
+    table = sd["embedding.embedding_dict.weight"]
+    R, D = table.shape
+    _, _, idx, dE = _local_grads(sd, X, y, g, 1.0 / B_GLOBAL)
+    want_table = _table_grad(idx, dE, R, D)
+    per = B_GLOBAL // world
+    got_table = torch.zeros(R, D)
+    for r in range(world):
+        o = torch.load(os.path.join(tmp_path, f"shard{r}.pt"), weights_only=False)
+        want_e = O.embed(table, X[r * per:(r + 1) * per], FD)
+        assert torch.equal(o["e"], want_e)                               # no NaN: only owned rows were ever read
+        assert float(o["owned_grad"][torch.arange(R) % world != r].abs().max()) == 0.0
+        got_table += o["owned_grad"]
+    assert torch.allclose(got_table, want_table, rtol=1e-5, atol=1e-7)
 
 
 def test_shard_ranges_partition_the_batch():

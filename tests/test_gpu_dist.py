@@ -58,7 +58,7 @@ def _single_process_reference(table_mode):
     return {k: v.cpu() for k, v in model.state_dict().items()}, losses
 
 
-def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist):
+def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_bn=True):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     sys.path.insert(0, ROOT)
     from cdcmdr_amd.dist import DataParallel
@@ -70,7 +70,7 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist):
     torch.manual_seed(5)
     model = MMoE(FD, 8, 3, 4, (32, 16), (8,), dropout=0.0).to(dev).set_precision("f32")
     opt = FusedAdam(model, table_mode=table_mode, flush_every=2)
-    ts = TrainStep(model, opt, B_LOCAL, use_graph=use_graph, dist=dp, table_dist=table_dist)
+    ts = TrainStep(model, opt, B_LOCAL, use_graph=use_graph, dist=dp, table_dist=table_dist, sync_bn=sync_bn)
     assert ts.table_dist == (table_dist or ("sharded" if table_mode == "lazy" else "replicated"))
     X, y, g = _data(world)
     gb = B_LOCAL * world
@@ -124,3 +124,32 @@ def test_two_ranks_stay_identical(cuda, tmp_path, table_mode, use_graph, table_d
     moved = (w - w0).abs()
     big = w0.abs() > 0.1
     assert float(moved[big].min()) > 0.9e-3 * STEPS and float(moved[big].max()) < 1.1e-3 * STEPS
+
+
+def test_two_ranks_with_per_rank_batchnorm_statistics(cuda, tmp_path):
+    """sync_bn=False (what bench.py runs by default for N>1: BatchNorm over the local rows, as torch DDP without
+    SyncBatchNorm): the replicas still stay bit-identical in every trained tensor, and the first step's loss is the mean
+    of the two single-rank losses on the shards (same initial weights, per-shard statistics)."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "lazy", True, "sharded", False), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
+    assert r0["losses"] == r1["losses"] and all(np.isfinite(r0["losses"]))
+    for k in r0["sd"]:
+        if "running_" in k:
+            continue                                   # per-rank statistics: each rank tracks its own shard's
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), f"replicas diverged in {k}"
+    sys.path.insert(0, ROOT)
+    from cdcmdr_amd.model.mmoe import MMoE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    X, y, g = _data(world)
+    shard_losses = []
+    for r in range(world):
+        torch.manual_seed(5)
+        model = MMoE(FD, 8, 3, 4, (32, 16), (8,), dropout=0.0).to(cuda).set_precision("f32")
+        ts = TrainStep(model, FusedAdam(model, table_mode="lazy"), B_LOCAL)
+        sl = slice(r * B_LOCAL, (r + 1) * B_LOCAL)
+        bce, _ = ts.step(torch.from_numpy(X[sl]).to(cuda), torch.from_numpy(y[sl]).to(cuda), torch.from_numpy(g[sl]).to(cuda))
+        shard_losses.append(float(bce.item()))
+    assert abs(r0["losses"][0] - float(np.mean(shard_losses))) < 2e-6
