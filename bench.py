@@ -242,7 +242,7 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
     """Per-launch HIP-event timing of instrumented eager steps (same launches as the timed region, which may be
     replayed as a graph where events cannot be placed).  The roofline object is for the step's dominant kernel."""
     batches = [(Xd[i], yd[i], gd[i]) for i in range(len(Xd))]
-    prof = ts.profile(batches, n_steps=12, skip=2)
+    prof = ts.profile(batches, n_steps=2 + 64, skip=2)      # 64 steps: exactly one period of the lazy table's whole-table flush
     total = sum(v["ms_per_step"] for v in prof.values())
     top = sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])
     name, d = top[0]

@@ -515,17 +515,18 @@ extern "C" int cdc_embed_adam_patch(const float* side, const int32_t* uniq_row, 
 // recurrence (g = 2*l2*w + wd*w) is replayed on demand.  Every element-step is computed exactly once
 // with the same adam_elem as the dense pass, so both forms give identical bits.
 // ------------------------------------------------------------------------------------------------
-template <bool FAST>
+template <bool FAST, int VEC>
 __global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
                                                       float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                       int32_t* __restrict__ last, cdc_adam_hp hp,
                                                       const int32_t* __restrict__ step_dev, int32_t B, int32_t F, int32_t D) {
     const AdamConsts c = make_consts(hp);
     const int target = *step_dev - 1;
-    const int64_t total = (int64_t)F * B * D;
+    const int chunks = D / VEC;
+    const int64_t total = (int64_t)F * B * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % D);
-        const int64_t slot = i / D;
+        const int d = (int)(i % chunks) * VEC;
+        const int64_t slot = i / chunks;
         const int f = (int)(slot / B);
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
@@ -533,9 +534,25 @@ __global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict_
         if (row < 0) continue;                                   // padding entry of an exchanged row list
         const int from = last[row];
         if (from >= target) continue;
-        float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
-        adam_replay<FAST>(wv, mv, vv, from, target, c, hp);
-        w[row * D + d] = wv; m[row * D + d] = mv; v[row * D + d] = vv;
+        const int64_t e0 = row * D + d;
+        float wv[VEC], mv[VEC], vv[VEC];
+        if (VEC == 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(w + e0), b4 = *reinterpret_cast<const float4*>(m + e0),
+                         c4 = *reinterpret_cast<const float4*>(v + e0);
+            wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
+            mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
+            vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
+        } else {
+            wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0];
+        }
+        adam_replay<FAST, VEC>(wv, mv, vv, from, target, c, hp);
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(w + e0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            *reinterpret_cast<float4*>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+            w[e0] = wv[0]; m[e0] = mv[0]; v[e0] = vv[0];
+        }
         // last[row] is advanced by k_lazy_mark afterwards: every lane of the row reads it here
     }
 }
@@ -561,15 +578,16 @@ extern "C" int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* un
     CDC_CHECK_ARG(uniq_row && uniq_cnt && w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0, CDC_E_BADARG,
                   "embed_lazy_catchup: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0 && D > 0, CDC_E_BADARG, "embed_lazy_catchup: bad sizes");
-    const int64_t total = (int64_t)F * B * D;
+    const bool vec = (D % 4 == 0) && ((((uintptr_t)w | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const int64_t total = (int64_t)F * B * (vec ? D / 4 : D);
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
     CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_catchup: fast_replay needs the inv_bc2 table");
-    if (hp.fast_replay)
-        hipLaunchKernelGGL(k_lazy_catchup<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, w, m, v, last, hp,
-                           step_dev, (int32_t)B, F, D);
-    else
-        hipLaunchKernelGGL(k_lazy_catchup<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, w, m, v, last, hp,
-                           step_dev, (int32_t)B, F, D);
+#define CDC_CATCHUP(FASTV, VECV)                                                                                                 \
+    hipLaunchKernelGGL((k_lazy_catchup<FASTV, VECV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, w, m, \
+                       v, last, hp, step_dev, (int32_t)B, F, D)
+    if (hp.fast_replay) { if (vec) CDC_CATCHUP(true, 4); else CDC_CATCHUP(true, 1); }
+    else                { if (vec) CDC_CATCHUP(false, 4); else CDC_CATCHUP(false, 1); }
+#undef CDC_CATCHUP
     CDC_LAUNCH_CHECK("embed_lazy_catchup");
     int blocks2 = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 256 * 16);
     hipLaunchKernelGGL(k_lazy_mark, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, last, step_dev,
@@ -620,27 +638,41 @@ extern "C" int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_r
     return 0;
 }
 
-// all rows -> step target = *step_dev + step_bias (only when target % period == 0).  Rows not looked up since the last
-// flush share one `last`, so whole waves replay the same steps: no divergence, coalesced float4 traffic.
+// rows -> step target = *step_dev + step_bias: all of them (period <= 1) or the slice (target mod period) of the table.
+// Rows not looked up since their last flush share one `last`, so whole waves replay the same steps.
 template <bool FAST, int VEC>
 __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                     const int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
                                                     const int32_t* __restrict__ step_dev, int32_t step_bias, int32_t period,
                                                     int32_t own_mod, int32_t own_rem) {
     const int target = *step_dev + step_bias;
-    if (period > 1 && (target % period) != 0) return;
+    // period > 1: this call handles one slice of the table, slice (target mod period) — every row is brought up to date
+    // once per `period` steps, a 1/period share of the work in every step instead of a burst
+    int64_t row_lo = 0, row_hi = R;
+    if (period > 1) {
+        const int64_t rps = (R + period - 1) / period;
+        row_lo = (int64_t)(((target % period) + period) % period) * rps;
+        row_hi = row_lo + rps < R ? row_lo + rps : R;
+        if (row_lo >= row_hi) return;
+    }
     const AdamConsts c = make_consts(hp);
-    const int64_t total = R * D / VEC;
+    // row-sharded table: only the rows this rank owns (row % own_mod == own_rem) are visited
+    const int64_t stride = own_mod > 1 ? own_mod : 1;
+    int64_t first = row_lo;
+    if (stride > 1) first = row_lo + ((own_rem - row_lo % stride) + stride) % stride;
+    if (first >= row_hi) return;
+    const int64_t n_rows = (row_hi - first + stride - 1) / stride;
+    const int chunks = D / VEC;
+    const int64_t total = n_rows * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t e0 = i * VEC;
-        const int64_t row = e0 / D;
-        if (own_mod > 1 && (row % own_mod) != own_rem) continue;   // row-sharded table: only the rows this rank owns
+        const int64_t row = first + (i / chunks) * stride;
+        const int64_t e0 = row * D + (i % chunks) * VEC;
         const int from = last[row];
         if (from >= target) continue;
         float wv[VEC], mv[VEC], vv[VEC];
         if (VEC == 4) {
-            const float4 a4 = reinterpret_cast<const float4*>(w)[i], b4 = reinterpret_cast<const float4*>(m)[i],
-                         c4 = reinterpret_cast<const float4*>(v)[i];
+            const float4 a4 = *reinterpret_cast<const float4*>(w + e0), b4 = *reinterpret_cast<const float4*>(m + e0),
+                         c4 = *reinterpret_cast<const float4*>(v + e0);
             wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
             mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
             vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
@@ -649,9 +681,9 @@ __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float
         }
         adam_replay<FAST, VEC>(wv, mv, vv, from, target, c, hp);
         if (VEC == 4) {
-            reinterpret_cast<float4*>(w)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
-            reinterpret_cast<float4*>(m)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
-            reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            *reinterpret_cast<float4*>(w + e0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            *reinterpret_cast<float4*>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         } else {
             w[e0] = wv[0]; m[e0] = mv[0]; v[e0] = vv[0];
         }
@@ -660,8 +692,13 @@ __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float
 __global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ last, int64_t R, const int32_t* __restrict__ step_dev,
                                                        int32_t step_bias, int32_t period, int32_t own_mod, int32_t own_rem) {
     const int target = *step_dev + step_bias;
-    if (period > 1 && (target % period) != 0) return;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t row_lo = 0, row_hi = R;
+    if (period > 1) {
+        const int64_t rps = (R + period - 1) / period;
+        row_lo = (int64_t)(((target % period) + period) % period) * rps;
+        row_hi = row_lo + rps < R ? row_lo + rps : R;
+    }
+    for (int64_t i = row_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < row_hi; i += (int64_t)gridDim.x * blockDim.x) {
         if (own_mod > 1 && (i % own_mod) != own_rem) continue;
         if (last[i] < target) last[i] = target;
     }
@@ -675,7 +712,9 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
                   "embed_lazy_flush: bad sizes");
     CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_flush: fast_replay needs the inv_bc2 table");
     const bool vec = (D % 4 == 0) && ((((uintptr_t)w | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div(R * D / (vec ? 4 : 1), 256), 256 * 16);
+    int64_t rows_call = period > 1 ? cdc_ceil_div(R, period) : R;
+    if (own_mod > 1) rows_call = cdc_ceil_div(rows_call, own_mod) + 1;
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdc_ceil_div(rows_call * D / (vec ? 4 : 1), 256), 256 * 16));
     hipStream_t st = (hipStream_t)stream;
     if (hp.fast_replay) {
         if (vec) hipLaunchKernelGGL((k_lazy_flush<true, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
@@ -685,7 +724,7 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
         else     hipLaunchKernelGGL((k_lazy_flush<false, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
     }
     CDC_LAUNCH_CHECK("embed_lazy_flush");
-    int blocks2 = (int)std::min<int64_t>(cdc_ceil_div(R, 256), 256 * 16);
+    int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>(cdc_ceil_div(period > 1 ? cdc_ceil_div(R, period) : R, 256), 256 * 16));
     hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias, period, own_mod, own_rem);
     CDC_LAUNCH_CHECK("embed_lazy_set_last");
     return 0;

@@ -41,7 +41,8 @@ class FusedAdam:
                  fast_replay=True, flush_every=64):
         """frozen: parameters left untouched by the optimiser (like leaving them out of torch.optim.Adam's list).
         lazy mode: fast_replay = hardware rcp/sqrt in the replay of L2-only steps (False: the exact routine, bit-identical
-        to the dense mode); flush_every = period (steps) of the whole-table catch-up that bounds replay gaps (0 = never)."""
+        to the dense mode); flush_every = P: every step replays one of P slices of the table, so that every row is brought
+        up to date once per P steps (bounds the replay gaps; 0 = only on demand)."""
         assert table_mode in ("dense", "lazy")
         self.model = model
         self.frozen = {id(p) for p in frozen}
@@ -144,36 +145,35 @@ class FusedAdam:
                  (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), None if err is None else err.data_ptr(), B, F,
                   self.table.shape[0]), self._stream())
 
-    def table_catchup_rows(self, idx, B, F, D, tag="", runs=0):
-        """lazy mode, BEFORE the gather of this step, on already computed row indices [B,F] (the gathered batch under DP)."""
+    def flush_slice(self):
+        """lazy mode, once per step AFTER the catch-up of the step's rows: replays slice (t-1 mod flush_every) of the table
+        up to step t-1.  Rows of the current batch are already at t-1 and are skipped."""
+        if self.table_mode != "lazy" or self.flush_every <= 1:
+            return
+        L.launch("cdc_embed_lazy_flush(slice)", self.lib.cdc_embed_lazy_flush,
+                 (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
+                  self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every,
+                  self.own_mod, self.own_rem), self._stream(),
+                 nbytes=24.0 * self.table.numel() / self.flush_every / max(self.own_mod, 1))
+
+    def table_catchup_rows(self, idx, B, F, D, tag="", runs=0, flush=True):
+        """lazy mode, BEFORE the gather of this step, on already computed row indices [B,F] (the gathered batch under DP).
+        flush=False: the caller issues flush_slice() itself, later in the step."""
         assert self.table_mode == "lazy"
         s = self._stream()
-        if self.flush_every > 1:
-            L.launch("cdc_embed_lazy_flush(periodic)", self.lib.cdc_embed_lazy_flush,
-                     (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every,
-                      self.own_mod, self.own_rem), s)
         ws = self.sort_rows(idx, B, F, D, tag, runs)
         L.launch("cdc_embed_lazy_catchup", self.lib.cdc_embed_lazy_catchup,
                  (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(), self.table_m.data_ptr(),
                   self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D), s)
+        if flush:
+            self.flush_slice()
 
-    def table_catchup(self, ids, offsets, idx, B, F, D):
+    def table_catchup(self, ids, offsets, idx, B, F, D, flush=True):
         """lazy mode, BEFORE the gather of this step: row indices -> dedupe -> replay the rows up to step t-1."""
         assert self.table_mode == "lazy"
-        s = self._stream()
-        if self.flush_every > 1:
-            # every `flush_every` steps the whole table is brought to step t-1 (device-side decision: graph-replay safe)
-            L.launch("cdc_embed_lazy_flush(periodic)", self.lib.cdc_embed_lazy_flush,
-                     (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
-                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every,
-                      self.own_mod, self.own_rem), s)
         L.launch("cdc_embed_index", self.lib.cdc_embed_index,
-                 (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), None, B, F, self.table.shape[0]), s)
-        ws = self.sort_rows(idx, B, F, D)
-        L.launch("cdc_embed_lazy_catchup", self.lib.cdc_embed_lazy_catchup,
-                 (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(), self.table_m.data_ptr(),
-                  self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D), s)
+                 (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), None, B, F, self.table.shape[0]), self._stream())
+        self.table_catchup_rows(idx, B, F, D, flush=flush)
 
     def table_step(self, idx, d_out, B, F, D, tag=""):
         """Adam step t on the table from the batch's row indices [B,F] and the gradient of the gathered rows [B,F*D]."""

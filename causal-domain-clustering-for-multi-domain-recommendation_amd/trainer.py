@@ -111,7 +111,7 @@ class TrainStep:
         B, F, D = self.B, emb.F, emb.D
         opt.begin_step()
         if opt.table_mode == "lazy":
-            opt.table_catchup(emb.ids, emb.offsets, emb.idx, B, F, D)
+            opt.table_catchup(emb.ids, emb.offsets, emb.idx, B, F, D)     # + this step's slice of the whole-table replay
         plan.forward()
         self._bce()
         plan.backward()
@@ -186,7 +186,7 @@ class TrainStep:
                       self.overflow.data_ptr(), B, F, N, cap), st())
 
         def serve():
-            opt.table_catchup_rows(self.recv_ids, Bv, F, D, "owner", runs=N)      # each sender's list is already sorted
+            opt.table_catchup_rows(self.recv_ids, Bv, F, D, "owner", runs=N, flush=False)   # each sender's list is sorted
             L.launch("cdc_embed_gather_fwd(owner)", lib.cdc_embed_gather_fwd,
                      (self.recv_ids.data_ptr(), self.zero_offsets.data_ptr(), opt.table.data_ptr(), self.rows_send.data_ptr(),
                       None, None, Bv, F, D, opt.table.shape[0]), st())
@@ -211,6 +211,7 @@ class TrainStep:
 
         def update():
             opt.table_step(self.recv_ids, self.grads_recv, Bv, F, D, "owner")
+            opt.flush_slice()                           # off the rows-exchange critical path: after the owner's update
             opt.dense_step(plan.param_grads, plan._param_refs)
 
         def run_steps(steps):
@@ -302,30 +303,37 @@ class TrainStep:
         return self.loss, self.opt.reg_loss()
 
     def profile(self, batches, n_steps=10, skip=2):
-        """Per-launch timing of `n_steps` eager steps (HIP events on the launch stream).  Returns
-        {name: {"ms_per_step", "launches_per_step", "flops_per_step", "bytes_per_step"}}."""
+        """Per-launch timing of `n_steps` eager steps (HIP events on the launch stream); the first `skip` are not counted.
+        Returns {name: {"ms_per_step", "launches_per_step", "flops_per_step", "bytes_per_step"}}.  Events are read back
+        and released every few steps: the runtime backs each timed event with a signal from a bounded pool."""
         was_graph, self.use_graph = self.use_graph, False
         rec = []
+        out = {}
+        used = max(n_steps - skip, 1)
+
+        def fold(count):
+            torch.cuda.synchronize()
+            if count:
+                for name, e0, e1, fl, nb in rec:
+                    d = out.setdefault(name, {"ms_per_step": 0.0, "launches_per_step": 0.0, "flops_per_step": 0.0, "bytes_per_step": 0.0})
+                    d["ms_per_step"] += e0.elapsed_time(e1) / used
+                    d["launches_per_step"] += 1.0 / used
+                    d["flops_per_step"] += fl / used
+                    d["bytes_per_step"] += nb / used
+            rec.clear()
+
         L.PROFILE = rec
         try:
-            marks = []
             for i in range(n_steps):
-                marks.append(len(rec))
-                b = batches[i % len(batches)]
-                self.step(*b)
-            torch.cuda.synchronize()
+                if i == skip:
+                    fold(False)
+                self.step(*batches[i % len(batches)])
+                if i >= skip and (i - skip) % 4 == 3:
+                    fold(True)
+            fold(n_steps > skip)
         finally:
             L.PROFILE = None
             self.use_graph = was_graph
-        out = {}
-        start = marks[skip] if len(marks) > skip else 0
-        used = n_steps - skip if len(marks) > skip else n_steps
-        for name, e0, e1, fl, nb in rec[start:]:
-            d = out.setdefault(name, {"ms_per_step": 0.0, "launches_per_step": 0.0, "flops_per_step": 0.0, "bytes_per_step": 0.0})
-            d["ms_per_step"] += e0.elapsed_time(e1) / used
-            d["launches_per_step"] += 1.0 / used
-            d["flops_per_step"] += fl / used
-            d["bytes_per_step"] += nb / used
         return out
 
     def check_ids(self):

@@ -132,9 +132,12 @@ int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_row, const i
                           float* w, float* m, float* v, int32_t* last,
                           cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring, int32_t ring_len,
                           int64_t B, int32_t F, int32_t D, void* stream);
-/* brings all R rows to step target = *step_dev + step_bias: rows with last < target are replayed.
- * period > 1: the launch does nothing unless target % period == 0 (a periodic whole-table catch-up that bounds the
- * gaps the per-batch catch-up sees and runs divergence-free; decided on the device, so it sits in a replayed graph). */
+/* brings rows to step target = *step_dev + step_bias: rows with last < target are replayed.
+ * period <= 1: all R rows.  period > 1: only slice (target mod period) of the table (ceil(R/period) consecutive rows), so
+ * that calling it every step brings every row up to date once per `period` steps — this bounds the gaps the per-batch
+ * catch-up sees, spreads the replay work evenly over the steps, and the slice is chosen on the device (graph-replay safe).
+ * The slice launch touches no row whose last >= target (the step's own rows after their catch-up).  Measured: running it
+ * on a second stream beside the forward/backward gains nothing — both sides are bound by VALU issue. */
 int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D,
                          cdc_adam_hp hp, const int32_t* step_dev, int32_t step_bias, int32_t period,
                          int32_t own_mod, int32_t own_rem, void* stream);   /* own_mod > 1: only rows r with r % own_mod == own_rem */
