@@ -93,6 +93,73 @@ struct Stage {
     }
 };
 
+// ---- lean staging for reduction-contiguous operands ---------------------------------------------------------------
+// PMC counters showed the generic Stage spending ~400 VALU instructions per K-slab and wave on index arithmetic, bounds
+// predicates and alignment tests, against 16 MFMAs.  Everything that does not depend on the slab is hoisted here: one
+// pointer per pass (rows past the operand's extent are CLAMPED to its last row — they only feed accumulator rows/columns
+// the epilogue never stores), unconditional 16-byte loads for every full slab, pointer += BK.  Needs: 16-byte aligned base,
+// row stride a multiple of 4 floats; the (rare) partial last slab takes a guarded path.
+template <int ROWS, int BK>
+struct LeanStage {
+    static constexpr int PER = ROWS * BK / 4 / GEMM_THREADS;
+    static constexpr int TPR = BK / 4;                    // threads per tile row
+    static constexpr int RSTEP = GEMM_THREADS / TPR;      // tile rows per pass
+    f32x4_t v[PER];
+    const float* ptr[PER];
+
+    __device__ __forceinline__ void init(const Operand& op, int i0, int tid) {
+        const int r = (tid % TPR) * 4, i = tid / TPR;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int gi = i0 + i + p * RSTEP;
+            gi = gi < op.I ? gi : op.I - 1;
+            ptr[p] = op.p + (int64_t)gi * op.s_i + r;
+        }
+    }
+    __device__ __forceinline__ void load_full() {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            v[p] = *reinterpret_cast<const f32x4_t*>(ptr[p]);
+            ptr[p] += BK;
+        }
+    }
+    __device__ __forceinline__ void stride2() {}
+    __device__ __forceinline__ void load2() {                                  // every other slab (two stages in flight)
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            v[p] = *reinterpret_cast<const f32x4_t*>(ptr[p]);
+            ptr[p] += 2 * BK;
+        }
+    }
+    __device__ __forceinline__ void load_tail(int r0, int Rn, int tid) {       // partial last slab: element guards
+        const int r = r0 + (tid % TPR) * 4;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            f32x4_t val = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (r + q < Rn) val[q] = ptr[p][q];
+            v[p] = val;
+        }
+    }
+    template <typename T>
+    __device__ __forceinline__ void store(T* lds, int stride, int tid) const {
+        const int r = (tid % TPR) * 4, i = tid / TPR;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            T* dst = lds + (i + p * RSTEP) * stride + r;
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<bf16x4_t*>(dst) = __builtin_convertvector(v[p], bf16x4_t);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q] = v[p][q];
+            }
+        }
+    }
+};
+__device__ __forceinline__ bool lean_ok(const Operand& op) {
+    return op.s_r == 1 && op.I > 0 && ((((uintptr_t)op.p) & 15) == 0) && (op.s_i % 4 == 0);
+}
+
 // ---- one K-slab of MFMAs for this wave ------------------------------------------------------------
 template <bool BF16, int MT, int NT, int BK>
 __device__ __forceinline__ void mma_slab(const typename LdsElem<BF16, BK>::type* As, const typename LdsElem<BF16, BK>::type* Bs,
@@ -131,7 +198,7 @@ __device__ __forceinline__ void mma_slab(const typename LdsElem<BF16, BK>::type*
 }
 
 // ---- accumulate A(i,r)·B(j,r) over r for one (A,B) operand pair into acc ---------------------------
-template <bool BF16, int BM, int BN, bool A_RC, bool B_RC, bool COLSUM>
+template <bool BF16, int BM, int BN, bool A_RC, bool B_RC, bool COLSUM, int DEPTH = 1>
 __device__ __forceinline__ void gemm_accumulate(const Operand& A, const Operand& B, int i0, int j0, unsigned char* smem,
                                                 f32x4_t (&acc)[BM / 32][BN / 32], f32x4_t* colsum) {
     constexpr int BK = GEMM_BK;
@@ -142,6 +209,56 @@ __device__ __forceinline__ void gemm_accumulate(const Operand& A, const Operand&
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     const int nk = (A.Rn + BK - 1) / BK;
+    if constexpr (A_RC && B_RC && !COLSUM) {
+        if (lean_ok(A) && lean_ok(B)) {                    // uniform over the workgroup
+            const int nfull = A.Rn / BK;
+            if constexpr (DEPTH == 2) {
+                // two slabs in flight (only full slabs take this path; a partial last slab falls back to depth 1 below)
+                if (nfull == nk && nk >= 2) {
+                    LeanStage<BM, BK> a0, a1;
+                    LeanStage<BN, BK> b0, b1;
+                    a0.init(A, i0, tid); b0.init(B, j0, tid);
+                    a1 = a0; b1 = b0;
+#pragma unroll
+                    for (int p = 0; p < LeanStage<BM, BK>::PER; ++p) { a1.ptr[p] += BK; a0.stride2(); }
+#pragma unroll
+                    for (int p = 0; p < LeanStage<BN, BK>::PER; ++p) { b1.ptr[p] += BK; b0.stride2(); }
+                    a0.load2(); b0.load2(); a1.load2(); b1.load2();
+                    for (int kt = 0; kt < nk; kt += 2) {
+                        a0.store(As, S, tid); b0.store(Bs, S, tid);
+                        __syncthreads();
+                        if (kt + 2 < nk) { a0.load2(); b0.load2(); }
+                        mma_slab<BF16, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
+                        __syncthreads();
+                        if (kt + 1 < nk) {
+                            a1.store(As, S, tid); b1.store(Bs, S, tid);
+                            __syncthreads();
+                            if (kt + 3 < nk) { a1.load2(); b1.load2(); }
+                            mma_slab<BF16, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
+                            __syncthreads();
+                        }
+                    }
+                    return;
+                }
+            }
+            LeanStage<BM, BK> la;
+            LeanStage<BN, BK> lb;
+            la.init(A, i0, tid);
+            lb.init(B, j0, tid);
+            if (nfull > 0) { la.load_full(); lb.load_full(); }
+            else if (nk > 0) { la.load_tail(0, A.Rn, tid); lb.load_tail(0, A.Rn, tid); }
+            for (int kt = 0; kt < nk; ++kt) {
+                la.store(As, S, tid);
+                lb.store(Bs, S, tid);
+                __syncthreads();
+                if (kt + 1 < nfull) { la.load_full(); lb.load_full(); }
+                else if (kt + 1 < nk) { la.load_tail((kt + 1) * BK, A.Rn, tid); lb.load_tail((kt + 1) * BK, A.Rn, tid); }
+                mma_slab<BF16, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
+                __syncthreads();
+            }
+            return;
+        }
+    }
     Stage<BM, A_RC, BK> sa;
     Stage<BN, B_RC, BK> sb;
     if (nk > 0) { sa.load(A, i0, 0, tid); sb.load(B, j0, 0, tid); }
@@ -169,7 +286,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // =================================================================================================
 // forward: y = act(x · wᵀ + bias)
 // =================================================================================================
-template <bool BF16, int BM, int BN>
+template <bool BF16, int BM, int BN, int DEPTH>
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -194,7 +311,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_
     for (int mt = 0; mt < BM / 32; ++mt)
 #pragma unroll
         for (int nt = 0; nt < BN / 32; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    gemm_accumulate<BF16, BM, BN, true, true, false>(A, B, i0, j0, smem, acc, nullptr);
+    gemm_accumulate<BF16, BM, BN, true, true, false, DEPTH>(A, B, i0, j0, smem, acc, nullptr);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -229,7 +346,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_
 // =================================================================================================
 // grad-input: dX_o = sum_s dZ_s · W_s  (+ activation mask of the producing layer)
 // =================================================================================================
-template <bool BF16, int BM, int BN, bool WT>
+template <bool BF16, int BM, int BN, bool WT, int DEPTH>
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bwdx_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -258,7 +375,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bw
         Operand A{S.dz + (int64_t)row_lo * S.lddz, S.lddz, 1, M, S.N};   // (i=row, r=n)  r contiguous
         if (WT) {
             Operand B{S.wt, S.ldwt, 1, O.K, S.N};                         // W^T [K,N]: (j=k, r=n)  r contiguous
-            gemm_accumulate<BF16, BM, BN, true, true, false>(A, B, i0, j0, smem, acc, nullptr);
+            gemm_accumulate<BF16, BM, BN, true, true, false, DEPTH>(A, B, i0, j0, smem, acc, nullptr);
         } else {
             Operand B{S.w, 1, S.ldw, O.K, S.N};                           // W [N,K]:   (j=k, r=n)  j contiguous
             gemm_accumulate<BF16, BM, BN, true, false, false>(A, B, i0, j0, smem, acc, nullptr);
@@ -556,8 +673,11 @@ static constexpr size_t lds_bytes() {
 }
 
 static bool pick_big_tiles(int64_t tiles64) {
-    // 128x128 tiles quarter the L2 traffic per flop; use them once they still give every CU >= 2 workgroups
-    return tiles64 / 4 >= 512;
+    // Measured on the C2 launches (M = 4096): 64x64 tiles beat 128x128 even for the 2048-tile level-1 launch (0.097 vs
+    // 0.101 ms forward, 0.126 vs 0.153 ms grad-input per step) — these launches wait on loads, and four resident
+    // workgroups per CU hide more of that than two.  128x128 (a quarter of the L2 traffic per flop) only once the
+    // small tiles already oversubscribe the chip many times over.
+    return tiles64 >= 16384;
 }
 
 extern "C" int cdc_glinear_fwd(const cdc_lin_fwd_args* a, int32_t prec, void* stream) {
@@ -578,11 +698,12 @@ extern "C" int cdc_glinear_fwd(const cdc_lin_fwd_args* a, int32_t prec, void* st
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "glinear_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
     if (prec == CDC_PREC_BF16) {
-        if (big) hipLaunchKernelGGL((k_glinear_fwd<true, 128, 128>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 128, 128>()), st, *a);
-        else     hipLaunchKernelGGL((k_glinear_fwd<true, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
+        // one slab in flight: a second one slowed the forward down (0.102 vs 0.097 ms per step at 64x64)
+        if (big) hipLaunchKernelGGL((k_glinear_fwd<true, 128, 128, 1>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_fwd<true, 64, 64, 1>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
     } else {
-        if (big) hipLaunchKernelGGL((k_glinear_fwd<false, 128, 128>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 128, 128>()), st, *a);
-        else     hipLaunchKernelGGL((k_glinear_fwd<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
+        if (big) hipLaunchKernelGGL((k_glinear_fwd<false, 128, 128, 1>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_fwd<false, 64, 64, 1>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
     }
     CDC_LAUNCH_CHECK("glinear_fwd");
     return 0;
@@ -591,11 +712,12 @@ extern "C" int cdc_glinear_fwd(const cdc_lin_fwd_args* a, int32_t prec, void* st
 template <bool WT>
 static void launch_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, bool big, int64_t grid, hipStream_t st) {
     if (prec == CDC_PREC_BF16) {
-        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<true, 128, 128, WT>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 128, 128>()), st, *a);
-        else     hipLaunchKernelGGL((k_glinear_bwd_x<true, 64, 64, WT>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
+        // 64x64: two slabs in flight (0.114 vs 0.126 ms per step); 128x128: one (two cost 25 %)
+        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<true, 128, 128, WT, 1>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_bwd_x<true, 64, 64, WT, WT ? 2 : 1>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<true, 64, 64>()), st, *a);
     } else {
-        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<false, 128, 128, WT>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 128, 128>()), st, *a);
-        else     hipLaunchKernelGGL((k_glinear_bwd_x<false, 64, 64, WT>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
+        if (big) hipLaunchKernelGGL((k_glinear_bwd_x<false, 128, 128, WT, 1>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 128, 128>()), st, *a);
+        else     hipLaunchKernelGGL((k_glinear_bwd_x<false, 64, 64, WT, 1>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a);
     }
 }
 

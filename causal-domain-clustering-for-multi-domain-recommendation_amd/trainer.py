@@ -46,6 +46,7 @@ class TrainStep:
         self.y = torch.zeros(self.B, dtype=torch.int16, device=dev)
         self.group = torch.zeros(self.B, dtype=torch.int64, device=dev) if mode == "multi" else None
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.reg = torch.zeros((), dtype=torch.float64, device=dev)        # the step's sum(l2*w^2), formed inside the launch sequence
         self.use_graph = use_graph
         self.graph = None
         self._stage_graphs = {}
@@ -105,6 +106,10 @@ class TrainStep:
                   self.loss.data_ptr(), og.ptr, og.ld, self.B, self.out.cols, 1.0 / self.global_B),
                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
+    def _reg(self):
+        # part of the (graph-replayed) launch sequence, so that step() issues nothing else per call
+        torch.add(self.opt.reg_sum[0], self.opt.reg_sum[1], alpha=self.opt.l2_table, out=self.reg)
+
     def _launch_all(self):
         """single GPU: the whole step is one launch sequence (one hipGraph when use_graph)."""
         opt, plan, emb = self.opt, self.plan, self.emb
@@ -117,6 +122,7 @@ class TrainStep:
         plan.backward()
         opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
         opt.dense_step(plan.param_grads, plan._param_refs)
+        self._reg()
 
     # ---- data parallel: launch segments separated by the collectives (each segment replayable as a graph) ---------------
     def _dp_sequence(self):
@@ -142,6 +148,7 @@ class TrainStep:
         def update():
             opt.table_step(self.idx_all, self.dE_all, self.global_B, F, D)
             opt.dense_step(plan.param_grads, plan._param_refs)
+            self._reg()
 
         def run_steps(steps):
             def fn():
@@ -213,6 +220,7 @@ class TrainStep:
             opt.table_step(self.recv_ids, self.grads_recv, Bv, F, D, "owner")
             opt.flush_slice()                           # off the rows-exchange critical path: after the owner's update
             opt.dense_step(plan.param_grads, plan._param_refs)
+            self._reg()
 
         def run_steps(steps):
             def fn():
@@ -300,7 +308,7 @@ class TrainStep:
         else:
             self._launch_all()
             self._warm += 1
-        return self.loss, self.opt.reg_loss()
+        return self.loss, self.reg
 
     def profile(self, batches, n_steps=10, skip=2):
         """Per-launch timing of `n_steps` eager steps (HIP events on the launch stream); the first `skip` are not counted.
