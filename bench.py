@@ -258,6 +258,15 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
         achieved = nbytes / (d["ms_per_step"] * 1e-3) / 1e9 if nbytes else None
         roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": nbytes}
+    if "lazy_flush" in name:
+        # the slice launch reads and writes each of its elements once but advances it flush_every Adam steps in between:
+        # its own floor is VALU issue (13 issue cycles per element-step with packed fp32 + two quarter-rate transcendentals)
+        es = opt.table.numel() * 1.0                       # element-steps per training step (every element, one step)
+        lane_rate = 256 * 64 * 2.4e9                       # fp32 lanes x clock
+        roof["valu"] = {"element_steps_per_step": es, "element_steps_per_s": es / (d["ms_per_step"] * 1e-3),
+                        "lane_cycles_per_element_step": lane_rate * d["ms_per_step"] * 1e-3 / es,
+                        "instruction_floor_lane_cycles": 12.5,
+                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved"}
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": None,
                  "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown, "breakdown_all": breakdown_all})
     # all MFMA launches together (north-star figure: expert GEMMs vs bf16 peak)

@@ -174,6 +174,8 @@ _SIGNATURES = {
     "cdc_embed_lazy_update": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
     "cdc_embed_merge_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
+    "cdc_eval_workspace_bytes": (c_i64, [c_i64, c_i32]),
+    "cdc_eval_metrics": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i32, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "cdc_shard_bucket": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_shard_expand": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p]),
     "cdc_shard_pack": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p]),
@@ -238,6 +240,8 @@ def load():
                 raise HipExtensionError(
                     f"libcdcmdr.so is missing at {path} and could not be built ({e}); "
                     "run `python __graft_entry__.py build` — there is no CPU fallback") from e
+            import warnings
+            warnings.warn(f"libcdcmdr.so is older than its sources and the rebuild failed: {str(e)[:400]}")
     try:
         lib = C.CDLL(path)
     except OSError as e:

@@ -509,6 +509,21 @@ int cdc_group_partition(const int64_t* group, int32_t* row_offsets, int32_t* ord
 int cdc_rows_permute(const float* in, int64_t ld_in, const int32_t* order, float* out, int64_t ld_out,
                      int64_t B, int32_t C, int32_t inverse, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Evaluation metrics — run.py:684-711: roc_auc_score + log_loss over the whole evaluation set and per
+ * domain (evaluate_multi_domain's groupby).  pred f32 [n] (the gathered tower probabilities), label int16 [n] (0/1),
+ * domain int32, element i at domain[i*ld_domain] (e.g. the domain column of X: ld = F); NULL when n_domain == 1.
+ *   out    [2*(n_domain+1)] doubles: auc of domain 0..n_domain-1, then of ALL rows; then the log-losses in the same order.
+ *          A segment with no row or a single class gets NaN for both (the reference's ValueError branch, run.py:699-704).
+ *   counts [2*(n_domain+1)] int64: rows per segment, then positives per segment.
+ *   err_flag (optional): 1 + index of a row with a NaN score, a label other than 0/1 or a domain outside [0, n_domain).
+ * AUC = Mann-Whitney U with mid-ranks, rank sums in integer arithmetic (order-independent); loss in double with sklearn's
+ * clipping to the float32 epsilon.  workspace: cdc_eval_workspace_bytes(n, n_domain) bytes, 256-byte aligned. */
+int64_t cdc_eval_workspace_bytes(int64_t n, int32_t n_domain);
+int cdc_eval_metrics(const float* pred, const int16_t* label, const int32_t* domain, int64_t ld_domain, int64_t n,
+                     int32_t n_domain, double* out, int64_t* counts, int32_t* err_flag, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -417,12 +417,20 @@ def auc(targets, scores):
 
 
 def logloss(targets, scores, eps=None):
-    """sklearn.metrics.log_loss for binary labels (probabilities clipped to float eps of their dtype)."""
-    t = np.asarray(targets).astype(np.float64).reshape(-1)
+    """sklearn.metrics.log_loss for binary labels, as run.py:686,701 calls it.  scikit-learn is a third-party dependency
+    that is not part of /root/reference; the arithmetic restated here is that of the version the golden vectors were
+    captured with (1.7.2, sklearn/metrics/_classification.py): the probability matrix [1-p, p] is formed IN THE DTYPE OF
+    THE PREDICTIONS (float32 for the reference's `.cpu().numpy()` tensors), clipped to [eps, 1-eps] with that dtype's
+    machine epsilon, and only the logarithm (scipy xlogy against int64 labels) and the mean are float64."""
+    t = np.asarray(targets).astype(np.int64).reshape(-1)
     s = np.asarray(scores).reshape(-1)
-    e = np.finfo(s.dtype).eps if eps is None else eps
-    p = np.clip(s.astype(np.float64), e, 1 - e)
-    return float(-(t * np.log(p) + (1 - t) * np.log(1 - p)).mean())
+    if s.dtype not in (np.float64, np.float32, np.float16):
+        s = s.astype(np.float64)
+    e = np.finfo(s.dtype).eps if eps is None else s.dtype.type(eps)
+    one = s.dtype.type(1)
+    p = np.clip(s, e, one - e).astype(np.float64)
+    q = np.clip(one - s, e, one - e).astype(np.float64)
+    return float(-np.where(t == 1, np.log(p), np.log(q)).mean())
 
 
 # --------------------------------------------------------------------------------------------------
