@@ -344,6 +344,18 @@ class TrainStep:
             self.use_graph = was_graph
         return out
 
+    def sibling(self, batch_size):
+        """A TrainStep for another batch size on the SAME model and optimiser state (the ragged last batch of an epoch,
+        which the reference trains on like any other: run.py:476).  Single GPU only; runs eagerly."""
+        if self.world > 1:
+            raise NotImplementedError("ragged batches under data parallelism")
+        sib = self.__dict__.setdefault("_siblings", {})
+        ts = sib.get(int(batch_size))
+        if ts is None:
+            ts = TrainStep(self.model, self.opt, int(batch_size), mode=self.mode, use_graph=False)
+            sib[int(batch_size)] = ts
+        return ts
+
     def check_ids(self):
         """Host-synchronising: raises IndexError like the reference if the last batch held an out-of-range id."""
         bad = int(self.emb.err.item())

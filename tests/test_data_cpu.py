@@ -1,0 +1,85 @@
+"""SURVEY §8f N3 on CPU: DeviceLoader yields exactly the batches torch's own
+DataLoader(TensorDataset(...), bs, shuffle=True) yields for the same RNG state (what run.py:244 builds), the reference's
+on-disk tensor format round-trips, tower indices / domain weights follow run.py:228-237, and the rank-sharded variant
+partitions every global batch."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _data(n=1000, F=5, seed=0):
+    rng = np.random.default_rng(seed)
+    X = torch.from_numpy(rng.integers(0, 50, size=(n, F)).astype(np.int32))
+    X[:, 2] = torch.from_numpy(rng.integers(0, 4, size=n).astype(np.int32))
+    y = torch.from_numpy(rng.integers(0, 2, size=(n, 1)).astype(np.int16))
+    return X, y
+
+
+@pytest.mark.parametrize("bs", [64, 1000, 333])
+def test_device_loader_equals_torch_dataloader_batch_for_batch(bs):
+    from cdcmdr_amd.data import DeviceLoader
+    X, y = _data()
+    g = X[:, 2:3].to(torch.int64)
+    torch.manual_seed(123)
+    ref = DataLoader(TensorDataset(X, y, g), bs, shuffle=True)
+    want = [tuple(t.clone() for t in b) for _ in range(2) for b in ref]            # two epochs: RNG advances like the sampler's
+    torch.manual_seed(123)
+    mine = DeviceLoader((X, y, g), bs, shuffle=True)
+    got = [b for _ in range(2) for b in mine]
+    assert len(mine) == len(ref) and len(got) == len(want)
+    for a, b in zip(got, want):
+        assert all(torch.equal(u, v) for u, v in zip(a, b))
+    # shuffle=False: plain slices
+    for a, b in zip(DeviceLoader((X, y), bs, shuffle=False), DataLoader(TensorDataset(X, y), bs, shuffle=False)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_rank_shards_partition_every_global_batch():
+    from cdcmdr_amd.data import DeviceLoader
+    X, y = _data(n=1003)
+    world, bs = 4, 50
+    torch.manual_seed(7)
+    whole = [b for b in DeviceLoader((X, y), bs * world, shuffle=True)]
+    parts = []
+    for r in range(world):
+        torch.manual_seed(7)
+        parts.append([b for b in DeviceLoader((X, y), bs, shuffle=True, rank=r, world=world)])
+    assert all(len(p) == len(whole) for p in parts)
+    for i, b in enumerate(whole):
+        cat = torch.cat([parts[r][i][0] for r in range(world)])
+        assert torch.equal(cat, b[0])                            # rank order == batch order (the DP parity definition)
+    assert all(parts[r][0][0].shape[0] == bs for r in range(world))
+
+
+def test_split_files_round_trip_and_make_loader(tmp_path):
+    from cdcmdr_amd.data import load_split, make_domain_loaders, make_loader, save_split
+    X, y = _data()
+    save_split(str(tmp_path), "train", X, y)
+    X2, y2 = load_split(str(tmp_path), "train")
+    assert X2.dtype == torch.int32 and y2.dtype == torch.int16 and torch.equal(X2, X) and torch.equal(y2, y)
+    d2g = {0: 0, 1: 1, 2: 1, 3: 2}
+    loader, w = make_loader(X, y, 128, "cpu", domain_idx=2, domain2group=d2g, shuffle=False)
+    cnt = np.bincount(X[:, 2].numpy())
+    np.testing.assert_allclose(w, cnt / len(X))                  # run.py:233-237
+    for xb, yb, gb in loader:
+        assert gb.dtype == torch.int64 and gb.shape == (xb.shape[0], 1)
+        assert gb.view(-1).tolist() == [d2g[int(d)] for d in xb[:, 2]]
+    # domain filter (run.py:223-226) + per-domain loaders with the batch sequence (run.py:252-293)
+    loader, _ = make_loader(X, y, 128, "cpu", domain_idx=2, domain_filter=[1, 3], shuffle=False)
+    assert all(set(xb[:, 2].tolist()) <= {1, 3} for xb, _ in loader)
+    np.random.seed(0)
+    loaders, seq, w2 = make_domain_loaders(X, y, 100, "cpu", 2, 4)
+    assert sorted(loaders) == [0, 1, 2, 3]
+    for d, ld in loaders.items():
+        assert seq.count(d) == len(ld) == int(np.ceil(cnt[d] / 100))
+        assert all(bool((xb[:, 2] == d).all()) for xb, _ in ld)
+    np.testing.assert_allclose(w2, cnt / len(X))
+    with pytest.raises(ValueError):
+        make_loader(X, y, 128, "cpu", domain_idx=2, domain2group={0: 0, 1: 1})     # domains 2, 3 have no tower

@@ -202,3 +202,55 @@ def test_table_adam_kernels_bits_equal_the_c_restatement(cuda):
             ulp = int(np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)).max())
             assert same >= floor and ulp <= 8, f"step {t} table {name}: {same:.4f} bit-identical, max {ulp} ulp"
         w, m, v = gw.copy(), gm.copy(), gv.copy()             # continue from the device state (no drift accumulation)
+
+
+def test_train_epoch_over_a_device_loader_with_a_ragged_last_batch(cuda):
+    """Run.train's epoch loop (run.py:470-497) on the DeviceLoader — three batches of 32, 32 and 16 rows
+    (the reference trains on the ragged tail like on any other batch) against the CPU oracle driven by torch's own Adam."""
+    from cdcmdr_amd.data import make_loader, train_epoch
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = FD_SPARSE
+    torch.manual_seed(21)
+    model = PLE(fd, 4, 3, 2, 2, ((32, 16), (8,)), (8, 4), dropout=0.0).to(cuda).set_precision("f32")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(8)
+    n = 80
+    X = torch.from_numpy(make_ids(rng, n, fd))
+    X[:, 2] = torch.from_numpy(rng.integers(0, 3, size=n).astype(np.int32))
+    y = torch.from_numpy(rng.integers(0, 2, size=(n, 1)).astype(np.int16))
+    loader, w = make_loader(X, y, 32, cuda, domain_idx=2, domain2group={0: 0, 1: 1, 2: 2}, shuffle=False)
+    opt = FusedAdam(model, table_mode="dense")          # dense: the logged regularisation value is exact every step
+    ts = TrainStep(model, opt, 32)
+    logged = []
+    done, skipped = train_epoch(ts, loader, log_interval=1, log=logged.append)
+    assert (done, skipped) == (3, 0) and len(logged) == 3
+    opt.flush_table()
+    # the oracle: same batches, torch.optim.Adam on the CPU (what run.py:481-493 makes torch do)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    s2 = dict(sd)
+    s2.update(leaves)
+    l2 = {k: 1e-5 for k in O.reg_names(list(sd), "ple")}
+    ref_opt = torch.optim.Adam(list(leaves.values()), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    names = set(sd)
+    want_losses = []
+    for lo in (0, 32, 64):
+        xb, yb = X[lo:lo + 32].numpy(), y[lo:lo + 32, 0].float()
+        gb = X[lo:lo + 32, 2].to(torch.int64).reshape(-1, 1)
+        stats = {}
+        p = O.ple_forward(s2, xb, fd, 3, training=True, stats_out=stats).gather(1, gb).squeeze(1)
+        loss = O.bce_mean(p, yb) + O.reg_loss(s2, l2)
+        ref_opt.zero_grad()
+        loss.sum().backward()
+        ref_opt.step()
+        want_losses.append(float(loss.sum().detach()))
+        s2.update(stats)
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for a, b in zip(logged, want_losses):
+        assert abs(a - b) < 2e-5 * max(1.0, abs(b)), (logged, want_losses)
+    for k in names:
+        if is_pre_bn_bias(k, names) or "num_batches" in k:
+            continue
+        atol = 5e-4 if k.endswith("running_mean") else 2e-5
+        assert_close(got[k], s2[k].detach(), 5e-4, atol, f"epoch: {k}")
