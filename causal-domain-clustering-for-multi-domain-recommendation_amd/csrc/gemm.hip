@@ -17,6 +17,9 @@ typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 #define GEMM_THREADS 256
+#ifndef CDC_GEMM_PROBE
+#define CDC_GEMM_PROBE 0      /* tools/gemm_probe.hip: 1 = no reloads, 2 = no MFMAs, 4 = no LDS stores, 8 = no epilogue */
+#endif
 #define GEMM_BK 32           // reduction depth staged per barrier pair (64 measured slower: register pressure halves occupancy)
 // LDS row strides chosen so the 16 lanes of a ds_read_b128 group land on disjoint bank quads:
 // bf16: BK + 8 elements (80 B at BK 32, 144 B at BK 64); fp32: BK + 1
@@ -248,13 +251,23 @@ __device__ __forceinline__ void gemm_accumulate(const Operand& A, const Operand&
             if (nfull > 0) { la.load_full(); lb.load_full(); }
             else if (nk > 0) { la.load_tail(0, A.Rn, tid); lb.load_tail(0, A.Rn, tid); }
             for (int kt = 0; kt < nk; ++kt) {
-                la.store(As, S, tid);
-                lb.store(Bs, S, tid);
+                if (!(CDC_GEMM_PROBE & 4) || kt == 0) {
+                    la.store(As, S, tid);
+                    lb.store(Bs, S, tid);
+                }
                 __syncthreads();
-                if (kt + 1 < nfull) { la.load_full(); lb.load_full(); }
-                else if (kt + 1 < nk) { la.load_tail((kt + 1) * BK, A.Rn, tid); lb.load_tail((kt + 1) * BK, A.Rn, tid); }
-                mma_slab<BF16, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
+                if (!(CDC_GEMM_PROBE & 1)) {
+                    if (kt + 1 < nfull) { la.load_full(); lb.load_full(); }
+                    else if (kt + 1 < nk) { la.load_tail((kt + 1) * BK, A.Rn, tid); lb.load_tail((kt + 1) * BK, A.Rn, tid); }
+                }
+                if (!(CDC_GEMM_PROBE & 2)) mma_slab<BF16, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
                 __syncthreads();
+            }
+            if (CDC_GEMM_PROBE & 2) {                      // keep the loads alive when the MFMAs are probed away
+#pragma unroll
+                for (int p = 0; p < LeanStage<BM, BK>::PER; ++p) acc[0][0] += la.v[p];
+#pragma unroll
+                for (int p = 0; p < LeanStage<BN, BK>::PER; ++p) acc[0][0] += lb.v[p];
             }
             return;
         }
@@ -276,6 +289,27 @@ __device__ __forceinline__ void gemm_accumulate(const Operand& A, const Operand&
         __syncthreads();
     }
 }
+
+// ---- epilogue staging: the wave's accumulators go through LDS so that global rows are written as full float4 runs ----
+// (an MFMA accumulator lane owns 4 rows x 1 column: stored directly, every wave store covers four 64-byte pieces of four
+// different rows and every element pays its own 64-bit address arithmetic; the probe build showed that direct epilogue
+// costing 15 of the 37 us of the level-1 launch)
+template <int BM, int BN>
+struct OutTile {
+    static constexpr int CS = BN + 4;                                      // row stride (floats): 16-lane groups land on disjoint banks
+    static constexpr bool staged = (size_t)BM * CS * sizeof(float) <= 48 * 1024;
+    static constexpr int F4_PER_ROW = BN / 4;
+    static constexpr int PER = BM * F4_PER_ROW / GEMM_THREADS;
+    __device__ static __forceinline__ void put(float* ct, const f32x4_t (&acc)[BM / 32][BN / 32], int wm, int wn, int lane) {
+#pragma unroll
+        for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < BN / 32; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ct[(wm + mt * 16 + (lane >> 4) * 4 + r) * CS + wn + nt * 16 + (lane & 15)] = acc[mt][nt][r];
+    }
+};
 
 // XCD-aware block remap (bijective): blocks that share an XCD (bid % 8) get a contiguous run of tiles
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -315,32 +349,66 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    if (CDC_GEMM_PROBE & 8) {
+        if (acc[0][0][0] == 123.456f) G.y[0] = acc[1][1][1];
+        return;
+    }
     const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     uint64_t seed = a.seed;
     if (a.drop_p > 0.f && a.seed_offset_dev) seed += (uint64_t)(uint32_t)(*a.seed_offset_dev) * 0xD1342543DE82EF95ull;
     float* y = G.y + (int64_t)row_lo * G.ldy;
-#pragma unroll
-    for (int mt = 0; mt < BM / 32; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < BN / 32; ++nt) {
-            const int col = j0 + wn + nt * 16 + (lane & 15);
-            if (col >= G.N) continue;
-            const float bv = G.bias ? G.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
-                if (row >= M) continue;
-                float val = acc[mt][nt][r] + bv;
-                if (col < G.act_cols) {
-                    if (a.relu) val = fmaxf(val, 0.f);
-                    if (a.drop_p > 0.f) {
-                        const uint64_t e = ((uint64_t)g << 56) ^ ((uint64_t)(row_lo + row) * (uint64_t)G.N + (uint64_t)col);
-                        val = cdc_uniform(seed, e) < a.drop_p ? 0.f : val * keep_scale;
-                    }
-                }
-                y[(int64_t)row * G.ldy + col] = val;
+    auto finish = [&](float val, int row, int col, float bv) -> float {
+        val += bv;
+        if (col < G.act_cols) {
+            if (a.relu) val = fmaxf(val, 0.f);
+            if (a.drop_p > 0.f) {
+                const uint64_t e = ((uint64_t)g << 56) ^ ((uint64_t)(row_lo + row) * (uint64_t)G.N + (uint64_t)col);
+                val = cdc_uniform(seed, e) < a.drop_p ? 0.f : val * keep_scale;
             }
         }
+        return val;
+    };
+    typedef OutTile<BM, BN> OT;
+    if constexpr (OT::staged) {
+        float* ct = reinterpret_cast<float*>(smem);                      // the operand staging area is free after the last barrier
+        OT::put(ct, acc, wm, wn, lane);
+        __syncthreads();
+        const bool vec = ((((uintptr_t)y) & 15) == 0) && (G.ldy % 4 == 0);
+#pragma unroll
+        for (int p = 0; p < OT::PER; ++p) {
+            const int idx = threadIdx.x + p * GEMM_THREADS;
+            const int lr = idx / OT::F4_PER_ROW, c4 = (idx % OT::F4_PER_ROW) * 4;
+            const int row = i0 + lr, col = j0 + c4;
+            if (row >= M || col >= G.N) continue;
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + lr * OT::CS + c4);
+            float* dst = y + (int64_t)row * G.ldy + col;
+            if (vec && col + 3 < G.N) {
+                f32x4_t o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = finish(v[q], row, col + q, G.bias ? G.bias[col + q] : 0.f);
+                *reinterpret_cast<f32x4_t*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (col + q < G.N) dst[q] = finish(v[q], row, col + q, G.bias ? G.bias[col + q] : 0.f);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < BN / 32; ++nt) {
+                const int col = j0 + wn + nt * 16 + (lane & 15);
+                if (col >= G.N) continue;
+                const float bv = G.bias ? G.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
+                    if (row >= M) continue;
+                    y[(int64_t)row * G.ldy + col] = finish(acc[mt][nt][r], row, col, bv);
+                }
+            }
+    }
 }
 
 // =================================================================================================
@@ -385,22 +453,62 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bw
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     float* dx = O.dx + (int64_t)row_lo * O.lddx;
     const float* mk = O.mask_y ? O.mask_y + (int64_t)row_lo * O.ldmask : nullptr;
+    typedef OutTile<BM, BN> OT;
+    if constexpr (OT::staged) {
+        float* ct = reinterpret_cast<float*>(smem);
+        OT::put(ct, acc, wm, wn, lane);
+        __syncthreads();
+        const bool vec = ((((uintptr_t)dx) & 15) == 0) && (O.lddx % 4 == 0) &&
+                         (!mk || (((((uintptr_t)mk) & 15) == 0) && (O.ldmask % 4 == 0)));
 #pragma unroll
-    for (int mt = 0; mt < BM / 32; ++mt)
+        for (int p = 0; p < OT::PER; ++p) {
+            const int idx = threadIdx.x + p * GEMM_THREADS;
+            const int lr = idx / OT::F4_PER_ROW, c4 = (idx % OT::F4_PER_ROW) * 4;
+            const int row = i0 + lr, col = j0 + c4;
+            if (row >= M || col >= O.K) continue;
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(ct + lr * OT::CS + c4);
+            float* dst = dx + (int64_t)row * O.lddx + col;
+            if (vec && col + 3 < O.K) {
+                if (mk) {
+                    const f32x4_t m4 = *reinterpret_cast<const f32x4_t*>(mk + (int64_t)row * O.ldmask + col);
 #pragma unroll
-        for (int nt = 0; nt < BN / 32; ++nt) {
-            const int col = j0 + wn + nt * 16 + (lane & 15);
-            if (col >= O.K) continue;
+                    for (int q = 0; q < 4; ++q)
+                        if (col + q < O.mask_cols) v[q] = m4[q] > 0.f ? v[q] * a.mask_scale : 0.f;
+                }
+                if (O.accumulate) {
+                    const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dst);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
-                if (row >= M) continue;
-                float val = acc[mt][nt][r];
-                if (mk && col < O.mask_cols) val = mk[(int64_t)row * O.ldmask + col] > 0.f ? val * a.mask_scale : 0.f;
-                float* dst = dx + (int64_t)row * O.lddx + col;
-                *dst = O.accumulate ? *dst + val : val;
+                    for (int q = 0; q < 4; ++q) v[q] = d4[q] + v[q];
+                }
+                *reinterpret_cast<f32x4_t*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (col + q >= O.K) continue;
+                    float val = v[q];
+                    if (mk && col + q < O.mask_cols) val = mk[(int64_t)row * O.ldmask + col + q] > 0.f ? val * a.mask_scale : 0.f;
+                    dst[q] = O.accumulate ? dst[q] + val : val;
+                }
             }
         }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < BM / 32; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < BN / 32; ++nt) {
+                const int col = j0 + wn + nt * 16 + (lane & 15);
+                if (col >= O.K) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + wm + mt * 16 + (lane >> 4) * 4 + r;
+                    if (row >= M) continue;
+                    float val = acc[mt][nt][r];
+                    if (mk && col < O.mask_cols) val = mk[(int64_t)row * O.ldmask + col] > 0.f ? val * a.mask_scale : 0.f;
+                    float* dst = dx + (int64_t)row * O.lddx + col;
+                    *dst = O.accumulate ? *dst + val : val;
+                }
+            }
+    }
 }
 
 // =================================================================================================
@@ -669,7 +777,9 @@ template <bool BF16, int BM, int BN>
 static constexpr size_t lds_bytes() {
     size_t tiles = (size_t)(BM + BN) * LdsElem<BF16, GEMM_BK>::stride * sizeof(typename LdsElem<BF16, GEMM_BK>::type);
     size_t red = (size_t)GEMM_THREADS * 4 * sizeof(float);
-    return tiles > red ? tiles : red;
+    size_t out = OutTile<BM, BN>::staged ? (size_t)BM * OutTile<BM, BN>::CS * sizeof(float) : 0;
+    size_t m = tiles > red ? tiles : red;
+    return m > out ? m : out;
 }
 
 static bool pick_big_tiles(int64_t tiles64) {
