@@ -83,7 +83,11 @@ extern "C" int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32
 #define SORT_THREADS 1024
 #define SORT_CHUNK CDC_SORT_MAX_B        /* keys one workgroup sorts in LDS (16384 x 8 B = 128 KB) */
 
-// bitonic sort of n_pad 64-bit keys in LDS (n_pad a power of two >= SORT_THREADS)
+// bitonic sort of n_pad 64-bit keys in LDS (n_pad a power of two >= SORT_THREADS).
+// A compare-exchange stage with distance j only moves keys inside aligned blocks of 2j keys, and those are handled by j
+// consecutive (virtual) threads: for j <= 32 every block lives inside one wavefront, whose LDS operations execute in issue
+// order — such stages need no workgroup barrier, only a wavefront-scope fence.  Of the 78 stages of a 4096-key sort 27
+// keep their barrier (those with j >= 64, and the last stage before one).
 __device__ __forceinline__ void lds_bitonic_sort(uint64_t* keys, int n_pad, int tid) {
     for (int k = 2; k <= n_pad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -94,9 +98,15 @@ __device__ __forceinline__ void lds_bitonic_sort(uint64_t* keys, int n_pad, int 
                 const uint64_t a = keys[lo], b = keys[hi];
                 if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
             }
-            __syncthreads();
+            const int next_j = j > 1 ? (j >> 1) : k;                     // distance of the stage that reads these keys next
+            if (j >= 64 || next_j >= 64) __syncthreads();
+            else {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
+    __syncthreads();
 }
 
 // head flags + block-wide exclusive scan over n sorted keys (LDS or global): unique rows, segment starts, permutation
@@ -156,44 +166,50 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __r
     dedupe_sorted(keys, B, scan, uniq_row + (int64_t)f * B, seg_start + (int64_t)f * (B + 1), perm + (int64_t)f * B, uniq_cnt + f, tid);
 }
 
-// B > SORT_CHUNK (the gathered batch of an 8-GPU step): (1) each chunk of SORT_CHUNK rows is sorted in LDS and written out,
-// (2) the two sorted runs are merged by rank (keys are unique: the batch row is part of the key), (3) dedupe from global.
+// Chunked path (a scratch buffer is given and B > 1024): one workgroup's LDS moves 16 bytes per key and stage, and a
+// 4096-key sort has 78 stages — a single workgroup per field is bound by its CU's LDS bandwidth (45 us at B = 4096, 26 CUs
+// busy).  So (1) chunks of `chunk` rows are sorted by separate workgroups (fewer stages, more CUs) and written out,
+// (2) the sorted runs are merged by rank — a key's final position is the sum over the runs of the number of smaller keys;
+// keys are unique, the batch row is part of them — and (3) dedupe runs from global memory.
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunk(const int32_t* __restrict__ idx, uint64_t* __restrict__ runs, int32_t B,
-                                                             int32_t F) {
+                                                             int32_t F, int32_t chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
     const int f = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    const int r0 = c * SORT_CHUNK;
-    const int n = min(SORT_CHUNK, B - r0);
-    for (int i = tid; i < SORT_CHUNK; i += SORT_THREADS) {
+    const int r0 = c * chunk;
+    const int n = min(chunk, B - r0);
+    for (int i = tid; i < chunk; i += SORT_THREADS) {
         uint64_t k = ~0ull;
         if (i < n) k = ((uint64_t)(uint32_t)idx[(int64_t)(r0 + i) * F + f] << 32) | (uint32_t)(r0 + i);
         keys[i] = k;
     }
     __syncthreads();
-    lds_bitonic_sort(keys, SORT_CHUNK, tid);
+    lds_bitonic_sort(keys, chunk, tid);
     uint64_t* out = runs + (int64_t)f * B + r0;
     for (int i = tid; i < n; i += SORT_THREADS) out[i] = keys[i];
 }
 __global__ void __launch_bounds__(256) k_merge_runs(const uint64_t* __restrict__ runs, uint64_t* __restrict__ merged, int32_t B,
-                                                    int32_t F) {
+                                                    int32_t F, int32_t chunk) {
     const int64_t total = (int64_t)F * B;
+    const int n_runs = (B + chunk - 1) / chunk;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int f = (int)(t / B);
         const int i = (int)(t - (int64_t)f * B);
-        const uint64_t* a = runs + (int64_t)f * B;             // run 0: [0, n0), run 1: [n0, B)
-        const int n0 = SORT_CHUNK, n1 = B - SORT_CHUNK;
-        const uint64_t* other;
-        int n_other, mine;
-        uint64_t key;
-        if (i < n0) { key = a[i]; other = a + n0; n_other = n1; mine = i; }
-        else        { key = a[i]; other = a; n_other = n0; mine = i - n0; }
-        int lo = 0, hi = n_other;                              // number of keys of the other run that are smaller
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (other[mid] < key) lo = mid + 1; else hi = mid;
+        const uint64_t* a = runs + (int64_t)f * B;
+        const uint64_t key = a[i];
+        const int r = i / chunk;
+        int pos = i - r * chunk;
+        for (int q = 0; q < n_runs; ++q) {
+            if (q == r) continue;
+            const uint64_t* other = a + (int64_t)q * chunk;
+            int lo = 0, hi = min(chunk, B - q * chunk);            // number of keys of run q that are smaller
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (other[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            pos += lo;
         }
-        merged[(int64_t)f * B + mine + lo] = key;
+        merged[(int64_t)f * B + pos] = key;
     }
 }
 __global__ void __launch_bounds__(SORT_THREADS) k_dedupe_merged(const uint64_t* __restrict__ merged, int32_t* __restrict__ uniq_row,
@@ -218,7 +234,7 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (B <= SORT_CHUNK) {
+    if (B <= 1024 || (!scratch && B <= SORT_CHUNK)) {
         int n_pad = SORT_THREADS;   // at least one key per thread keeps the chunking simple
         while (n_pad < B) n_pad <<= 1;
         const size_t lds = (size_t)n_pad * 8 + SORT_THREADS * 4;
@@ -227,12 +243,15 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
         return 0;
     }
     CDC_CHECK_ARG(scratch, CDC_E_BADARG, "embed_sort_dedupe: B > %d needs a scratch buffer of 2*F*B uint64", SORT_CHUNK);
+    int chunk = 1024;                                       // about eight runs, each within one workgroup's LDS
+    while (chunk < SORT_CHUNK && (int64_t)chunk * 8 < B) chunk <<= 1;
+    const int n_runs = (int)cdc_ceil_div(B, chunk);
     uint64_t* runs = scratch;
     uint64_t* merged = scratch + (int64_t)F * B;
-    hipLaunchKernelGGL(k_sort_chunk, dim3(F, 2), dim3(SORT_THREADS), (size_t)SORT_CHUNK * 8, st, idx, runs, (int32_t)B, F);
+    hipLaunchKernelGGL(k_sort_chunk, dim3(F, n_runs), dim3(SORT_THREADS), (size_t)chunk * 8, st, idx, runs, (int32_t)B, F, chunk);
     CDC_LAUNCH_CHECK("embed_sort_chunk");
     int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 8192);
-    hipLaunchKernelGGL(k_merge_runs, dim3(blocks), dim3(256), 0, st, runs, merged, (int32_t)B, F);
+    hipLaunchKernelGGL(k_merge_runs, dim3(blocks), dim3(256), 0, st, runs, merged, (int32_t)B, F, chunk);
     CDC_LAUNCH_CHECK("embed_merge_runs");
     hipLaunchKernelGGL(k_dedupe_merged, dim3(F), dim3(SORT_THREADS), 0, st, merged, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F);
     CDC_LAUNCH_CHECK("embed_dedupe_merged");

@@ -47,7 +47,7 @@ def table_dense_grad(plan, emb_op, table):
     cnt = torch.empty((F,), dtype=torch.int32, device=dev)
     grad = torch.zeros_like(table)
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    scratch = torch.empty((2 * F * B,), dtype=torch.int64, device=dev) if B > L.SORT_MAX_B else None
+    scratch = torch.empty((2 * F * B,), dtype=torch.int64, device=dev) if B > 1024 else None
     L.check(lib.cdc_embed_sort_dedupe(emb_op.idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
                                       None if scratch is None else scratch.data_ptr(), B, F, s), "embed_sort_dedupe")
     g = emb_op.out.grad

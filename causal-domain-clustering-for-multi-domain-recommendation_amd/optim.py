@@ -111,7 +111,7 @@ class FusedAdam:
                   "seg": torch.empty((F, B + 1), dtype=torch.int32, device=dev),
                   "perm": torch.empty((F, B), dtype=torch.int32, device=dev),
                   "cnt": torch.zeros((F,), dtype=torch.int32, device=dev),
-                  "scratch": torch.empty((2 * F * B,), dtype=torch.int64, device=dev) if B > L.SORT_MAX_B else None,
+                  "scratch": torch.empty((2 * F * B,), dtype=torch.int64, device=dev) if B > 1024 else None,
                   "sorted": torch.empty((F * B * D,), dtype=torch.float32, device=dev),
                   "rowgrad": torch.empty((F * B * D,), dtype=torch.float32, device=dev),
                   "side": torch.empty((F * B * 3 * D,), dtype=torch.float32, device=dev) if self.table_mode == "dense" else None}

@@ -63,8 +63,10 @@ int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out
                     int64_t R, void* stream);   /* out-of-range ids: idx_out = -1 (+ err_flag), skipped downstream */
 
 /* Per-field sort + dedupe of the row indices of one batch (rows of different fields never collide, so each field is
- * sorted on its own).  B <= CDC_SORT_MAX_B: one workgroup per field sorts (row<<32|b) in LDS.  B <= CDC_SORT_MAX_ROWS
- * (the gathered batch of an 8-GPU step): two LDS-sorted runs per field, merged by rank; needs `scratch` >= 2*F*B uint64.
+ * sorted on its own).  Keys are (row<<32|b).  Without `scratch` (B <= CDC_SORT_MAX_B): one workgroup per field sorts in
+ * LDS.  With `scratch` >= 2*F*B uint64 (any B <= CDC_SORT_MAX_ROWS; required above CDC_SORT_MAX_B): chunks of 1024..16384
+ * rows are sorted by separate workgroups and the ~8 sorted runs merged by rank — 3x faster at B = 4096, where one
+ * workgroup per field is bound by its CU's LDS bandwidth.  Same output either way.
  *   idx       [B,F] int32 row indices (from cdc_embed_gather_fwd / cdc_embed_index)
  *   uniq_row  [F,B] int32 — field f's unique rows, ascending, first uniq_cnt[f] entries valid
  *   seg_start [F,B+1] int32 — uniq j of field f owns sorted positions [seg_start[f][j], seg_start[f][j+1])

@@ -299,10 +299,14 @@ def test_bce_golden_g7(cuda):
     assert_close(dp.reshape(-1), d["dp"], 1e-5, 0.0, "bce gradient incl. the 1e-12 clamp")
 
 
-@pytest.mark.parametrize("B", [1, 100, 4096, 16384, 16385, 20000, 32768])
-def test_sort_dedupe_against_numpy(cuda, B):
-    """Per-field sort + dedupe (single-workgroup LDS path up to 16384 rows, two merged runs beyond: the gathered batch
-    of an 8-GPU step) — integer work, bit-exact against numpy's stable sort."""
+@pytest.mark.parametrize("with_scratch", [False, True])
+@pytest.mark.parametrize("B", [1, 100, 1024, 1025, 4096, 5000, 16384, 16385, 20000, 32768])
+def test_sort_dedupe_against_numpy(cuda, B, with_scratch):
+    """Per-field sort + dedupe — single-workgroup LDS path (no scratch, up to 16384 rows) and chunked path (sorted runs
+    merged by rank; any size up to 32768 = the gathered batch of an 8-GPU step) — integer work, bit-exact against numpy's
+    stable sort."""
+    if not with_scratch and B > 16384:
+        pytest.skip("needs the scratch buffer")
     import ctypes as C
     from cdcmdr_amd import _lib as L
     lib = L.load()
@@ -315,7 +319,7 @@ def test_sort_dedupe_against_numpy(cuda, B):
     seg = torch.full((F, B + 1), -1, dtype=torch.int32, device=cuda)
     perm = torch.full((F, B), -1, dtype=torch.int32, device=cuda)
     cnt = torch.zeros(F, dtype=torch.int32, device=cuda)
-    scratch = torch.empty(2 * F * B, dtype=torch.int64, device=cuda) if B > L.SORT_MAX_B else None
+    scratch = torch.empty(2 * F * B, dtype=torch.int64, device=cuda) if with_scratch else None
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L.check(lib.cdc_embed_sort_dedupe(d_idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
                                       None if scratch is None else scratch.data_ptr(), B, F, s), "sort")
