@@ -598,17 +598,29 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
         }
 }
 
-__global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a, int64_t slab_stride) {
-    const int g = blockIdx.y;
-    const cdc_bwdw_group& G = a.g[g];
-    int64_t g_off = 0;
-    for (int i = 0; i < g; ++i) g_off += (int64_t)a.g[i].N * a.g[i].K + a.g[i].N;
-    const int64_t nk = (int64_t)G.N * G.K, sz = nk + G.N;
-    for (int64_t local = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; local < sz; local += (int64_t)gridDim.x * blockDim.x) {
+__global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a, int64_t slab_stride, int64_t total) {
+    // one flat index space over all groups: a slab IS the concatenation [dW_0 | db_0 | dW_1 | db_1 | ...]
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        // slabs are added in slice order (deterministic); four loads are in flight per round
         float sum = 0.f;
-        for (int s = 0; s < a.split_k; ++s) sum += a.workspace[(int64_t)s * slab_stride + g_off + local];
+        int s = 0;
+        for (; s + 4 <= a.split_k; s += 4) {
+            const float v0 = a.workspace[(int64_t)s * slab_stride + e], v1 = a.workspace[(int64_t)(s + 1) * slab_stride + e];
+            const float v2 = a.workspace[(int64_t)(s + 2) * slab_stride + e], v3 = a.workspace[(int64_t)(s + 3) * slab_stride + e];
+            sum += v0; sum += v1; sum += v2; sum += v3;
+        }
+        for (; s < a.split_k; ++s) sum += a.workspace[(int64_t)s * slab_stride + e];
+        int g = 0;
+        int64_t local = e;
+        for (; g < a.n_groups; ++g) {
+            const int64_t sz = (int64_t)a.g[g].N * a.g[g].K + a.g[g].N;
+            if (local < sz) break;
+            local -= sz;
+        }
+        const cdc_bwdw_group& G = a.g[g];
+        const int64_t nk = (int64_t)G.N * G.K;
         if (local < nk) {
-            float* dst = G.dw + (local / G.K) * G.lddw + (local % G.K);
+            float* dst = G.lddw == G.K ? G.dw + local : G.dw + (local / G.K) * G.lddw + (local % G.K);
             *dst = G.accumulate ? *dst + sum : sum;
         } else if (G.db) {
             float* dst = G.db + (local - nk);
@@ -919,10 +931,10 @@ extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void*
         hipLaunchKernelGGL((k_glinear_bwd_w<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a, slab);
     CDC_LAUNCH_CHECK("glinear_bwd_w");
     if (S > 1) {
-        int64_t biggest = 0;
-        for (int g = 0; g < a->n_groups; ++g) biggest = std::max<int64_t>(biggest, (int64_t)a->g[g].N * a->g[g].K + a->g[g].N);
-        int blocks = (int)std::min<int64_t>(cdc_ceil_div(biggest, 256), 512);
-        hipLaunchKernelGGL(k_bwd_w_reduce, dim3(blocks, a->n_groups), dim3(256), 0, st, *a, slab);
+        int64_t total = 0;
+        for (int g = 0; g < a->n_groups; ++g) total += (int64_t)a->g[g].N * a->g[g].K + a->g[g].N;
+        int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 4096);
+        hipLaunchKernelGGL(k_bwd_w_reduce, dim3(blocks), dim3(256), 0, st, *a, slab, total);
         CDC_LAUNCH_CHECK("bwd_w_reduce");
     }
     return 0;
