@@ -1,16 +1,21 @@
 """Causal Domain Clustering wrapper on the HIP hot path.
 
-Mirror of the reference's model/cdc.py forward surface (CDC.__init__ 24-93, forward 95-111, get_matrix_metric
-113-119, save/load_model_state 343-354, get_regularization_loss 356-357).  The base model (MMoE / PLE / STAR) runs on
-the HIP kernels; CDC itself only selects a tower output per row.  The clustering control loop (update_group,
-get_source_domain, calc_causal_matrix, kmeans: cdc.py:121-341,359-426 — O(n_domain^2) numpy/scipy/sklearn work on
-30x30 matrices) is NOT part of the hot path and is not rebuilt here."""
+Mirror of the reference's model/cdc.py (CDC.__init__ 24-93, forward 95-111, get_matrix_metric 113-119, update_group
+121-236, get_source_domain 238-293, update_p_weight 295-304, calc_metric_in_source_group 306-310,
+get_center_domain_in_group 312-318, calc_domain_lambda_in_group 320-341, save/load_model_state 343-354,
+get_regularization_loss 356-357, kmeans_group 359-362, calc_causal_matrix 364-396, save_draw_matrix 398-403).
+The base model (MMoE / PLE / STAR) runs on the HIP kernels; CDC itself only selects a tower output per row.  The
+clustering arithmetic (O(n_domain^2) numpy/scipy/sklearn/torch work on 30x30 matrices, host side) lives in
+`clustering.py` and is pinned against the reference's own outputs (tests/test_cdc_group.py)."""
 import copy
+import os
 import re
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import clustering
 from .layer import BaseModel
 from .mmoe import MMoE
 from .ple import PLE
@@ -43,6 +48,8 @@ class CDC(BaseModel):
         self.use_atten = getattr(config, 'use_atten', False)
         self.device = device
         self.config = config
+        # cdc.py:58-60: the regrouping dumps its matrices under result/<dataset>/<folder>; created on first use here
+        self.savefig_path = os.path.join('result', str(getattr(config, 'dataset_name', 'cdc')), savefig_folder)
         self.n_cluster = n_tower
         self.n_causal_mask = n_causal_mask
         self.n_domain = n_domain
@@ -105,6 +112,38 @@ class CDC(BaseModel):
         self.base_model_instance.set_precision(precision)
         return self
 
+    # ---- the regrouping (cdc.py:121-341, 359-403): arithmetic in clustering.py ------------------------------
     def update_group(self, mode='iterative'):
-        raise NotImplementedError("the clustering control loop (cdc.py:121-341) is outside the HIP hot path this round "
-                                  "(SURVEY.md §8f row N1)")
+        return clustering.regroup(self, mode)
+
+    def get_source_domain(self, t_group, group_idx):
+        return clustering.select_source_domains(self, t_group, group_idx)
+
+    def update_p_weight(self):
+        clustering.decay_p_weight(self)
+
+    def calc_metric_in_source_group(self, target_domain, s_group):
+        return clustering.source_group_metric(self, target_domain, s_group)
+
+    def get_center_domain_in_group(self, group, center_num=1):
+        return clustering.group_centers(self.matrix_causal, group, center_num)
+
+    def calc_domain_lambda_in_group(self, group, domain=None, mode='avg_dis'):
+        if mode == 'avg_dis':
+            return clustering.group_lambda(self.matrix_causal, group, domain, self.n_domain)
+
+    @staticmethod
+    def kmeans_group(matrix_causal, n_cluster):
+        return clustering.kmeans_labels(matrix_causal, n_cluster)
+
+    @staticmethod
+    def calc_causal_matrix(X, alpha=None):
+        return clustering.causal_kernel(X, alpha)
+
+    def save_draw_matrix(self, matrix, name, is_illustration=False):
+        """cdc.py:398-403 writes `<name> step-<k>.xlsx` through pandas/openpyxl; the same table goes out as .csv here
+        (openpyxl is not a dependency of this package)."""
+        if isinstance(matrix, torch.Tensor):
+            matrix = matrix.cpu().numpy()
+        os.makedirs(self.savefig_path, exist_ok=True)
+        np.savetxt(os.path.join(self.savefig_path, f'{name} step-{self.call_update_group}.csv'), np.asarray(matrix), delimiter=',')
