@@ -566,6 +566,44 @@ extern "C" int cdc_bce_fwd_bwd(const float* p, int64_t ldp, const int64_t* group
     return 0;
 }
 
+// BCE on the MEAN of the tower probabilities (CDC warm-up, cdc.py:100-102 `torch.mean(y_cat, dim=1)` + run.py:616):
+// loss = mean_b bce(mean_c p[b,c], y[b]); d loss / d p[b,c] = bce'(mean) / n_col for every column.
+__global__ void __launch_bounds__(1024) k_bce_mean(const float* __restrict__ p, int64_t ldp, const int16_t* __restrict__ y_i16,
+                                                   const float* __restrict__ y_f32, float* __restrict__ loss, float* __restrict__ dp,
+                                                   int64_t lddp, int64_t B, int32_t n_col, float inv_count) {
+    double acc = 0.0;
+    const float inv_c = 1.f / (float)n_col;
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        float sum = 0.f;
+        for (int c = 0; c < n_col; ++c) sum += p[b * ldp + c];
+        const float x = sum / (float)n_col;
+        const float t = y_i16 ? (float)y_i16[b] : y_f32[b];
+        const float l = (t - 1.f) * fmaxf(log1pf(-x), -100.f) - t * fmaxf(logf(x), -100.f);
+        acc += (double)l;
+        if (dp) {
+            const float g = inv_count * (x - t) / fmaxf((1.f - x) * x, 1e-12f) * inv_c;
+            for (int c = 0; c < n_col; ++c) dp[b * lddp + c] = g;
+        }
+    }
+    __shared__ double sh[16];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+        *loss = (float)(s * (double)inv_count);
+    }
+}
+extern "C" int cdc_bce_mean_fwd_bwd(const float* p, int64_t ldp, const int16_t* y_i16, const float* y_f32, float* loss, float* dp,
+                                    int64_t lddp, int64_t B, int32_t n_col, float inv_count, void* stream) {
+    CDC_CHECK_ARG(p && loss && (y_i16 || y_f32) && B > 0 && n_col > 0 && ldp >= n_col && (!dp || lddp >= n_col), CDC_E_BADARG,
+                  "bce_mean_fwd_bwd: bad argument");
+    hipLaunchKernelGGL(k_bce_mean, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, ldp, y_i16, y_f32, loss, dp, lddp, B, n_col, inv_count);
+    CDC_LAUNCH_CHECK("bce_mean_fwd_bwd");
+    return 0;
+}
+
 // =================================================================================================
 // DCN-v1 cross layer  (model/layer.py:321-329):  out = x0 * (xl . w) + b + xl
 // =================================================================================================

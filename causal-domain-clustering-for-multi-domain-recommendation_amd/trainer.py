@@ -18,12 +18,15 @@ from .optim import FusedAdam
 
 class TrainStep:
     """mode:
-         "multi"   multi-tower models (PLE / MMoE / CDC): pred = model(X).gather(1, group)        (run.py:481-484)
+         "multi"   multi-tower models (PLE / MMoE / CDC split): pred = model(X).gather(1, group)  (run.py:481-484)
          "single"  DCN / DCNv2: pred = model(X)                                                   (run.py:486-488)
-    """
+         "mean"    CDC warm-up: pred = mean over the towers of model(X)                           (cdc.py:100-102, run.py:616)
+       train_mode=False: the step runs with the module in EVAL mode (BatchNorm on its running statistics, no dropout) but
+       still back-propagates and updates — what the reference's CDC loop does after its first evaluation pass, which
+       leaves the model in eval() (run.py:550-551 sets it, nothing sets it back before the training that follows)."""
 
     def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None, sync_bn=True,
-                 table_dist=None, shard_slack=1.5):
+                 table_dist=None, shard_slack=1.5, train_mode=True):
         """sync_bn (data parallel only): BatchNorm statistics over the GLOBAL batch, as the reference's single process
         computes them — two small all-reduces per BatchNorm launch; False = per-rank statistics.
         table_dist (data parallel only): "sharded" (row r owned by rank r % world; default with the lazy table optimiser)
@@ -37,7 +40,8 @@ class TrainStep:
         self.global_B = self.B * self.world
         dev = optimizer.device
         self.device = dev
-        model.train()
+        self.train_mode = bool(train_mode)
+        assert mode in ("multi", "single", "mean")
         # the plan shares the optimiser's step counter (dropout stream) and its flat gradient arena
         self.holder = self._build_plan()
         self.plan = self.holder.plan
@@ -88,7 +92,8 @@ class TrainStep:
         from . import plan as P
 
         def build():
-            plan = P.Plan(dev, B, precision=model.precision, training=True, dropout=float(getattr(model, "dropout_p", 0.0)),
+            plan = P.Plan(dev, B, precision=model.precision, training=self.train_mode,
+                          dropout=float(getattr(model, "dropout_p", 0.0)) if self.train_mode else 0.0,
                           seed=int(getattr(model, "seed", 0)), step_dev=opt.step_dev, grad_arena=opt.grad_arena,
                           dist=self.dist if self.sync_bn else None)
             emb = model.embedding.describe(plan)
@@ -96,11 +101,21 @@ class TrainStep:
             plan.finalize(outs)
             return PlanHolder(plan, [emb.ids] + ins, outs, emb_op=emb, extra_outputs=extra)
 
-        return model._cache().get(model, ("train_step", id(opt)), B, build)
+        was = model.training
+        model.train(self.train_mode)                 # the ops read module.training while describing themselves
+        try:
+            return model._cache().get(model, ("train_step", id(opt), self.train_mode), B, build)
+        finally:
+            model.train(was)
 
     # ------------------------------------------------------------------------------------------
     def _bce(self):
         og = self.out.grad
+        if self.mode == "mean":
+            L.launch("cdc_bce_mean_fwd_bwd", self.lib.cdc_bce_mean_fwd_bwd,
+                     (self.out.ptr, self.out.ld, self.y.data_ptr(), None, self.loss.data_ptr(), og.ptr, og.ld, self.B, self.out.cols,
+                      1.0 / self.global_B), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return
         L.launch("cdc_bce_fwd_bwd", self.lib.cdc_bce_fwd_bwd,
                  (self.out.ptr, self.out.ld, None if self.group is None else self.group.data_ptr(), self.y.data_ptr(), None,
                   self.loss.data_ptr(), og.ptr, og.ld, self.B, self.out.cols, 1.0 / self.global_B),
@@ -352,7 +367,7 @@ class TrainStep:
         sib = self.__dict__.setdefault("_siblings", {})
         ts = sib.get(int(batch_size))
         if ts is None:
-            ts = TrainStep(self.model, self.opt, int(batch_size), mode=self.mode, use_graph=False)
+            ts = TrainStep(self.model, self.opt, int(batch_size), mode=self.mode, use_graph=False, train_mode=self.train_mode)
             sib[int(batch_size)] = ts
         return ts
 

@@ -411,6 +411,10 @@ int cdc_rowdot_bwd(const cdc_rowdot_bwd_args* a, void* stream);
 int cdc_bce_fwd_bwd(const float* p, int64_t ldp, const int64_t* group, const int16_t* y_i16,
                     const float* y_f32, float* loss, float* dp, int64_t lddp,
                     int64_t B, int32_t n_col, float inv_count, void* stream);
+/* the same on the MEAN over the n_col tower probabilities of a row (CDC warm-up: cdc.py:100-102 + run.py:616-617);
+ * dp[b, c] = bce'(mean_b) / n_col for every column. */
+int cdc_bce_mean_fwd_bwd(const float* p, int64_t ldp, const int16_t* y_i16, const float* y_f32, float* loss, float* dp,
+                         int64_t lddp, int64_t B, int32_t n_col, float inv_count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CrossNetwork (DCN v1) layer (reference: model/layer.py:321-329): out = x0 * (xl·w) + b + xl
