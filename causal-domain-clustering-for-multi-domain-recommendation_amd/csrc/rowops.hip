@@ -51,6 +51,55 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_fwd(const cdc_pool_fw
     }
 }
 
+// The same with 16-byte lanes: a row's H values are covered by H/4 lanes (a power of two), so one wave handles 64/(H/4)
+// rows and every global access is a float4.  Per element the sum over the selected experts keeps its order, so the
+// results equal the scalar kernel's bit for bit.
+typedef float pool_f4 __attribute__((ext_vector_type(4)));
+static bool pool_vec_ok(int H, const void* experts, int64_t ld_exp) {
+    const int gl = H / 4;
+    return H % 4 == 0 && gl >= 1 && gl <= 64 && (gl & (gl - 1)) == 0 && (((uintptr_t)experts & 15) == 0) && ld_exp % 4 == 0;
+}
+__global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_fwd_v4(const cdc_pool_fwd_args a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = a.H / 4, l = lane % gl;
+    const int64_t row = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (64 / gl) + lane / gl;
+    if (row >= a.B) return;
+    const pool_f4* ex = reinterpret_cast<const pool_f4*>(a.experts + row * a.ld_exp);
+    for (int g = 0; g < a.n_gates; ++g) {
+        const auto& G = a.gate[g];
+        const float* lg = G.logits + row * G.ld_logits;
+        float p[CDC_MAX_SEL];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) {
+            p[j] = j < G.n_sel ? lg[j] : -INFINITY;
+            mx = fmaxf(mx, p[j]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) {
+            p[j] = j < G.n_sel ? expf(p[j] - mx) : 0.f;
+            sum += p[j];
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] *= inv;
+        if (G.probs) {
+            for (int j0 = l; j0 < G.n_sel; j0 += gl) {               // the row's lanes share the n_sel stores
+                float pv = 0.f;
+#pragma unroll
+                for (int j = 0; j < CDC_MAX_SEL; ++j) if (j == j0) pv = p[j];
+                G.probs[row * G.n_sel + j0] = pv;
+            }
+        }
+        pool_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j)
+            if (j < G.n_sel) acc += p[j] * ex[(int64_t)G.sel[j] * gl + l];
+        reinterpret_cast<pool_f4*>(G.out + row * G.ld_out)[l] = acc;
+    }
+}
+
 extern "C" int cdc_gate_pool_fwd(const cdc_pool_fwd_args* a, void* stream) {
     CDC_CHECK_ARG(a && a->n_gates > 0 && a->n_gates <= CDC_MAX_GATES && a->n_expert > 0 && a->H > 0 && a->B >= 0 && a->experts,
                   CDC_E_BADARG, "gate_pool_fwd: bad argument");
@@ -61,6 +110,17 @@ extern "C" int cdc_gate_pool_fwd(const cdc_pool_fwd_args* a, void* stream) {
             CDC_CHECK_ARG(a->gate[g].sel[j] >= 0 && a->gate[g].sel[j] < a->n_expert, CDC_E_BADARG, "gate_pool_fwd: gate %d selects expert out of range", g);
     }
     if (a->B == 0) return 0;
+    if (pool_vec_ok(a->H, a->experts, a->ld_exp)) {
+        bool ok = true;
+        for (int g = 0; g < a->n_gates; ++g)
+            ok = ok && (((uintptr_t)a->gate[g].out & 15) == 0) && (a->gate[g].ld_out % 4 == 0);
+        if (ok) {
+            const int rows_per_block = WAVES_PER_BLOCK * (64 / (a->H / 4));
+            hipLaunchKernelGGL(k_gate_pool_fwd_v4, dim3(cdc_ceil_div(a->B, rows_per_block)), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
+            CDC_LAUNCH_CHECK("gate_pool_fwd");
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(k_gate_pool_fwd, dim3(cdc_ceil_div(a->B, WAVES_PER_BLOCK)), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
     CDC_LAUNCH_CHECK("gate_pool_fwd");
     return 0;
@@ -119,6 +179,62 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd(const cdc_pool_bw
     }
 }
 
+// 16-byte-lane form of the backward (see k_gate_pool_fwd_v4): H/4 lanes per row, sub-wave xor reductions for the gate
+// gradients, float4 expert-gradient accumulators in LDS ([expert][lane] per wave).
+__global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd_v4(const cdc_pool_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gl = a.H / 4, l = lane % gl;
+    const int64_t row = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + wave) * (64 / gl) + lane / gl;
+    const bool live = row < a.B;
+    const int64_t r = live ? row : 0;                                     // dead lanes compute on row 0 and store nothing
+    const pool_f4* ex = reinterpret_cast<const pool_f4*>(a.experts + r * a.ld_exp);
+    pool_f4* acc = reinterpret_cast<pool_f4*>(pool_smem) + (int64_t)wave * a.n_expert * 64;
+    for (int e = 0; e < a.n_expert; ++e) acc[e * 64 + lane] = pool_f4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < a.n_gates; ++g) {
+        const auto& G = a.gate[g];
+        const pool_f4 d = reinterpret_cast<const pool_f4*>(G.d_out + r * G.ld_dout)[l];
+        // (1) dp_j = <d_out, expert_sel[j]> over the row; d_logit_j = p_j * (dp_j - sum_k p_k dp_k)
+        float dp[CDC_MAX_SEL];
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) {
+            dp[j] = 0.f;
+            if (j < G.n_sel) {
+                const pool_f4 x = ex[(int64_t)G.sel[j] * gl + l];
+                float part = d[0] * x[0] + d[1] * x[1] + d[2] * x[2] + d[3] * x[3];
+                for (int o = gl >> 1; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                dp[j] = part;
+            }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j)
+            if (j < G.n_sel) dot += G.probs[r * G.n_sel + j] * dp[j];
+        if (live) {
+            for (int j0 = l; j0 < G.n_sel; j0 += gl) {
+                float dpj = 0.f;
+#pragma unroll
+                for (int j = 0; j < CDC_MAX_SEL; ++j) if (j == j0) dpj = dp[j];
+                G.d_logits[r * G.ld_dlogits + j0] = G.probs[r * G.n_sel + j0] * (dpj - dot);
+            }
+        }
+        // (2) every selected expert receives p_j * d_out
+        for (int j = 0; j < G.n_sel; ++j) acc[G.sel[j] * 64 + lane] += G.probs[r * G.n_sel + j] * d;
+    }
+    if (!live) return;
+    pool_f4* dex = reinterpret_cast<pool_f4*>(a.d_experts + r * a.ld_dexp);
+    for (int e = 0; e < a.n_expert; ++e) {
+        pool_f4 v = acc[e * 64 + lane];
+        if (a.mask_relu) {
+            const pool_f4 x = ex[(int64_t)e * gl + l];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = x[q] > 0.f ? v[q] * a.mask_scale : 0.f;
+        }
+        pool_f4* dst = dex + (int64_t)e * gl + l;
+        *dst = a.accumulate ? *dst + v : v;
+    }
+}
+
 extern "C" int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream) {
     CDC_CHECK_ARG(a && a->n_gates > 0 && a->n_gates <= CDC_MAX_GATES && a->n_expert > 0 && a->n_expert <= 2 * CDC_MAX_SEL && a->H > 0 &&
                       a->B >= 0 && a->experts && a->d_experts, CDC_E_BADARG, "gate_pool_bwd: bad argument (n_expert <= 32)");
@@ -126,6 +242,18 @@ extern "C" int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream) {
         CDC_CHECK_ARG(a->gate[g].d_out && a->gate[g].probs && a->gate[g].d_logits && a->gate[g].n_sel > 0 &&
                           a->gate[g].n_sel <= CDC_MAX_SEL, CDC_E_BADARG, "gate_pool_bwd: gate %d malformed", g);
     if (a->B == 0) return 0;
+    if (pool_vec_ok(a->H, a->experts, a->ld_exp) && (((uintptr_t)a->d_experts & 15) == 0) && a->ld_dexp % 4 == 0 && a->n_expert <= 16) {
+        bool ok = true;
+        for (int g = 0; g < a->n_gates; ++g)
+            ok = ok && (((uintptr_t)a->gate[g].d_out & 15) == 0) && (a->gate[g].ld_dout % 4 == 0);
+        if (ok) {
+            const int rows_per_block = WAVES_PER_BLOCK * (64 / (a->H / 4));
+            const size_t lds = (size_t)WAVES_PER_BLOCK * a->n_expert * 64 * sizeof(pool_f4);
+            hipLaunchKernelGGL(k_gate_pool_bwd_v4, dim3(cdc_ceil_div(a->B, rows_per_block)), dim3(ROW_THREADS), lds, (hipStream_t)stream, *a);
+            CDC_LAUNCH_CHECK("gate_pool_bwd");
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(k_gate_pool_bwd, dim3(cdc_ceil_div(a->B, WAVES_PER_BLOCK)), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
     CDC_LAUNCH_CHECK("gate_pool_bwd");
     return 0;
