@@ -826,7 +826,7 @@ extern "C" int cdc_cross_bwd(const float* d_out, int64_t ldo, const float* x0, i
 // =================================================================================================
 // dense-parameter Adam, multi-tensor (run.py:720-721 + the L2 term of model/layer.py:96-112)
 // =================================================================================================
-#define ADAM_CHUNK 1024
+#define ADAM_CHUNK 4096
 __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args a) {
     int chunk = blockIdx.x, ti = 0;
     for (; ti < a.n_tensors; ++ti) {
@@ -844,13 +844,26 @@ __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args 
     const int64_t begin = (int64_t)chunk * ADAM_CHUNK;
     const int64_t end = min(begin + ADAM_CHUNK, T.n);
     double sq = 0.0;
-    for (int64_t i = begin + threadIdx.x; i < end; i += ROW_THREADS) {
-        float w = T.w[i], m = T.m[i], v = T.v[i];
-        float g = T.g ? T.g[i] : 0.f;
-        if (a.grad_scale != 1.f) g *= a.grad_scale;
-        sq += (double)(w * w);
-        adam_elem(w, m, v, g, c, step_size, bc2s);
-        T.w[i] = w; T.m[i] = m; T.v[i] = v;
+    // four elements per round with all their loads issued first; one workgroup covers ADAM_CHUNK elements so that the
+    // launch ends in a few hundred (not thousands of) same-address double atomics for the regularisation sum
+    for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += 4 * ROW_THREADS) {
+        float w[4], m[4], v[4], g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = i0 + (int64_t)q * ROW_THREADS;
+            const bool ok = i < end;
+            w[q] = ok ? T.w[i] : 0.f; m[q] = ok ? T.m[i] : 0.f; v[q] = ok ? T.v[i] : 0.f;
+            g[q] = (ok && T.g) ? T.g[i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t i = i0 + (int64_t)q * ROW_THREADS;
+            if (i >= end) continue;
+            if (a.grad_scale != 1.f) g[q] *= a.grad_scale;
+            sq += (double)(w[q] * w[q]);
+            adam_elem(w[q], m[q], v[q], g[q], c, step_size, bc2s);
+            T.w[i] = w[q]; T.m[i] = m[q]; T.v[i] = v[q];
+        }
     }
     if (a.reg_sum && T.l2 != 0.f) {
         __shared__ double part[WAVES_PER_BLOCK];
