@@ -21,6 +21,8 @@ class TrainStep:
          "multi"   multi-tower models (PLE / MMoE / CDC split): pred = model(X).gather(1, group)  (run.py:481-484)
          "single"  DCN / DCNv2: pred = model(X)                                                   (run.py:486-488)
          "mean"    CDC warm-up: pred = mean over the towers of model(X)                           (cdc.py:100-102, run.py:616)
+         "star"    STAR: pred, y = model(X, group, targets=y) — rows partitioned by domain, every   (run.py:476-479,
+                   partition through its own tower, loss on the group-ordered targets              star.py:109-181)
        train_mode=False: the step runs with the module in EVAL mode (BatchNorm on its running statistics, no dropout) but
        still back-propagates and updates — what the reference's CDC loop does after its first evaluation pass, which
        leaves the model in eval() (run.py:550-551 sets it, nothing sets it back before the training that follows)."""
@@ -41,7 +43,7 @@ class TrainStep:
         dev = optimizer.device
         self.device = dev
         self.train_mode = bool(train_mode)
-        assert mode in ("multi", "single", "mean")
+        assert mode in ("multi", "single", "mean", "star")
         # the plan shares the optimiser's step counter (dropout stream) and its flat gradient arena
         self.holder = self._build_plan()
         self.plan = self.holder.plan
@@ -49,6 +51,12 @@ class TrainStep:
         self.out = self.holder.outputs[0]
         self.y = torch.zeros(self.B, dtype=torch.int16, device=dev)
         self.group = torch.zeros(self.B, dtype=torch.int64, device=dev) if mode == "multi" else None
+        if mode == "star":
+            if self.world > 1:
+                raise NotImplementedError("STAR's per-domain partition under data parallelism")
+            self.group = self.holder.inputs[1]                    # the partition kernel reads the domain of every row here
+            self.order = self.holder.extra_outputs[0]             # row order after the partition (ascending group)
+            self.y_perm = torch.zeros(self.B, dtype=torch.int16, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.reg = torch.zeros((), dtype=torch.float64, device=dev)        # the step's sum(l2*w^2), formed inside the launch sequence
         self.use_graph = use_graph
@@ -97,14 +105,14 @@ class TrainStep:
                           seed=int(getattr(model, "seed", 0)), step_dev=opt.step_dev, grad_arena=opt.grad_arena,
                           dist=self.dist if self.sync_bn else None)
             emb = model.embedding.describe(plan)
-            outs, ins, extra = model.describe(plan, emb)
+            outs, ins, extra = model.describe(plan, emb, grouped=True) if self.mode == "star" else model.describe(plan, emb)
             plan.finalize(outs)
             return PlanHolder(plan, [emb.ids] + ins, outs, emb_op=emb, extra_outputs=extra)
 
         was = model.training
         model.train(self.train_mode)                 # the ops read module.training while describing themselves
         try:
-            return model._cache().get(model, ("train_step", id(opt), self.train_mode), B, build)
+            return model._cache().get(model, ("train_step", id(opt), self.train_mode, self.mode == "star"), B, build)
         finally:
             model.train(was)
 
@@ -116,8 +124,12 @@ class TrainStep:
                      (self.out.ptr, self.out.ld, self.y.data_ptr(), None, self.loss.data_ptr(), og.ptr, og.ld, self.B, self.out.cols,
                       1.0 / self.global_B), C.c_void_p(torch.cuda.current_stream().cuda_stream))
             return
+        y, group = self.y, self.group
+        if self.mode == "star":                                   # targets[order] (star.py:181), one column
+            torch.index_select(self.y, 0, self.order.long(), out=self.y_perm)
+            y, group = self.y_perm, None
         L.launch("cdc_bce_fwd_bwd", self.lib.cdc_bce_fwd_bwd,
-                 (self.out.ptr, self.out.ld, None if self.group is None else self.group.data_ptr(), self.y.data_ptr(), None,
+                 (self.out.ptr, self.out.ld, None if group is None else group.data_ptr(), y.data_ptr(), None,
                   self.loss.data_ptr(), og.ptr, og.ld, self.B, self.out.cols, 1.0 / self.global_B),
                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
 

@@ -254,3 +254,56 @@ def test_train_epoch_over_a_device_loader_with_a_ragged_last_batch(cuda):
             continue
         atol = 5e-4 if k.endswith("running_mean") else 2e-5
         assert_close(got[k], s2[k].detach(), 5e-4, atol, f"epoch: {k}")
+
+
+def test_star_fast_path_matches_the_oracle(cuda):
+    """TrainStep(mode="star"): rows partitioned by domain, every partition through its own tower + the shared one
+    (star.py:109-181), BCE on the group-ordered targets (run.py:476-479) — two steps against the oracle's grouped forward
+    driven by torch autograd + torch.optim.Adam; one of the five domains has no row in the second batch."""
+    from cdcmdr_amd.model.star import STAR
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [7, 400, 3, 50, 5, 29]
+    torch.manual_seed(9)
+    model = STAR(fd, 4, 5, (32, 16, 8), domain_idx=4, dropout=0.0).to(cuda).set_precision("f32")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    opt = FusedAdam(model, table_mode="dense")
+    ts = TrainStep(model, opt, 96, mode="star")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    s2 = dict(sd)
+    s2.update(leaves)
+    l2 = {k: 1e-5 for k in O.reg_names(list(sd), "star")}
+    ref_opt = torch.optim.Adam(list(leaves.values()), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    rng = np.random.default_rng(6)
+    names = set(sd)
+    for step in range(2):
+        X = make_ids(rng, 96, fd)
+        if step == 1:
+            X[X[:, 4] == 3, 4] = 2                                  # domain 3 absent
+        y = rng.integers(0, 2, size=96).astype(np.int16)
+        g = X[:, 4].astype(np.int64)
+        bce, _ = ts.step(torch.from_numpy(X).to(cuda), torch.from_numpy(y).to(cuda), torch.from_numpy(g).to(cuda))
+        stats = {}
+        p, t = O.star_forward(s2, X, fd, 5, x_group=g, targets=torch.from_numpy(y).float(), training=True, stats_out=stats)
+        loss = O.bce_mean(p.squeeze(1), t) + O.reg_loss(s2, l2)
+        ref_opt.zero_grad()
+        loss.sum().backward()
+        if step == 0:
+            used = {k for k, leaf in leaves.items() if leaf.grad is not None}      # every domain is present in batch 0
+        for k, leaf in leaves.items():
+            # the reference runs an absent domain's tower on an empty tensor: its parameters get exact ZERO gradients
+            # (tests/golden/g4), so Adam still moves them (momentum, weight decay) — the oracle's forward skips the tower.
+            # Parameters the forward never touches (shared_dnn's own BatchNorm) keep grad None on both sides.
+            if leaf.grad is None and k in used:
+                leaf.grad = torch.zeros_like(leaf)
+        ref_opt.step()
+        s2.update(stats)
+        assert abs(float(bce.item()) - float(O.bce_mean(p.squeeze(1), t).detach())) < 2e-5
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k in names:
+        if "num_batches" in k or is_pre_bn_bias(k, names):
+            continue
+        if k == "shared_bn_bias" or (k.startswith("domain_norm.") and k.endswith(".bias")):
+            continue        # a constant added in front of Linear -> BatchNorm: zero gradient up to rounding noise, like a pre-BN bias
+        atol = 5e-4 if k.endswith("running_mean") else 2e-5
+        assert_close(got[k], s2[k].detach(), 5e-4, atol, f"star step: {k}")
