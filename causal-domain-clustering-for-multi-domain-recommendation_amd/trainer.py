@@ -52,8 +52,6 @@ class TrainStep:
         self.y = torch.zeros(self.B, dtype=torch.int16, device=dev)
         self.group = torch.zeros(self.B, dtype=torch.int64, device=dev) if mode == "multi" else None
         if mode == "star":
-            if self.world > 1:
-                raise NotImplementedError("STAR's per-domain partition under data parallelism")
             self.group = self.holder.inputs[1]                    # the partition kernel reads the domain of every row here
             self.order = self.holder.extra_outputs[0]             # row order after the partition (ascending group)
             self.y_perm = torch.zeros(self.B, dtype=torch.int16, device=dev)

@@ -36,7 +36,15 @@ def _data(world):
     return X, y, g
 
 
-def _single_process_reference(table_mode):
+def _build(kind, dev):
+    if kind == "star":
+        from cdcmdr_amd.model.star import STAR
+        return STAR(FD, 8, 3, (32, 16), domain_idx=4, dropout=0.0).to(dev).set_precision("f32"), "star"
+    from cdcmdr_amd.model.mmoe import MMoE
+    return MMoE(FD, 8, 3, 4, (32, 16), (8,), dropout=0.0).to(dev).set_precision("f32"), "multi"
+
+
+def _single_process_reference(table_mode, kind="mmoe"):
     """the same global batches through ONE rank (what the reference's single process would see)"""
     sys.path.insert(0, ROOT)
     from cdcmdr_amd.model.mmoe import MMoE
@@ -44,10 +52,10 @@ def _single_process_reference(table_mode):
     from cdcmdr_amd.trainer import TrainStep
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
-    model = MMoE(FD, 8, 3, 4, (32, 16), (8,), dropout=0.0).to(dev).set_precision("f32")
+    model, mode = _build(kind, dev)
     opt = FusedAdam(model, table_mode=table_mode, flush_every=2)
     gb = B_LOCAL * 2
-    ts = TrainStep(model, opt, gb)
+    ts = TrainStep(model, opt, gb, mode=mode)
     X, y, g = _data(2)
     losses = []
     for s in range(STEPS):
@@ -58,7 +66,7 @@ def _single_process_reference(table_mode):
     return {k: v.cpu() for k, v in model.state_dict().items()}, losses
 
 
-def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_bn=True):
+def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_bn=True, kind="mmoe"):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     sys.path.insert(0, ROOT)
     from cdcmdr_amd.dist import DataParallel
@@ -68,9 +76,9 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_
     dev = torch.device("cuda:0")
     dp = DataParallel(backend="gloo")
     torch.manual_seed(5)
-    model = MMoE(FD, 8, 3, 4, (32, 16), (8,), dropout=0.0).to(dev).set_precision("f32")
+    model, mode = _build(kind, dev)
     opt = FusedAdam(model, table_mode=table_mode, flush_every=2)
-    ts = TrainStep(model, opt, B_LOCAL, use_graph=use_graph, dist=dp, table_dist=table_dist, sync_bn=sync_bn)
+    ts = TrainStep(model, opt, B_LOCAL, mode=mode, use_graph=use_graph, dist=dp, table_dist=table_dist, sync_bn=sync_bn)
     assert ts.table_dist == (table_dist or ("sharded" if table_mode == "lazy" else "replicated"))
     X, y, g = _data(world)
     gb = B_LOCAL * world
@@ -153,3 +161,26 @@ def test_two_ranks_with_per_rank_batchnorm_statistics(cuda, tmp_path):
         bce, _ = ts.step(torch.from_numpy(X[sl]).to(cuda), torch.from_numpy(y[sl]).to(cuda), torch.from_numpy(g[sl]).to(cuda))
         shard_losses.append(float(bce.item()))
     assert abs(r0["losses"][0] - float(np.mean(shard_losses))) < 2e-6
+
+
+def test_two_ranks_star_partitioned_towers(cuda, tmp_path):
+    """BASELINE config C5's shape of problem: STAR (rows partitioned by domain, ragged per-domain BatchNorm groups) under data
+    parallelism with the row-sharded table and global-batch statistics: replicas identical, and equal to the single-process
+    step on the concatenated batch."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "lazy", False, "sharded", True, "star"), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
+    assert r0["losses"] == r1["losses"] and all(np.isfinite(r0["losses"]))
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), f"replicas diverged in {k}"
+    from helpers import assert_close, is_pre_bn_bias
+    ref_sd, ref_losses = _single_process_reference("lazy", "star")
+    for a, b in zip(r0["losses"], ref_losses):
+        assert abs(a - b) < 2e-5, (r0["losses"], ref_losses)
+    names = set(ref_sd)
+    for k, v in ref_sd.items():
+        if is_pre_bn_bias(k, names) or "num_batches" in k or k == "shared_bn_bias" or (k.startswith("domain_norm.") and k.endswith(".bias")):
+            continue
+        atol = 5e-4 if k.endswith("running_mean") else 2e-5
+        assert_close(r0["sd"][k], v, 5e-4, atol, f"star 2-rank vs 1-rank: {k}")
