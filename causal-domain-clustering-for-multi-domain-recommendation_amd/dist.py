@@ -88,6 +88,20 @@ class DataParallel:
             out.copy_(inp)
         return out
 
+    def all_to_all_start(self, out, inp):
+        """all_to_all whose completion the caller awaits later with wait(): over RCCL the exchange runs on the
+        communicator's stream while the launches issued in between run on the compute stream.  Host-staged backends (the
+        gloo rehearsal) complete at once and return None."""
+        if self.world_size > 1 and not self._staged(out) and self.backend != "gloo":
+            return dist.all_to_all_single(out, inp, async_op=True)
+        self.all_to_all(out, inp)
+        return None
+
+    @staticmethod
+    def wait(handle):
+        if handle is not None:
+            handle.wait()                      # orders the current stream after the collective; does not block the host
+
     def barrier(self):
         if self.world_size > 1:
             dist.barrier()

@@ -322,9 +322,12 @@ class Plan:
         dw = self._emit_deferred_dw()
         if self._gemm_ws.numel() < self._gemm_ws_need:
             self._gemm_ws = torch.empty(self._gemm_ws_need, dtype=torch.float32, device=self.device)
+        self.deferred_dw_steps = []          # the tail of bwd_steps nothing else in the backward depends on
         for a, fl in dw:
             a.workspace = self._gemm_ws.data_ptr()
-            self.bwd_steps.append(self.call("cdc_glinear_bwd_w", C.byref(a), self.prec, flops=fl))
+            step = self.call("cdc_glinear_bwd_w", C.byref(a), self.prec, flops=fl)
+            self.bwd_steps.append(step)
+            self.deferred_dw_steps.append(step)
         self.bwd_steps[0:0] = self._emit_transposes()
         self.finalized = True
 

@@ -89,6 +89,11 @@ class TrainStep:
             self.grads_recv = torch.zeros((N, cap, F * D), dtype=torch.float32, **z)
             self.zero_offsets = torch.zeros(F, dtype=torch.int32, **z)
             optimizer.own_mod, optimizer.own_rem = N, dist.rank
+            # the loss scalar sits right behind the used part of the flat gradient arena: one all-reduce covers both
+            used = max(self.plan._arena_used, 1)
+            assert optimizer.grad_arena.numel() > used
+            self.arena_and_loss = optimizer.grad_arena[:used + 1]
+            self.loss = optimizer.grad_arena[used:used + 1]
 
     def _build_plan(self):
         model, opt = self.model, self.opt
@@ -236,10 +241,15 @@ class TrainStep:
                      (ws["rowgrad"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.slot_of.data_ptr(),
                       self.grads_send.data_ptr(), B, F, D, N, cap), st())
 
-        def exchange():
-            dp.all_to_all(self.grads_recv, self.grads_send)
-            dp.all_reduce_sum(opt.grad_arena[:max(plan._arena_used, 1)])
-            dp.all_reduce_sum(self.loss)
+        pending = {}
+
+        def exchange_rows_start():
+            # the row gradients travel while the grad-weight launches (which nothing here depends on) run
+            pending["grads"] = dp.all_to_all_start(self.grads_recv, self.grads_send)
+
+        def exchange_finish():
+            dp.wait(pending.pop("grads", None))
+            dp.all_reduce_sum(self.arena_and_loss)                      # dense gradients + the loss scalar behind them
 
         def update():
             opt.table_step(self.recv_ids, self.grads_recv, Bv, F, D, "owner")
@@ -260,9 +270,11 @@ class TrainStep:
         for is_comm, steps in plan.segments(fwd):
             seq.append((is_comm, run_steps(steps)))
         seq.append((False, self._bce))
-        for is_comm, steps in plan.segments(plan.bwd_steps):
+        late = set(id(s_) for s_ in plan.deferred_dw_steps)
+        for is_comm, steps in plan.segments([s_ for s_ in plan.bwd_steps if id(s_) not in late]):
             seq.append((is_comm, run_steps(steps)))
-        seq += [(False, pack), (True, exchange), (False, update)]
+        seq += [(False, pack), (True, exchange_rows_start), (False, run_steps(plan.deferred_dw_steps)), (True, exchange_finish),
+                (False, update)]
         merged = []
         for is_comm, fn in seq:
             if merged and not is_comm and not merged[-1][0]:
