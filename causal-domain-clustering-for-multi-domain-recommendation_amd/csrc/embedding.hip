@@ -226,6 +226,7 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
     CDC_CHECK_ARG(idx && uniq_row && seg_start && perm && uniq_cnt, CDC_E_BADARG, "embed_sort_dedupe: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0, CDC_E_BADARG, "embed_sort_dedupe: bad sizes");
     CDC_CHECK_ARG(B <= CDC_SORT_MAX_ROWS, CDC_E_TOOBIG, "embed_sort_dedupe: B=%ld exceeds %d", (long)B, CDC_SORT_MAX_ROWS);
+    CDC_CHECK_ARG(scratch || B <= SORT_CHUNK, CDC_E_BADARG, "embed_sort_dedupe: B > %d needs a scratch buffer of 2*F*B uint64", SORT_CHUNK);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_sort_dedupe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -242,7 +243,6 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
         CDC_LAUNCH_CHECK("embed_sort_dedupe");
         return 0;
     }
-    CDC_CHECK_ARG(scratch, CDC_E_BADARG, "embed_sort_dedupe: B > %d needs a scratch buffer of 2*F*B uint64", SORT_CHUNK);
     int chunk = 1024;                                       // about eight runs, each within one workgroup's LDS
     while (chunk < SORT_CHUNK && (int64_t)chunk * 8 < B) chunk <<= 1;
     const int n_runs = (int)cdc_ceil_div(B, chunk);

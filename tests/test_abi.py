@@ -154,3 +154,30 @@ def test_compat_package_serves_the_reference_import_names():
             "import cdcmdr_amd.model.ple as m; assert PLE is m.PLE; print('ok')") % (os.path.join(ROOT, "compat"), ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_entry_points_reject_bad_arguments_without_touching_the_device():
+    """Every entry point validates its arguments before any launch: a negative return code and a message from
+    cdc_last_error(), no GPU needed (and none used: this runs in the CPU-only container)."""
+    from cdcmdr_amd import _lib
+    lib = _lib.load()
+    rc = lib.cdc_embed_gather_fwd(None, None, None, None, None, None, 4, 3, 8, 100, None)
+    assert rc < 0 and b"null pointer" in lib.cdc_last_error()
+    one = C.c_void_p(16)                                    # a non-null address that is never dereferenced on the host
+    rc = lib.cdc_embed_gather_fwd(one, one, one, one, None, None, 4, 0, 8, 100, None)
+    assert rc < 0 and b"bad sizes" in lib.cdc_last_error()
+    rc = lib.cdc_embed_sort_dedupe(one, one, one, one, one, None, 40000, 3, None)
+    assert rc < 0 and b"exceeds" in lib.cdc_last_error()
+    rc = lib.cdc_embed_sort_dedupe(one, one, one, one, one, None, 20000, 3, None)
+    assert rc < 0 and b"scratch" in lib.cdc_last_error()
+    a = _lib.LinFwdArgs()
+    a.n_groups = 0
+    assert lib.cdc_glinear_fwd(C.byref(a), 0, None) < 0
+    a.n_groups = 1
+    a.drop_p = 1.5
+    assert lib.cdc_glinear_fwd(C.byref(a), 0, None) < 0 and b"dropout" in lib.cdc_last_error()
+    assert lib.cdc_bce_fwd_bwd(None, 1, None, None, None, None, None, 1, 4, 1, 1.0, None) < 0
+    assert lib.cdc_eval_metrics(one, one, None, 0, 10, 3, one, one, None, one, 1 << 20, None) < 0      # n_domain > 1 needs the domain column
+    assert lib.cdc_shard_bucket(one, one, one, one, one, 64, 3, 99, 8, None) < 0                       # more ranks than supported
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "probe")
