@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="diagnostic, single process: run ONE rank's launch work of a W-rank step with the collectives replaced "
                          "by local copies (timing of the compute side only; the numbers it trains on are meaningless)")
+    ap.add_argument("--flush-every", type=int, default=64, help="lazy table: the whole table is replayed once per this many steps")
     ap.add_argument("--pool", type=int, default=0,
                     help="resident synthetic batches cycled through; 0 = warmup+steps (max 1024), so that no batch repeats and "
                          "the lazy table replay sees realistic gaps between two look-ups of a row")
@@ -164,7 +165,8 @@ def main():
     model, field_dims = build_model(args, device)
     table_mode = args.table_mode
     use_graph = bool(args.graph)        # under DP the three launch stages between the collectives are graphs
-    opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode)
+    opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode,
+                    flush_every=args.flush_every)
     ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dp or sim, sync_bn=bool(args.sync_bn),
                    table_dist=args.table_dist)
 
