@@ -733,6 +733,66 @@ extern "C" int cdc_bce_mean_fwd_bwd(const float* p, int64_t ldp, const int16_t* 
 }
 
 // =================================================================================================
+// second-order factorisation-machine term (model/layer.py:160-175, reduce_sum=True):
+//   out[b] = 0.5 * sum_d ( (sum_f e[b,f,d])^2 - sum_f e[b,f,d]^2 )        d out / d e[b,f,d] = sum_f' e[b,f',d] - e[b,f,d]
+// one wave per row; lane l owns dimension d = l (+64, ...); the field sums run in field order like torch.sum(dim=1)
+// =================================================================================================
+__global__ void __launch_bounds__(ROW_THREADS) k_fm_fwd(const float* __restrict__ e, int64_t lde, float* __restrict__ out, int64_t ldo,
+                                                        int64_t B, int32_t F, int32_t D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* er = e + row * lde;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        float s = 0.f, q = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float v = er[f * D + d];
+            s += v;
+            q += v * v;
+        }
+        acc += s * s - q;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row * ldo] = 0.5f * acc;
+}
+__global__ void __launch_bounds__(ROW_THREADS) k_fm_bwd(const float* __restrict__ e, int64_t lde, const float* __restrict__ dout,
+                                                        int64_t ldd, float* __restrict__ de, int64_t ldde, int64_t B, int32_t F,
+                                                        int32_t D, int32_t accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* er = e + row * lde;
+    float* dr = de + row * ldde;
+    const float g = dout[row * ldd];
+    for (int d = lane; d < D; d += 64) {
+        float s = 0.f;
+        for (int f = 0; f < F; ++f) s += er[f * D + d];
+        for (int f = 0; f < F; ++f) {
+            const float v = g * (s - er[f * D + d]);
+            dr[f * D + d] = accumulate ? dr[f * D + d] + v : v;
+        }
+    }
+}
+extern "C" int cdc_fm_fwd(const float* e, int64_t lde, float* out, int64_t ldo, int64_t B, int32_t F, int32_t D, void* stream) {
+    CDC_CHECK_ARG(e && out && B >= 0 && F > 0 && D > 0 && lde >= (int64_t)F * D && ldo >= 1, CDC_E_BADARG, "fm_fwd: bad argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_fm_fwd, dim3(cdc_ceil_div(B, WAVES_PER_BLOCK)), dim3(ROW_THREADS), 0, (hipStream_t)stream, e, lde, out, ldo, B, F, D);
+    CDC_LAUNCH_CHECK("fm_fwd");
+    return 0;
+}
+extern "C" int cdc_fm_bwd(const float* e, int64_t lde, const float* dout, int64_t ldd, float* de, int64_t ldde, int64_t B, int32_t F,
+                          int32_t D, int32_t accumulate, void* stream) {
+    CDC_CHECK_ARG(e && dout && de && B >= 0 && F > 0 && D > 0 && lde >= (int64_t)F * D && ldde >= (int64_t)F * D && ldd >= 1, CDC_E_BADARG,
+                  "fm_bwd: bad argument");
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(k_fm_bwd, dim3(cdc_ceil_div(B, WAVES_PER_BLOCK)), dim3(ROW_THREADS), 0, (hipStream_t)stream, e, lde, dout, ldd, de, ldde,
+                       B, F, D, accumulate);
+    CDC_LAUNCH_CHECK("fm_bwd");
+    return 0;
+}
+
+// =================================================================================================
 // DCN-v1 cross layer  (model/layer.py:321-329):  out = x0 * (xl . w) + b + xl
 // =================================================================================================
 __global__ void __launch_bounds__(ROW_THREADS) k_cross_fwd(const float* __restrict__ x0, int64_t ld0, const float* __restrict__ xl,

@@ -1003,6 +1003,29 @@ class Tanh:
                                         C.c_int64(xg.ld), C.c_int64(self.x.rows), self.x.cols, 1 if acc else 0))
 
 
+class FMInteraction:
+    """Second-order FM term over the gathered embeddings (model/layer.py:160-175): [B, F*D] -> [B, 1]."""
+
+    def __init__(self, plan, x, n_fields, dim, out=None):
+        assert x.cols == n_fields * dim
+        self.x, self.F, self.D = x, n_fields, dim
+        self.out = out if out is not None else plan.new(1, rows=x.rows)
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        plan.fwd_steps.append(plan.call("cdc_fm_fwd", self.x.cptr(), C.c_int64(self.x.ld), self.out.cptr(), C.c_int64(self.out.ld),
+                                        C.c_int64(self.x.rows), self.F, self.D))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        if self.x.mask is not None:
+            raise RuntimeError("the FM term cannot consume an activation-fused linear output")
+        acc = gs.claim(self.x)
+        og, xg = self.out.grad, self.x.grad
+        plan.bwd_steps.append(plan.call("cdc_fm_bwd", self.x.cptr(), C.c_int64(self.x.ld), og.cptr(), C.c_int64(og.ld), xg.cptr(),
+                                        C.c_int64(xg.ld), C.c_int64(self.x.rows), self.F, self.D, 1 if acc else 0))
+
+
 class MatmulRight:
     """y_g = x_g @ M_g with M_g stored [K, N] row-major (CrossNetMix's V: model/layer.py:384 `v_list[i][k].t() @ x`).
     The three contractions reuse the grouped-linear kernels with the operand roles rotated."""

@@ -416,6 +416,13 @@ int cdc_bce_fwd_bwd(const float* p, int64_t ldp, const int64_t* group, const int
 int cdc_bce_mean_fwd_bwd(const float* p, int64_t ldp, const int16_t* y_i16, const float* y_f32, float* loss, float* dp,
                          int64_t lddp, int64_t B, int32_t n_col, float inv_count, void* stream);
 
+/* Second-order factorisation-machine term (reference: model/layer.py:160-175 FactorizationMachine(reduce_sum=True), used by
+ * model/dfm.py:33): e [B, F*D] gathered embeddings; out[b] = 0.5 * sum_d((sum_f e)^2 - sum_f e^2);
+ * de[b,f,d] (+)= dout[b] * (sum_f' e[b,f',d] - e[b,f,d]). */
+int cdc_fm_fwd(const float* e, int64_t lde, float* out, int64_t ldo, int64_t B, int32_t F, int32_t D, void* stream);
+int cdc_fm_bwd(const float* e, int64_t lde, const float* dout, int64_t ldd, float* de, int64_t ldde, int64_t B, int32_t F,
+               int32_t D, int32_t accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * CrossNetwork (DCN v1) layer (reference: model/layer.py:321-329): out = x0 * (xl·w) + b + xl
  * ---------------------------------------------------------------------------------------- */

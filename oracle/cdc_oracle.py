@@ -246,6 +246,19 @@ def dcn_forward(sd, x_i32, field_dims, training=True, stats_out=None):
     return torch.sigmoid(wide_logit(e, sd) + stack @ sd["mlp_linear.weight"].t()).squeeze(1)
 
 
+def fm_term(e3):
+    """FactorizationMachine(reduce_sum=True) (model/layer.py:160-175) on [B, F, D]."""
+    return 0.5 * ((e3.sum(dim=1) ** 2 - (e3 ** 2).sum(dim=1)).sum(dim=1, keepdim=True))
+
+
+def deepfm_forward(sd, x_i32, field_dims, training=True, stats_out=None):
+    """DeepFM.forward (model/dfm.py:29-35): sigmoid(linear(e) + fm(e) + mlp(e)), the MLP ending in Linear(-> 1)."""
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    D = sd["embedding.embedding_dict.weight"].shape[1]
+    deep = mlp(e, sd, "mlp", training, stats_out, output_layer=True)
+    return torch.sigmoid(wide_logit(e, sd) + fm_term(e.reshape(e.shape[0], -1, D)) + deep).squeeze(1)
+
+
 def dcnv2_forward(sd, x_i32, field_dims, training=True, stats_out=None, model_structure="parallel"):
     e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
     if "crossnet.u_list.0" in sd:
@@ -362,6 +375,8 @@ def reg_names(names, model_kind):
         elif model_kind == "mmoe" and top in ("experts", "towers") and "weight" in rel and "bn" not in rel:
             out.append(n)
         elif model_kind == "dcn" and top in ("mlp", "cn") and "weight" in rel and "bn" not in rel:
+            out.append(n)
+        elif model_kind == "deepfm" and top == "mlp" and "weight" in rel and "bn" not in rel:
             out.append(n)
         elif model_kind == "dcnv2":
             if top == "dnn" and "weight" in rel and "bn" not in rel:

@@ -42,6 +42,7 @@ def build(name):
         "g2_dcnv2_stacked": lambda: DCNv2(FD13, 4, 2, (32, 16), dropout=0.0, model_structure="stacked", low_rank=8),
         "g2_star5_all": lambda: STAR(FD, 4, 5, (32, 16, 8), dropout=0.0),
         "g2_star30_all": lambda: STAR(FD, 4, 30, (16, 8), dropout=0.0),
+        "g11_deepfm": lambda: __import__("cdcmdr_amd.model.dfm", fromlist=["DeepFM"]).DeepFM(FD13, 4, (32, 16, 8), dropout=0.0),
     }[name]()
 
 
@@ -67,7 +68,7 @@ def check_grads(model, d, names):
 
 
 @pytest.mark.parametrize("name", ["g2_ple3", "g2_mmoe4", "g2_mmoe8", "g2_dcn13", "g2_dcnv2_mix", "g2_dcnv2_stacked",
-                                  "g2_star5_all", "g2_star30_all"])
+                                  "g2_star5_all", "g2_star30_all", "g11_deepfm"])
 def test_model_matches_reference_golden(cuda, name):
     d = load(name)
     model = build(name).to(cuda).set_precision("f32")
@@ -213,3 +214,24 @@ def test_batch_of_one_golden(cuda):
     with pytest.raises(Exception) as e:
         m(torch.from_numpy(d["x13"]).to(cuda))
     assert type(e.value).__name__ == str(d["dcnv2mix_b1_error"])
+
+
+def test_fm_term_golden(cuda):
+    """cdc_fm_fwd / cdc_fm_bwd against the reference's FactorizationMachine(reduce_sum=True) (model/layer.py:160-175)."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    d = load("g11_deepfm")
+    e = torch.from_numpy(d["fm_in"]).to(cuda)
+    B, F, D = e.shape
+    e2 = e.reshape(B, F * D).contiguous()
+    out = torch.empty((B, 1), dtype=torch.float32, device=cuda)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.cdc_fm_fwd(e2.data_ptr(), F * D, out.data_ptr(), 1, B, F, D, s), "fm_fwd")
+    assert_close(out, d["fm_out"], 1e-5, 1e-6, "fm_out")
+    de = torch.full((B, F * D), 7.0, dtype=torch.float32, device=cuda)
+    ones = torch.ones((B, 1), dtype=torch.float32, device=cuda)
+    L.check(lib.cdc_fm_bwd(e2.data_ptr(), F * D, ones.data_ptr(), 1, de.data_ptr(), F * D, B, F, D, 0, s), "fm_bwd")
+    assert_close(de.reshape(B, F, D), d["fm_grad"], 1e-5, 1e-6, "fm_grad")
+    L.check(lib.cdc_fm_bwd(e2.data_ptr(), F * D, ones.data_ptr(), 1, de.data_ptr(), F * D, B, F, D, 1, s), "fm_bwd(acc)")
+    assert_close(de.reshape(B, F, D), 2 * d["fm_grad"], 1e-5, 1e-6, "fm_grad accumulated")

@@ -48,6 +48,7 @@ MODELS = {
     "g2_dcnv2_stacked": ("dcnv2", lambda sd, x, tr, so: O.dcnv2_forward(sd, x, FD13, tr, so, model_structure="stacked")),
     "g2_star5_all": ("star", lambda sd, x, tr, so: O.star_forward(sd, x, FD, 5, training=tr, stats_out=so)),
     "g2_star30_all": ("star", lambda sd, x, tr, so: O.star_forward(sd, x, FD, 30, training=tr, stats_out=so)),
+    "g11_deepfm": ("deepfm", lambda sd, x, tr, so: O.deepfm_forward(sd, x, FD13, tr, so)),
 }
 FD = [7, 100, 3, 50, 11, 29]
 FD13 = [11, 50, 7, 100, 3, 29, 64, 5, 17, 200, 9, 31, 13]
