@@ -341,10 +341,24 @@ def cdc_forward(base_forward, x_i32, domain2group, domain_idx, mode="split", dom
 # --------------------------------------------------------------------------------------------------
 # loss, regularisation, optimiser  (run.py:484-492, 720-723; model/layer.py:96-112)
 # --------------------------------------------------------------------------------------------------
+class _BceMean(torch.autograd.Function):
+    """torch.nn.BCELoss(reduction='mean') on probabilities (aten binary_cross_entropy): forward with the log terms clamped at
+    -100; backward (x - t) / max((1 - x) * x, 1e-12) / n — finite at saturated probabilities, where differentiating the
+    clamped logs would give 0 * inf."""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        ctx.save_for_backward(p, y)
+        return (-(y * torch.clamp(torch.log(p), min=-100.0) + (1 - y) * torch.clamp(torch.log1p(-p), min=-100.0))).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        p, y = ctx.saved_tensors
+        return g * (p - y) / torch.clamp((1 - p) * p, min=1e-12) / p.numel(), None
+
+
 def bce_mean(p, y):
-    """torch.nn.BCELoss(reduction='mean') on probabilities: log terms clamped at -100."""
-    y = y.float()
-    return (-(y * torch.clamp(torch.log(p), min=-100.0) + (1 - y) * torch.clamp(torch.log1p(-p), min=-100.0))).mean()
+    return _BceMean.apply(p, y.float())
 
 
 def reg_loss(sd, l2_by_name):
