@@ -433,8 +433,44 @@ class BaseModel(HipModule):
         return out
 
     def build_atten(self, config, dropout):
-        raise NotImplementedError("the attention branch (use_atten=True, model/layer.py:58-84) is not on the HIP path yet; "
-                                  "construct the model with config.use_atten = False")
+        """Parameters of the attention branch, named and initialised like the reference's (model/layer.py:58-69):
+        a token embedding D -> A, att_layer_num x nn.MultiheadAttention(A, heads) (used as parameter containers: the forward
+        runs on the HIP plan), the optional residual projection, and the final Linear(F*A -> 1, no bias)."""
+        atten_embed_dim = getattr(config, 'atten_embed_dim', self.embed_dim)
+        self.atten_embedding = nn.Linear(self.embed_dim, atten_embed_dim)
+        self.atten_output_dim = self.embedding.output_dim0 * atten_embed_dim
+        self.att_res = config.att_res
+        self.self_attns = nn.ModuleList([nn.MultiheadAttention(config.atten_embed_dim, config.att_head_num, dropout=dropout)
+                                         for _ in range(config.att_layer_num)])
+        if self.att_res:
+            self.V_res_embedding = nn.Linear(self.embed_dim, atten_embed_dim)
+        self.atten_linear = nn.Linear(self.atten_output_dim, 1, bias=False)
+        self.att_head_num = config.att_head_num
+
+    def describe_atten(self, plan, E):
+        """atten_forward (model/layer.py:71-84) on the plan: [B, F*D] -> logit [B, 1]."""
+        F_, D = self.field_num, self.embed_dim
+        A = self.atten_embedding.weight.shape[0]
+        tokens = P.Reshape(plan, E, plan.B * F_, D).out                       # embed_x.reshape(-1, field_num, embed_dim)
+        groups = [{"x": tokens, "w": self.atten_embedding.weight, "b": self.atten_embedding.bias}]
+        if self.att_res:
+            groups.append({"x": tokens, "w": self.V_res_embedding.weight, "b": self.V_res_embedding.bias})
+        first = P.GLinear(plan, groups, M=plan.B * F_)
+        cur = first.outs[0]
+        for attn in self.self_attns:                                          # q = k = v = the running token tensor
+            qkv = P.GLinear(plan, [{"x": cur, "w": attn.in_proj_weight, "b": attn.in_proj_bias}], M=plan.B * F_).outs[0]
+            ctx = P.AttnCore(plan, qkv, F_, self.att_head_num).out
+            cur = P.GLinear(plan, [{"x": ctx, "w": attn.out_proj.weight, "b": attn.out_proj.bias}], M=plan.B * F_).outs[0]
+        if self.att_res:
+            act = P.AddRelu(plan, cur, first.outs[1]).out
+        else:
+            zero = plan.new(A, rows=plan.B * F_)
+            zero.root.zero_()
+            act = P.AddRelu(plan, cur, zero).out
+        flat = P.Reshape(plan, act, plan.B, F_ * A).out                       # .contiguous().view(-1, atten_output_dim)
+        out = plan.new(1)
+        P.RowDot(plan, [{"x": flat, "w": self.atten_linear.weight, "b": None, "out": out}])
+        return out
 
     # ---- plan plumbing for whole models ----------------------------------------------------------------
     def plan_holder(self, B, tag="fwd", **kw):

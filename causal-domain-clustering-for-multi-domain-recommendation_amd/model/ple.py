@@ -100,9 +100,11 @@ class PLE(BaseModel):
         inputs = [E] * (self.n_tower + 1)
         for cgc in self.cgc_layers:
             inputs = cgc.describe(plan, inputs)
-        wide = self.linear.describe(plan, E)
+        others = [self.linear.describe(plan, E)]
+        if self.use_atten:
+            others.append(self.describe_atten(plan, E))                  # ple.py:65-67
         out = plan.new(self.n_tower)
-        self.describe_towers(plan, inputs[:self.n_tower], [wide], out)
+        self.describe_towers(plan, inputs[:self.n_tower], others, out)
         return [out], [], []
 
     def forward(self, x):

@@ -78,6 +78,7 @@ class STAR(BaseModel):
         else:
             X = E
         wide = self.linear.describe(plan, X)
+        atten = self.describe_atten(plan, X) if self.use_atten else None     # star.py:70-72 (per row: the partitioned rows do)
 
         def per_domain(buf, g, width):
             return buf if grouped else buf.slice(g * width, (g + 1) * width)
@@ -115,7 +116,7 @@ class STAR(BaseModel):
         for c0 in range(0, n, 32):
             P.RowDot(plan, [{"x": per_domain(cur, g, cur_w), "w": wl.views[g], "b": bl.views[g],
                              "out": out if grouped else out.slice(g, g + 1)} for g in range(c0, min(n, c0 + 32))],
-                     addends=[wide], sigmoid=True, row_offsets=ro)
+                     addends=[wide] if atten is None else [wide, atten], sigmoid=True, row_offsets=ro)
         return [out], ins, extra
 
     def forward(self, x, x_group=None, targets=None):

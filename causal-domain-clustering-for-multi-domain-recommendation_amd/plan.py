@@ -1003,6 +1003,88 @@ class Tanh:
                                         C.c_int64(xg.ld), C.c_int64(self.x.rows), self.x.cols, 1 if acc else 0))
 
 
+class Reshape:
+    """The same values under another [rows, cols] geometry (a copy: e.g. [B, F*D] embeddings as [B*F, D] field tokens,
+    model/layer.py:72).  The source must be a whole contiguous buffer."""
+
+    def __init__(self, plan, x, rows, cols):
+        assert x.col0 == 0 and x.ld == x.cols and x.rows * x.cols == rows * cols, "reshape needs a whole contiguous buffer"
+        self.x, self.rows, self.cols = x, rows, cols
+        self.out = plan.new(cols, rows=rows)
+        if x.mask is not None:
+            raise RuntimeError("reshape cannot consume an activation-fused linear output")
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        plan.fwd_steps.append(plan.call("cdc_copy_or_add", self.out.cptr(), C.c_int64(self.cols), self.x.cptr(), C.c_int64(self.cols),
+                                        C.c_int64(self.rows), self.cols, 0))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        acc = gs.claim(self.x)
+        og, xg = self.out.grad, self.x.grad
+        plan.bwd_steps.append(plan.call("cdc_copy_or_add", xg.cptr(), C.c_int64(self.cols), og.cptr(), C.c_int64(self.cols),
+                                        C.c_int64(self.rows), self.cols, 1 if acc else 0))
+
+
+class AttnCore:
+    """Per-sample multi-head self-attention over F tokens (the inside of nn.MultiheadAttention, model/layer.py:75-77):
+    qkv [B*F, 3A] -> [B*F, A]; dropout on the probabilities in training."""
+
+    def __init__(self, plan, qkv, n_tokens, n_head):
+        assert qkv.cols % 3 == 0 and qkv.rows % n_tokens == 0
+        self.qkv, self.F, self.H = qkv, n_tokens, n_head
+        self.A = qkv.cols // 3
+        self.Bs = qkv.rows // n_tokens
+        self.out = plan.new(self.A, rows=qkv.rows)
+        self.probs = torch.empty((self.Bs, n_head, n_tokens, n_tokens), dtype=torch.float32, device=plan.device)
+        self.drop_p = plan.dropout if plan.training else 0.0
+        self.seed = plan._next_seed()
+        if qkv.mask is not None:
+            raise RuntimeError("attention cannot consume an activation-fused linear output")
+        plan.add(self)
+
+    def _tail(self, plan):
+        return (C.c_int64(self.Bs), self.F, self.A, self.H, C.c_float(self.drop_p), C.c_uint64(self.seed), _p(plan.step_dev))
+
+    def build_fwd(self, plan):
+        plan.fwd_steps.append(plan.call("cdc_attn_fwd", self.qkv.cptr(), C.c_int64(self.qkv.ld), self.out.cptr(), C.c_int64(self.out.ld),
+                                        _p(self.probs), *self._tail(plan)))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        if gs.claim(self.qkv):
+            raise RuntimeError("the attention core must be the only consumer of its qkv buffer")
+        og, qg = self.out.grad, self.qkv.grad
+        plan.bwd_steps.append(plan.call("cdc_attn_bwd", self.qkv.cptr(), C.c_int64(self.qkv.ld), _p(self.probs), og.cptr(),
+                                        C.c_int64(og.ld), qg.cptr(), C.c_int64(qg.ld), *self._tail(plan)))
+
+
+class AddRelu:
+    """out = relu(a + b) (model/layer.py:80-82)."""
+
+    def __init__(self, plan, a, b):
+        assert a.rows == b.rows and a.cols == b.cols
+        self.a, self.b = a, b
+        self.out = plan.new(a.cols, rows=a.rows)
+        if a.mask is not None or b.mask is not None:
+            raise RuntimeError("add+relu cannot consume an activation-fused linear output")
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        a, b, o = self.a, self.b, self.out
+        plan.fwd_steps.append(plan.call("cdc_add_relu_fwd", a.cptr(), C.c_int64(a.ld), b.cptr(), C.c_int64(b.ld), o.cptr(), C.c_int64(o.ld),
+                                        C.c_int64(a.rows), a.cols))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        acc_a, acc_b = gs.claim(self.a), gs.claim(self.b)
+        o, og, ag, bg = self.out, self.out.grad, self.a.grad, self.b.grad
+        plan.bwd_steps.append(plan.call("cdc_add_relu_bwd", o.cptr(), C.c_int64(o.ld), og.cptr(), C.c_int64(og.ld), ag.cptr(),
+                                        C.c_int64(ag.ld), 1 if acc_a else 0, bg.cptr(), C.c_int64(bg.ld), 1 if acc_b else 0,
+                                        C.c_int64(o.rows), o.cols))
+
+
 class FMInteraction:
     """Second-order FM term over the gathered embeddings (model/layer.py:160-175): [B, F*D] -> [B, 1]."""
 

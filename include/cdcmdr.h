@@ -523,6 +523,25 @@ int cdc_rows_permute(const float* in, int64_t ld_in, const int32_t* order, float
                      int64_t B, int32_t C, int32_t inverse, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Attention branch (reference: model/layer.py:58-84 BaseModel.build_atten / atten_forward — on by default
+ * through config.py:24-28).  The linears around it are cdc_glinear_* / cdc_rowdot_* calls on [B*F, .] token buffers; these
+ * entry points are the core of torch's nn.MultiheadAttention in between, per sample over its F field tokens:
+ *   qkv [B*F, 3A] (row b*F+f; q | k | v, head h in columns h*dh..(h+1)*dh of each third), dh = A/H
+ *   probs [B, H, F, F] = softmax_j(q_i*dh^-1/2 . k_j)          (saved for the backward)
+ *   out   [B*F, A]: head h's columns = dropout(probs) @ v      (dropout on the probabilities, training only)
+ * F <= 64, dh in {4, 8, 16, 32, 64}.  The backward writes every column of dqkv. */
+int cdc_attn_fwd(const float* qkv, int64_t ld, float* out, int64_t ldo, float* probs, int64_t B, int32_t F, int32_t A, int32_t H,
+                 float drop_p, uint64_t seed, const int32_t* seed_offset_dev, void* stream);
+int cdc_attn_bwd(const float* qkv, int64_t ld, const float* probs, const float* dout, int64_t lddo, float* dqkv, int64_t lddq,
+                 int64_t B, int32_t F, int32_t A, int32_t H, float drop_p, uint64_t seed, const int32_t* seed_offset_dev,
+                 void* stream);
+/* out = relu(a + b) (model/layer.py:80-82) and its backward: (out > 0 ? dout : 0) to both addends (stored or added) */
+int cdc_add_relu_fwd(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo, int64_t rows, int32_t cols,
+                     void* stream);
+int cdc_add_relu_bwd(const float* out, int64_t ldo, const float* dout, int64_t lddo, float* da, int64_t ldda, int32_t acc_a,
+                     float* db, int64_t lddb, int32_t acc_b, int64_t rows, int32_t cols, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Evaluation metrics — run.py:684-711: roc_auc_score + log_loss over the whole evaluation set and per
  * domain (evaluate_multi_domain's groupby).  pred f32 [n] (the gathered tower probabilities), label int16 [n] (0/1),
  * domain int32, element i at domain[i*ld_domain] (e.g. the domain column of X: ld = F); NULL when n_domain == 1.

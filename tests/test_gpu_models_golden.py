@@ -42,8 +42,16 @@ def build(name):
         "g2_dcnv2_stacked": lambda: DCNv2(FD13, 4, 2, (32, 16), dropout=0.0, model_structure="stacked", low_rank=8),
         "g2_star5_all": lambda: STAR(FD, 4, 5, (32, 16, 8), dropout=0.0),
         "g2_star30_all": lambda: STAR(FD, 4, 30, (16, 8), dropout=0.0),
+        "g12_ple3_atten": lambda: PLE(FD, 4, 3, 2, 2, ((32, 16), (8,)), (8, 4), 0.0, _atten_cfg(True)),
+        "g12_mmoe4_atten_nores": lambda: MMoE(FD, 4, 3, 4, (32, 16, 8), (8, 4), 0.0, _atten_cfg(False)),
+        "g12_star3_atten": lambda: STAR(FD, 4, 3, (32, 16, 8), None, 0.0, _atten_cfg(True)),
         "g11_deepfm": lambda: __import__("cdcmdr_amd.model.dfm", fromlist=["DeepFM"]).DeepFM(FD13, 4, (32, 16, 8), dropout=0.0),
     }[name]()
+
+
+def _atten_cfg(att_res):
+    import types
+    return types.SimpleNamespace(use_atten=True, atten_embed_dim=8, att_layer_num=2, att_head_num=2, att_res=att_res, use_dcn=False)
 
 
 def check_grads(model, d, names):
@@ -68,7 +76,8 @@ def check_grads(model, d, names):
 
 
 @pytest.mark.parametrize("name", ["g2_ple3", "g2_mmoe4", "g2_mmoe8", "g2_dcn13", "g2_dcnv2_mix", "g2_dcnv2_stacked",
-                                  "g2_star5_all", "g2_star30_all", "g11_deepfm"])
+                                  "g2_star5_all", "g2_star30_all", "g11_deepfm", "g12_ple3_atten", "g12_mmoe4_atten_nores",
+                                  "g12_star3_atten"])
 def test_model_matches_reference_golden(cuda, name):
     d = load(name)
     model = build(name).to(cuda).set_precision("f32")
@@ -235,3 +244,47 @@ def test_fm_term_golden(cuda):
     assert_close(de.reshape(B, F, D), d["fm_grad"], 1e-5, 1e-6, "fm_grad")
     L.check(lib.cdc_fm_bwd(e2.data_ptr(), F * D, ones.data_ptr(), 1, de.data_ptr(), F * D, B, F, D, 1, s), "fm_bwd(acc)")
     assert_close(de.reshape(B, F, D), 2 * d["fm_grad"], 1e-5, 1e-6, "fm_grad accumulated")
+
+
+@pytest.mark.parametrize("B,F,A,H", [(5, 6, 8, 2), (64, 26, 64, 2), (3, 64, 16, 4), (7, 1, 4, 1)])
+def test_attention_core_against_torch(cuda, B, F, A, H):
+    """cdc_attn_fwd / cdc_attn_bwd (the inside of nn.MultiheadAttention, model/layer.py:75-77) against torch's own
+    scaled_dot_product_attention on the CPU in fp32 — probabilities, output, and the gradient of all three projections."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(B * 100 + F)
+    qkv = torch.randn(B * F, 3 * A)
+    dout = torch.randn(B * F, A)
+    ref = qkv.clone().requires_grad_(True)
+    dh = A // H
+    q, k, v = [t.reshape(B, F, H, dh).transpose(1, 2) for t in ref.split(A, dim=1)]            # [B, H, F, dh]
+    pr = torch.softmax((q * dh ** -0.5) @ k.transpose(-1, -2), dim=-1)
+    want = (pr @ v).transpose(1, 2).reshape(B * F, A)
+    want.backward(dout)
+    d_qkv = qkv.to(cuda).contiguous()
+    out = torch.empty((B * F, A), device=cuda)
+    probs = torch.empty((B, H, F, F), device=cuda)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.cdc_attn_fwd(d_qkv.data_ptr(), 3 * A, out.data_ptr(), A, probs.data_ptr(), B, F, A, H, 0.0, 1, None, s), "attn_fwd")
+    assert_close(probs, pr.detach(), 1e-5, 1e-6, "probs")
+    assert_close(out, want.detach(), 1e-5, 1e-6, "attention output")
+    dq = torch.full((B * F, 3 * A), 9.0, device=cuda)
+    L.check(lib.cdc_attn_bwd(d_qkv.data_ptr(), 3 * A, probs.data_ptr(), dout.to(cuda).data_ptr(), A, dq.data_ptr(), 3 * A, B, F, A, H,
+                             0.0, 1, None, s), "attn_bwd")
+    assert_close(dq, ref.grad, 2e-5, 2e-6, "d qkv")
+    # dropout on the probabilities: the backward regenerates the forward's decisions (finite-difference-free check:
+    # with dout = v-independent ones, d v equals the column sums of the dropped probabilities the forward used)
+    out2 = torch.empty_like(out)
+    L.check(lib.cdc_attn_fwd(d_qkv.data_ptr(), 3 * A, out2.data_ptr(), A, probs.data_ptr(), B, F, A, H, 0.5, 7, None, s), "attn_fwd(drop)")
+    if F > 1:
+        assert float((out2 - out).abs().max()) > 0
+    ones = torch.ones((B * F, A), device=cuda)
+    L.check(lib.cdc_attn_bwd(d_qkv.data_ptr(), 3 * A, probs.data_ptr(), ones.data_ptr(), A, dq.data_ptr(), 3 * A, B, F, A, H, 0.5, 7, None, s),
+            "attn_bwd(drop)")
+    dv = dq[:, 2 * A:].reshape(B, F, H, dh)                       # sum_i Pdrop[i, j] for every d
+    vsum = d_qkv[:, 2 * A:].reshape(B, F, H, dh)
+    # out2[b, i, h, :] = sum_j Pdrop[i, j] v[j]  =>  sum_i out2 = sum_j (sum_i Pdrop[i, j]) v[j] = sum_j dv[j, 0] * v[j]
+    lhs = out2.reshape(B, F, H, dh).sum(dim=1)
+    rhs = (dv[..., :1] * vsum).sum(dim=1)
+    assert_close(lhs, rhs, 1e-4, 1e-5, "dropout mask consistent between forward and backward")
