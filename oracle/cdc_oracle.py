@@ -133,6 +133,39 @@ def wide_logit(e, sd):
     return _lin(e, sd, "linear.fc", mfma=False)
 
 
+ATT_HEADS = 2       # config.att_head_num (config.py:27) — not recoverable from a state_dict
+
+
+def atten_logit(e, sd):
+    """BaseModel.atten_forward (model/layer.py:71-84) with dropout 0: token embedding D -> A, the stack of
+    nn.MultiheadAttention layers (q = k = v; in_proj, q scaled by dh^-1/2, softmax over the keys, out_proj), the optional
+    residual projection of the raw tokens, ReLU, flatten, Linear(F*A -> 1, no bias).  Written out with plain matmuls."""
+    D = sd["embedding.embedding_dict.weight"].shape[1]
+    B = e.shape[0]
+    tok = e.reshape(B, -1, D)                                                    # [B, F, D]
+    cur = tok @ sd["atten_embedding.weight"].t() + sd["atten_embedding.bias"]    # [B, F, A]
+    A = cur.shape[-1]
+    dh = A // ATT_HEADS
+    n_layer = _count(sd, r"self_attns\.(\d+)\.")
+    for i in range(n_layer):
+        qkv = cur @ sd[f"self_attns.{i}.in_proj_weight"].t() + sd[f"self_attns.{i}.in_proj_bias"]
+        q, k, v = [t.reshape(B, -1, ATT_HEADS, dh).transpose(1, 2) for t in qkv.split(A, dim=-1)]       # [B, H, F, dh]
+        p = torch.softmax((q * dh ** -0.5) @ k.transpose(-1, -2), dim=-1)
+        ctx = (p @ v).transpose(1, 2).reshape(B, -1, A)
+        cur = ctx @ sd[f"self_attns.{i}.out_proj.weight"].t() + sd[f"self_attns.{i}.out_proj.bias"]
+    if "V_res_embedding.weight" in sd:
+        cur = cur + (tok @ sd["V_res_embedding.weight"].t() + sd["V_res_embedding.bias"])
+    return torch.relu(cur).reshape(B, -1) @ sd["atten_linear.weight"].t()
+
+
+def other_logits(e, sd):
+    """the `other_outs` every tower adds to its logit: the wide term, and the attention branch when the model has one"""
+    outs = [wide_logit(e, sd)]
+    if "atten_embedding.weight" in sd:
+        outs.append(atten_logit(e, sd))
+    return outs
+
+
 def towers(tower_inputs, other_outs, sd, training, stats_out, prefix="towers"):
     """BaseModel.tower_forward (model/layer.py:48-56)."""
     ys = []
@@ -177,7 +210,7 @@ def ple_forward(sd, x_i32, field_dims, n_tower, training=True, stats_out=None, p
     inputs = [e] * (n_tower + 1)
     for lvl in range(n_level):
         inputs = cgc(inputs, sd, f"cgc_layers.{lvl}", n_tower, training)
-    return towers(inputs[:n_tower], [wide_logit(e, sd)], sd, training, _prefixed(stats_out, prefix))
+    return towers(inputs[:n_tower], other_logits(e, sd), sd, training, _prefixed(stats_out, prefix))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -193,7 +226,7 @@ def mmoe_forward(sd, x_i32, field_dims, n_tower, training=True, stats_out=None, 
     for i in range(n_tower):
         gate = torch.softmax(_lin(e, sd, f"gates.{i}.0"), dim=1)
         tin.append((gate.unsqueeze(-1) * experts).sum(1))
-    return towers(tin, [wide_logit(e, sd)], sd, training, so)
+    return towers(tin, other_logits(e, sd), sd, training, so)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -303,7 +336,7 @@ def star_forward(sd, x_i32, field_dims, n_tower, x_group=None, targets=None, tra
     sd = _strip(sd, prefix)
     so = _prefixed(stats_out, prefix)
     e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
-    wide = wide_logit(e, sd)
+    wide = sum(other_logits(e, sd))                                 # star.py:66-72: wide term (+ attention branch)
     ys, ts = [], []
     for g in range(n_tower):
         if x_group is None:

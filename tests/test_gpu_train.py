@@ -307,3 +307,37 @@ def test_star_fast_path_matches_the_oracle(cuda):
             continue        # a constant added in front of Linear -> BatchNorm: zero gradient up to rounding noise, like a pre-BN bias
         atol = 5e-4 if k.endswith("running_mean") else 2e-5
         assert_close(got[k], s2[k].detach(), 5e-4, atol, f"star step: {k}")
+
+
+def test_attention_model_trains_on_the_fast_path_graph_equals_eager(cuda):
+    """PLE with the attention branch and dropout 0.2 (dropout on the attention probabilities included) through TrainStep:
+    the hipGraph replay reproduces the eager run bit for bit (the dropout streams are keyed by the device step counter),
+    the loss goes down, every attention parameter moves."""
+    import types
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [20, 500, 7, 90, 4]
+    cfg = types.SimpleNamespace(use_atten=True, atten_embed_dim=16, att_layer_num=2, att_head_num=2, att_res=True, use_dcn=False)
+    res = {}
+    for use_graph in (False, True):
+        torch.manual_seed(4)
+        model = PLE(fd, 8, 3, 1, 1, ((16,), (8,)), (8,), 0.2, cfg).to(cuda).set_precision("f32")
+        w0 = {k: v.detach().clone() for k, v in model.named_parameters() if "atten" in k or "self_attns" in k or "V_res" in k}
+        opt = FusedAdam(model, table_mode="lazy")
+        ts = TrainStep(model, opt, 64, use_graph=use_graph)
+        r = np.random.default_rng(8)
+        X = torch.from_numpy(make_ids(r, 64, fd)).to(cuda)
+        y = torch.from_numpy((make_ids(r, 64, [2])[:, 0]).astype(np.int16)).to(cuda)
+        g = torch.from_numpy(r.integers(0, 3, size=64).astype(np.int64)).to(cuda)
+        losses = []
+        for _ in range(30):                                        # the same batch: the loss must fall
+            bce, _ = ts.step(X, y, g)
+            losses.append(float(bce.item()))
+        opt.flush_table()
+        res[use_graph] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        assert losses[-1] < losses[0] - 0.05, losses
+        assert len(w0) >= 9 and all(float((dict(model.named_parameters())[k] - v).abs().max()) > 0 for k, v in w0.items())
+    assert res[False][0] == res[True][0]
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k], res[True][1][k]), k

@@ -48,6 +48,9 @@ MODELS = {
     "g2_dcnv2_stacked": ("dcnv2", lambda sd, x, tr, so: O.dcnv2_forward(sd, x, FD13, tr, so, model_structure="stacked")),
     "g2_star5_all": ("star", lambda sd, x, tr, so: O.star_forward(sd, x, FD, 5, training=tr, stats_out=so)),
     "g2_star30_all": ("star", lambda sd, x, tr, so: O.star_forward(sd, x, FD, 30, training=tr, stats_out=so)),
+    "g12_ple3_atten": ("ple", lambda sd, x, tr, so: O.ple_forward(sd, x, FD, 3, tr, so)),
+    "g12_mmoe4_atten_nores": ("mmoe", lambda sd, x, tr, so: O.mmoe_forward(sd, x, FD, 3, tr, so)),
+    "g12_star3_atten": ("star", lambda sd, x, tr, so: O.star_forward(sd, x, FD, 3, training=tr, stats_out=so)),
     "g11_deepfm": ("deepfm", lambda sd, x, tr, so: O.deepfm_forward(sd, x, FD13, tr, so)),
 }
 FD = [7, 100, 3, 50, 11, 29]
