@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="diagnostic, single process: run ONE rank's launch work of a W-rank step with the collectives replaced "
                          "by local copies (timing of the compute side only; the numbers it trains on are meaningless)")
+    ap.add_argument("--atten", type=int, default=0,
+                    help="1: the reference's default attention branch (config.py:24-28: 3 x MultiheadAttention(64, 2 heads) + residual) "
+                         "on top of the BASELINE configuration, which is defined without it")
     ap.add_argument("--flush-every", type=int, default=64, help="lazy table: the whole table is replayed once per this many steps")
     ap.add_argument("--pool", type=int, default=0,
                     help="resident synthetic batches cycled through; 0 = warmup+steps (max 1024), so that no batch repeats and "
@@ -61,8 +64,12 @@ def build_model(args, device):
     from cdcmdr_amd.model.ple import PLE
     torch.manual_seed(2000)
     field_dims = [args.vocab] * args.fields
+    cfg = None
+    if args.atten:
+        import types
+        cfg = types.SimpleNamespace(use_atten=True, atten_embed_dim=64, att_layer_num=3, att_head_num=2, att_res=True, use_dcn=False)
     with torch.device(device):
-        model = PLE(field_dims, args.embed_dim, 3, 2, 2, ((256, 128), (64,)), (64, 32), dropout=args.dropout)
+        model = PLE(field_dims, args.embed_dim, 3, 2, 2, ((256, 128), (64,)), (64, 32), args.dropout, cfg)
     model.set_precision(args.precision)
     return model, field_dims
 
@@ -229,7 +236,7 @@ def main():
             "config": {"workload": "PLE 3-domain full training step (fwd + BCE + whole-table L2 + bwd + Adam), "
                                    f"{args.fields} fields x vocab {args.vocab}, emb_dim={args.embed_dim}, batch {B}/GPU",
                        "global_batch": B * world, "dropout": args.dropout, "table_mode": table_mode,
-                       "hip_graph": use_graph, "id_dist": args.id_dist, "parallelism": f"dp{world}",
+                       "hip_graph": use_graph, "id_dist": args.id_dist, "parallelism": f"dp{world}", "attention_branch": bool(args.atten),
                        "table_dist": ts.table_dist if world > 1 else None,
                        "bn_stats": None if world == 1 else ("global batch (sync)" if args.sync_bn else "per rank"),
                        "last_bce_loss": loss_val},

@@ -18,6 +18,30 @@ __device__ __forceinline__ float attn_keep(uint64_t seed, uint64_t idx, float dr
     return cdc_uniform(seed, idx) < drop_p ? 0.f : keep_scale;
 }
 
+typedef float attn_f4 __attribute__((ext_vector_type(4)));
+// row operations on an LDS row of DH floats (DH % 4 == 0) through 16-byte reads: broadcast rows cost a quarter of the LDS
+// issue slots of scalar reads
+template <int DH>
+__device__ __forceinline__ float lds_dot(const float (&r)[DH], const float* row) {
+    const attn_f4* r4 = reinterpret_cast<const attn_f4*>(row);
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH / 4; ++d) {
+        const attn_f4 x = r4[d];
+        s += r[4 * d] * x[0]; s += r[4 * d + 1] * x[1]; s += r[4 * d + 2] * x[2]; s += r[4 * d + 3] * x[3];
+    }
+    return s;
+}
+template <int DH>
+__device__ __forceinline__ void lds_axpy(float (&acc)[DH], float a, const float* row) {
+    const attn_f4* r4 = reinterpret_cast<const attn_f4*>(row);
+#pragma unroll
+    for (int d = 0; d < DH / 4; ++d) {
+        const attn_f4 x = r4[d];
+        acc[4 * d] += a * x[0]; acc[4 * d + 1] += a * x[1]; acc[4 * d + 2] += a * x[2]; acc[4 * d + 3] += a * x[3];
+    }
+}
+
 template <int DH>
 __global__ void __launch_bounds__(ATTN_THREADS) k_attn_fwd(const float* __restrict__ qkv, int64_t ld, float* __restrict__ out, int64_t ldo,
                                                            float* __restrict__ probs, int64_t B, int32_t F, int32_t A, int32_t H,
@@ -49,9 +73,7 @@ __global__ void __launch_bounds__(ATTN_THREADS) k_attn_fwd(const float* __restri
     float* prow = Ps + lane * (F + 1);
     float mx = -INFINITY;
     for (int j = 0; j < F; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < DH; ++d) s += q[d] * Ks[j * DH + d];
+        const float s = lds_dot<DH>(q, Ks + j * DH);
         prow[j] = s;
         mx = fmaxf(mx, s);
     }
@@ -71,8 +93,7 @@ __global__ void __launch_bounds__(ATTN_THREADS) k_attn_fwd(const float* __restri
         if (pg) pg[j] = p;                                                   // the softmax output (before dropout), for the backward
         float pd = p;
         if (drop_p > 0.f) pd *= attn_keep(seed, (uint64_t)((pair * F + lane) * (int64_t)F + j), drop_p, keep_scale);
-#pragma unroll
-        for (int d = 0; d < DH; ++d) o[d] += pd * Vs[j * DH + d];
+        lds_axpy<DH>(o, pd, Vs + j * DH);
     }
     float* dst = out + (b * F + lane) * ldo + h * DH;
 #pragma unroll
@@ -112,11 +133,12 @@ __global__ void __launch_bounds__(ATTN_THREADS) k_attn_bwd(const float* __restri
     if (live && lane < F) {
         // query row `lane`: dP = dO v^T (through the dropout mask), dS = P * (dP - sum_j dP P)
         const float* pg = probs + ((pair * F + lane) * (int64_t)F);
+        float orow[DH];                                                    // own dO row in registers: reading it from LDS at a
+#pragma unroll                                                             // stride of DH floats would put every lane on two banks
+        for (int d = 0; d < DH; ++d) orow[d] = dout[(b * F + lane) * lddo + h * DH + d];
         float dot = 0.f;
         for (int j = 0; j < F; ++j) {
-            float dp = 0.f;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) dp += Os[lane * DH + d] * Vs[j * DH + d];
+            float dp = lds_dot<DH>(orow, Vs + j * DH);
             const float p = pg[j];
             float keep = 1.f;
             if (drop_p > 0.f) keep = attn_keep(seed, (uint64_t)((pair * F + lane) * (int64_t)F + j), drop_p, keep_scale);
@@ -131,8 +153,7 @@ __global__ void __launch_bounds__(ATTN_THREADS) k_attn_bwd(const float* __restri
         for (int j = 0; j < F; ++j) {
             const float ds = pg[j] * (Ds[lane * (F + 1) + j] - dot);
             Ds[lane * (F + 1) + j] = ds;
-#pragma unroll
-            for (int d = 0; d < DH; ++d) dq[d] += ds * Ks[j * DH + d];
+            lds_axpy<DH>(dq, ds, Ks + j * DH);
         }
         float* dst = dqkv + (b * F + lane) * lddq + h * DH;
 #pragma unroll
@@ -147,11 +168,8 @@ __global__ void __launch_bounds__(ATTN_THREADS) k_attn_bwd(const float* __restri
         for (int d = 0; d < DH; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
         for (int i = 0; i < F; ++i) {
             const float ds = Ds[i * (F + 1) + lane], pd = Pd[i * (F + 1) + lane];
-#pragma unroll
-            for (int d = 0; d < DH; ++d) {
-                dk[d] += ds * Qs[i * DH + d];
-                dv[d] += pd * Os[i * DH + d];
-            }
+            lds_axpy<DH>(dk, ds, Qs + i * DH);
+            lds_axpy<DH>(dv, pd, Os + i * DH);
         }
         float* dst = dqkv + (b * F + lane) * lddq + h * DH;
 #pragma unroll
