@@ -449,6 +449,13 @@ class BaseModel(HipModule):
 
     def describe_atten(self, plan, E):
         """atten_forward (model/layer.py:71-84) on the plan: [B, F*D] -> logit [B, 1]."""
+        flat = self.describe_atten_features(plan, E, self.att_head_num)
+        out = plan.new(1)
+        P.RowDot(plan, [{"x": flat, "w": self.atten_linear.weight, "b": None, "out": out}])
+        return out
+
+    def describe_atten_features(self, plan, E, n_head, out=None):
+        """the interacting-layer stack up to relu(...).view(-1, F*A) (model/layer.py:72-83, model/autoint.py:49-60)"""
         F_, D = self.field_num, self.embed_dim
         A = self.atten_embedding.weight.shape[0]
         tokens = P.Reshape(plan, E, plan.B * F_, D).out                       # embed_x.reshape(-1, field_num, embed_dim)
@@ -459,7 +466,7 @@ class BaseModel(HipModule):
         cur = first.outs[0]
         for attn in self.self_attns:                                          # q = k = v = the running token tensor
             qkv = P.GLinear(plan, [{"x": cur, "w": attn.in_proj_weight, "b": attn.in_proj_bias}], M=plan.B * F_).outs[0]
-            ctx = P.AttnCore(plan, qkv, F_, self.att_head_num).out
+            ctx = P.AttnCore(plan, qkv, F_, n_head).out
             cur = P.GLinear(plan, [{"x": ctx, "w": attn.out_proj.weight, "b": attn.out_proj.bias}], M=plan.B * F_).outs[0]
         if self.att_res:
             act = P.AddRelu(plan, cur, first.outs[1]).out
@@ -467,10 +474,7 @@ class BaseModel(HipModule):
             zero = plan.new(A, rows=plan.B * F_)
             zero.root.zero_()
             act = P.AddRelu(plan, cur, zero).out
-        flat = P.Reshape(plan, act, plan.B, F_ * A).out                       # .contiguous().view(-1, atten_output_dim)
-        out = plan.new(1)
-        P.RowDot(plan, [{"x": flat, "w": self.atten_linear.weight, "b": None, "out": out}])
-        return out
+        return P.Reshape(plan, act, plan.B, F_ * A, out=out).out             # .contiguous().view(-1, atten_output_dim)
 
     # ---- plan plumbing for whole models ----------------------------------------------------------------
     def plan_holder(self, B, tag="fwd", **kw):

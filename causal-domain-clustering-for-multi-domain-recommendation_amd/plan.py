@@ -1007,23 +1007,25 @@ class Reshape:
     """The same values under another [rows, cols] geometry (a copy: e.g. [B, F*D] embeddings as [B*F, D] field tokens,
     model/layer.py:72).  The source must be a whole contiguous buffer."""
 
-    def __init__(self, plan, x, rows, cols):
+    def __init__(self, plan, x, rows, cols, out=None):
+        """out: optional destination [rows, cols] with any row stride (e.g. a column slice of a concatenation buffer)"""
         assert x.col0 == 0 and x.ld == x.cols and x.rows * x.cols == rows * cols, "reshape needs a whole contiguous buffer"
         self.x, self.rows, self.cols = x, rows, cols
-        self.out = plan.new(cols, rows=rows)
+        self.out = out if out is not None else plan.new(cols, rows=rows)
+        assert self.out.rows == rows and self.out.cols == cols
         if x.mask is not None:
             raise RuntimeError("reshape cannot consume an activation-fused linear output")
         plan.add(self)
 
     def build_fwd(self, plan):
-        plan.fwd_steps.append(plan.call("cdc_copy_or_add", self.out.cptr(), C.c_int64(self.cols), self.x.cptr(), C.c_int64(self.cols),
+        plan.fwd_steps.append(plan.call("cdc_copy_or_add", self.out.cptr(), C.c_int64(self.out.ld), self.x.cptr(), C.c_int64(self.cols),
                                         C.c_int64(self.rows), self.cols, 0))
 
     def build_bwd(self, plan, gs):
         plan.ensure_grad(self.out, gs)
         acc = gs.claim(self.x)
         og, xg = self.out.grad, self.x.grad
-        plan.bwd_steps.append(plan.call("cdc_copy_or_add", xg.cptr(), C.c_int64(self.cols), og.cptr(), C.c_int64(self.cols),
+        plan.bwd_steps.append(plan.call("cdc_copy_or_add", xg.cptr(), C.c_int64(self.cols), og.cptr(), C.c_int64(og.ld),
                                         C.c_int64(self.rows), self.cols, 1 if acc else 0))
 
 

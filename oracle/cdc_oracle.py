@@ -136,10 +136,10 @@ def wide_logit(e, sd):
 ATT_HEADS = 2       # config.att_head_num (config.py:27) — not recoverable from a state_dict
 
 
-def atten_logit(e, sd):
-    """BaseModel.atten_forward (model/layer.py:71-84) with dropout 0: token embedding D -> A, the stack of
+def atten_features(e, sd):
+    """model/layer.py:72-83 (= model/autoint.py:49-60) with dropout 0: token embedding D -> A, the stack of
     nn.MultiheadAttention layers (q = k = v; in_proj, q scaled by dh^-1/2, softmax over the keys, out_proj), the optional
-    residual projection of the raw tokens, ReLU, flatten, Linear(F*A -> 1, no bias).  Written out with plain matmuls."""
+    residual projection of the raw tokens, ReLU, flatten to [B, F*A].  Written out with plain matmuls."""
     D = sd["embedding.embedding_dict.weight"].shape[1]
     B = e.shape[0]
     tok = e.reshape(B, -1, D)                                                    # [B, F, D]
@@ -155,7 +155,19 @@ def atten_logit(e, sd):
         cur = ctx @ sd[f"self_attns.{i}.out_proj.weight"].t() + sd[f"self_attns.{i}.out_proj.bias"]
     if "V_res_embedding.weight" in sd:
         cur = cur + (tok @ sd["V_res_embedding.weight"].t() + sd["V_res_embedding.bias"])
-    return torch.relu(cur).reshape(B, -1) @ sd["atten_linear.weight"].t()
+    return torch.relu(cur).reshape(B, -1)
+
+
+def atten_logit(e, sd):
+    """BaseModel.atten_forward (model/layer.py:71-84): the features through Linear(F*A -> 1, no bias)."""
+    return atten_features(e, sd) @ sd["atten_linear.weight"].t()
+
+
+def autoint_forward(sd, x_i32, field_dims, training=True, stats_out=None):
+    """AutoInt.forward (model/autoint.py:48-65)."""
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    final = torch.cat([atten_features(e, sd), mlp(e, sd, "dnn", training, stats_out)], dim=1)
+    return torch.sigmoid(final @ sd["dnn_linear.weight"].t() + wide_logit(e, sd)).squeeze(1)
 
 
 def other_logits(e, sd):
@@ -424,6 +436,8 @@ def reg_names(names, model_kind):
         elif model_kind == "dcn" and top in ("mlp", "cn") and "weight" in rel and "bn" not in rel:
             out.append(n)
         elif model_kind == "deepfm" and top == "mlp" and "weight" in rel and "bn" not in rel:
+            out.append(n)
+        elif model_kind == "autoint" and top == "dnn" and "weight" in rel and "bn" not in rel:
             out.append(n)
         elif model_kind == "dcnv2":
             if top == "dnn" and "weight" in rel and "bn" not in rel:

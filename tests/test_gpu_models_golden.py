@@ -45,6 +45,8 @@ def build(name):
         "g12_ple3_atten": lambda: PLE(FD, 4, 3, 2, 2, ((32, 16), (8,)), (8, 4), 0.0, _atten_cfg(True)),
         "g12_mmoe4_atten_nores": lambda: MMoE(FD, 4, 3, 4, (32, 16, 8), (8, 4), 0.0, _atten_cfg(False)),
         "g12_star3_atten": lambda: STAR(FD, 4, 3, (32, 16, 8), None, 0.0, _atten_cfg(True)),
+        "g13_autoint": lambda: __import__("cdcmdr_amd.model.autoint", fromlist=["AutoInt"]).AutoInt(
+            FD, 4, atten_embed_dim=8, att_layer_num=2, att_head_num=2, att_res=True, mlp_dims=(32, 16), dropout=0.0),
         "g11_deepfm": lambda: __import__("cdcmdr_amd.model.dfm", fromlist=["DeepFM"]).DeepFM(FD13, 4, (32, 16, 8), dropout=0.0),
     }[name]()
 
@@ -77,7 +79,7 @@ def check_grads(model, d, names):
 
 @pytest.mark.parametrize("name", ["g2_ple3", "g2_mmoe4", "g2_mmoe8", "g2_dcn13", "g2_dcnv2_mix", "g2_dcnv2_stacked",
                                   "g2_star5_all", "g2_star30_all", "g11_deepfm", "g12_ple3_atten", "g12_mmoe4_atten_nores",
-                                  "g12_star3_atten"])
+                                  "g12_star3_atten", "g13_autoint"])
 def test_model_matches_reference_golden(cuda, name):
     d = load(name)
     model = build(name).to(cuda).set_precision("f32")

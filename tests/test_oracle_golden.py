@@ -51,6 +51,7 @@ MODELS = {
     "g12_ple3_atten": ("ple", lambda sd, x, tr, so: O.ple_forward(sd, x, FD, 3, tr, so)),
     "g12_mmoe4_atten_nores": ("mmoe", lambda sd, x, tr, so: O.mmoe_forward(sd, x, FD, 3, tr, so)),
     "g12_star3_atten": ("star", lambda sd, x, tr, so: O.star_forward(sd, x, FD, 3, training=tr, stats_out=so)),
+    "g13_autoint": ("autoint", lambda sd, x, tr, so: O.autoint_forward(sd, x, FD, tr, so)),
     "g11_deepfm": ("deepfm", lambda sd, x, tr, so: O.deepfm_forward(sd, x, FD13, tr, so)),
 }
 FD = [7, 100, 3, 50, 11, 29]
