@@ -247,6 +247,35 @@ def main():
         dp.close()
 
 
+# C-ABI call -> kernel name in the rocprofv3 summaries
+_KERNEL_OF = {"cdc_embed_lazy_flush(slice)": "k_lazy_flush", "cdc_embed_adam_dense_pass": "k_adam_dense_pass",
+              "cdc_glinear_fwd": "k_glinear_fwd", "cdc_glinear_bwd_x": "k_glinear_bwd_x", "cdc_embed_gather_fwd": "k_gather_fwd"}
+
+
+def profiled_traffic(call_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/round1/pmc_default_fetch_write.txt: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, KB per dispatch;
+    gfx950 reports half of a wide coalesced read, hence fetch x 2).  Not collected live: counters need the profiler."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "pmc_default_fetch_write.txt")
+    kern = _KERNEL_OF.get(call_name)
+    if kern is None or not os.path.exists(path):
+        return None, None
+    fetch = write = None
+    cur = None
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = line
+        elif cur is not None and kern in cur:
+            parts = line.split()
+            if parts[0] == "FETCH_SIZE":
+                fetch = float(parts[1])
+            elif parts[0] == "WRITE_SIZE":
+                write = float(parts[1])
+    if fetch is None or write is None:
+        return None, None
+    return fetch * 1024 * 2 + write * 1024, "profiles/round1/pmc_default_fetch_write.txt (rocprofv3 --pmc, per dispatch)"
+
+
 def measure_roofline(args, ts, opt, Xd, yd, gd):
     """Per-launch HIP-event timing of instrumented eager steps (same launches as the timed region, which may be
     replayed as a graph where events cannot be placed).  The roofline object is for the step's dominant kernel."""
@@ -276,7 +305,9 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
                         "lane_cycles_per_element_step": lane_rate * d["ms_per_step"] * 1e-3 / es,
                         "instruction_floor_lane_cycles": 12.5,
                         "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved"}
-    roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": None,
+    traffic, traffic_src = profiled_traffic(name)
+    roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": traffic,
+                 "traffic_source": traffic_src,
                  "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown, "breakdown_all": breakdown_all})
     # all MFMA launches together (north-star figure: expert GEMMs vs bf16 peak)
     gm = [v for k, v in prof.items() if "glinear" in k]
