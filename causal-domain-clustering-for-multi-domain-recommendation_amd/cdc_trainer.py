@@ -26,6 +26,8 @@ from .trainer import TrainStep
 
 
 class CDCTrainer:
+    MAX_STEPS = 16      # resident TrainSteps (one per batch size x flavour); least recently used ones are rebuilt on demand
+
     def __init__(self, model, optimizer, batch_size, train_loaders, n_domain, domain_cnt_weight, train_domain_batch_seq,
                  warmup_step=200, update_matrix_step=2, update_interval=1000, n_causal_mask=None, log=None):
         """model: cdcmdr_amd.model.cdc.CDC on the GPU; optimizer: FusedAdam(model.base_model_instance);
@@ -71,9 +73,12 @@ class CDCTrainer:
         B = X.shape[0]
         kind = "mean" if mode == "warmup" else "multi"
         key = (kind, B, self.training)
-        ts = self._steps.get(key)
+        ts = self._steps.pop(key, None)
         if ts is None:
-            ts = self._steps[key] = TrainStep(self.base, self.opt, B, mode=kind, use_graph=False, train_mode=self.training)
+            ts = TrainStep(self.base, self.opt, B, mode=kind, use_graph=False, train_mode=self.training)
+        self._steps[key] = ts                                         # most recently used last
+        while len(self._steps) > self.MAX_STEPS:                      # every step owns its batch size's buffers
+            self._steps.pop(next(iter(self._steps)))
         if kind == "mean":
             group = None
         elif domain_i is not None:                                    # cdc.py:108-111: one tower for the whole batch

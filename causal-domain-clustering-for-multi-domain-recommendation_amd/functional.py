@@ -16,6 +16,10 @@ class PlanCache:
     """Plans of one module keyed by (tag, batch, mode, precision, dropout) and by the storage addresses
     of the module's parameters/buffers (a .to()/.cuda() or a re-assigned .data invalidates the plans)."""
 
+    MAX_PLANS = 24      # a plan owns every activation and gradient buffer of its batch size: bound what stays resident
+                        # (loops over many batch sizes — ragged epoch tails, CDC's concatenated domain batches — evict the
+                        # least recently used plan; anything still holding an evicted plan keeps it alive and valid)
+
     def __init__(self):
         self.plans = {}
 
@@ -24,9 +28,13 @@ class PlanCache:
         key = (tag, B, module.training, getattr(module, "precision", "bf16"), float(getattr(module, "dropout_p", 0.0)))
         hit = self.plans.get(key)
         if hit is not None and hit[0] == sig:
+            self.plans[key] = self.plans.pop(key)          # most recently used last
             return hit[1]
         plan = build()
+        self.plans.pop(key, None)
         self.plans[key] = (sig, plan)
+        while len(self.plans) > self.MAX_PLANS:
+            self.plans.pop(next(iter(self.plans)))
         return plan
 
     def clear(self):
