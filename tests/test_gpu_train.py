@@ -341,3 +341,50 @@ def test_attention_model_trains_on_the_fast_path_graph_equals_eager(cuda):
     assert res[False][0] == res[True][0]
     for k in res[False][1]:
         assert torch.equal(res[False][1][k], res[True][1][k]), k
+
+
+@pytest.mark.parametrize("table_mode", ["dense", "lazy"])
+def test_checkpoint_resume_continues_bit_identically(cuda, tmp_path, table_mode):
+    """run.py:447-449 saves {'state_dict', 'optimizer'}: three steps, a checkpoint through torch.save / torch.load
+    (weights_only), a fresh model + optimiser + step restored from it, three more steps == six uninterrupted steps."""
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [50, 3000, 7, 900]
+
+    def make():
+        torch.manual_seed(11)
+        model = PLE(fd, 8, 3, 1, 1, ((16,), (8,)), (8,), dropout=0.2).to(cuda).set_precision("f32")
+        opt = FusedAdam(model, table_mode=table_mode, fast_replay=False, flush_every=4)
+        return model, opt
+
+    r = np.random.default_rng(5)
+    batches = [(torch.from_numpy(make_ids(r, 128, fd)).to(cuda), torch.from_numpy(r.integers(0, 2, size=128).astype(np.int16)).to(cuda),
+                torch.from_numpy(r.integers(0, 3, size=128).astype(np.int64)).to(cuda)) for _ in range(6)]
+    model, opt = make()
+    ts = TrainStep(model, opt, 128)
+    for b in batches:
+        ts.step(*b)
+    opt.flush_table()
+    want = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    want_m = opt.table_m.cpu().clone()
+
+    model, opt = make()
+    ts = TrainStep(model, opt, 128)
+    for b in batches[:3]:
+        ts.step(*b)
+    path = os.path.join(tmp_path, "ckpt.pth.tar")
+    torch.save({"state_dict": model.state_dict(), "optimizer": opt.state_dict()}, path)
+    del ts, opt, model
+    ck = torch.load(path, map_location=cuda, weights_only=True)
+    model, opt = make()
+    model.load_state_dict(ck["state_dict"])
+    opt.load_state_dict(ck["optimizer"])
+    assert int(opt.step_dev.item()) == 3
+    ts = TrainStep(model, opt, 128)
+    for b in batches[3:]:
+        ts.step(*b)
+    opt.flush_table()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), want[k]), f"{k} differs after resume"
+    assert torch.equal(opt.table_m.cpu(), want_m)
