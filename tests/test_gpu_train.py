@@ -388,3 +388,38 @@ def test_checkpoint_resume_continues_bit_identically(cuda, tmp_path, table_mode)
     for k, v in model.state_dict().items():
         assert torch.equal(v.cpu(), want[k]), f"{k} differs after resume"
     assert torch.equal(opt.table_m.cpu(), want_m)
+
+
+def test_runner_fit_keeps_the_best_checkpoint_and_stops_early(cuda, tmp_path):
+    """Run.main / is_continuable (run.py:440-468, 713-770) on the HIP path: epochs of training, validation through the
+    device-side evaluator, best checkpoint by mean_auc, early stop, reload of the best model, test-set evaluation."""
+    from cdcmdr_amd.data import make_loader
+    from cdcmdr_amd.evaluate import Evaluator
+    from cdcmdr_amd.model.mmoe import MMoE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.runner import Runner
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [20, 400, 3, 60, 9]
+    rng = np.random.default_rng(3)
+    n = 4096
+    X = torch.from_numpy(make_ids(rng, n, fd))
+    w = rng.standard_normal(60)
+    y = torch.from_numpy(((w[X[:, 3].numpy()] + 0.5 * rng.standard_normal(n)) > 0).astype(np.int16)).reshape(-1, 1)   # learnable labels
+    d2g = {0: 0, 1: 1, 2: 2}
+    tr, wgt = make_loader(X[:3072], y[:3072], 256, cuda, domain_idx=2, domain2group=d2g)
+    va, _ = make_loader(X[3072:3584], y[3072:3584], 256, cuda, domain_idx=2, domain2group=d2g, shuffle=False)
+    te, _ = make_loader(X[3584:], y[3584:], 256, cuda, domain_idx=2, domain2group=d2g, shuffle=False)
+    torch.manual_seed(0)
+    model = MMoE(fd, 8, 3, 4, (32, 16), (8,), dropout=0.1).to(cuda).set_precision("f32")
+    opt = FusedAdam(model, table_mode="lazy")
+    ts = TrainStep(model, opt, 256, use_graph=True)
+    ev = Evaluator(model, mode="multi", domain_idx=2, n_domain=3, domain_cnt_weight=wgt)
+    logs = []
+    runner = Runner(model, ts, ev, os.path.join(tmp_path, "best.pth.tar"), num_trials=2, log=logs.append)
+    out = runner.fit(tr, va, te, epochs=6)
+    assert 1 <= out["epochs_run"] <= 6 and os.path.exists(os.path.join(tmp_path, "best.pth.tar"))
+    assert out["best"]["total_auc"] > 0.6 and out["test"]["total_auc"] > 0.6           # it learned the planted signal
+    assert runner.best_mean_auc == out["best"]["mean_auc"] and set(out["test"]["domain_auc"]) == {0, 1, 2}
+    # the model now holds the best checkpoint's weights: re-evaluating the validation set reproduces its figures
+    again = ev.test(va)
+    assert abs(again["total_auc"] - out["best"]["total_auc"]) < 1e-12 and abs(again["mean_loss"] - out["best"]["mean_loss"]) < 1e-12
