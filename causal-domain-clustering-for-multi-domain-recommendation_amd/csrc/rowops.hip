@@ -793,6 +793,57 @@ extern "C" int cdc_fm_bwd(const float* e, int64_t lde, const float* dout, int64_
 }
 
 // =================================================================================================
+// per-row choice among n_group side-by-side feature blocks (model/hinet.py:71-74: con_feas[mask_g] = specific_feas[g][mask_g]):
+//   out[b, :] = feas[b, group[b]*H : (group[b]+1)*H]   (zeros when group[b] is outside [0, n_group))
+// backward: the chosen block receives d_out, the other blocks nothing (stored as zeros when this is the first writer)
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_group_select_fwd(const float* __restrict__ feas, int64_t ldf, const int64_t* __restrict__ group,
+                                                          float* __restrict__ out, int64_t ldo, int64_t B, int32_t n_group, int32_t H) {
+    const int64_t total = B * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / H;
+        const int h = (int)(i - b * H);
+        const int64_t g = group[b];
+        out[b * ldo + h] = (g >= 0 && g < n_group) ? feas[b * ldf + g * H + h] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) k_group_select_bwd(const float* __restrict__ dout, int64_t ldd, const int64_t* __restrict__ group,
+                                                          float* __restrict__ dfeas, int64_t ldf, int64_t B, int32_t n_group, int32_t H,
+                                                          int32_t accumulate) {
+    const int64_t total = B * (int64_t)n_group * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / ((int64_t)n_group * H);
+        const int c = (int)(i - b * (int64_t)n_group * H);
+        const int g = c / H, h = c - g * H;
+        const float d = group[b] == g ? dout[b * ldd + h] : 0.f;
+        float* dst = dfeas + b * ldf + c;
+        if (accumulate) { if (d != 0.f) *dst += d; }
+        else *dst = d;
+    }
+}
+extern "C" int cdc_group_select_fwd(const float* feas, int64_t ldf, const int64_t* group, float* out, int64_t ldo, int64_t B,
+                                    int32_t n_group, int32_t H, void* stream) {
+    CDC_CHECK_ARG(feas && group && out && B >= 0 && n_group > 0 && H > 0 && ldf >= (int64_t)n_group * H && ldo >= H, CDC_E_BADARG,
+                  "group_select_fwd: bad argument");
+    if (B == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(B * H, 256), 8192);
+    hipLaunchKernelGGL(k_group_select_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feas, ldf, group, out, ldo, B, n_group, H);
+    CDC_LAUNCH_CHECK("group_select_fwd");
+    return 0;
+}
+extern "C" int cdc_group_select_bwd(const float* dout, int64_t ldd, const int64_t* group, float* dfeas, int64_t ldf, int64_t B,
+                                    int32_t n_group, int32_t H, int32_t accumulate, void* stream) {
+    CDC_CHECK_ARG(dout && group && dfeas && B >= 0 && n_group > 0 && H > 0 && ldf >= (int64_t)n_group * H && ldd >= H, CDC_E_BADARG,
+                  "group_select_bwd: bad argument");
+    if (B == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(B * (int64_t)n_group * H, 256), 8192);
+    hipLaunchKernelGGL(k_group_select_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ldd, group, dfeas, ldf, B, n_group, H,
+                       accumulate);
+    CDC_LAUNCH_CHECK("group_select_bwd");
+    return 0;
+}
+
+// =================================================================================================
 // DCN-v1 cross layer  (model/layer.py:321-329):  out = x0 * (xl . w) + b + xl
 // =================================================================================================
 __global__ void __launch_bounds__(ROW_THREADS) k_cross_fwd(const float* __restrict__ x0, int64_t ld0, const float* __restrict__ xl,

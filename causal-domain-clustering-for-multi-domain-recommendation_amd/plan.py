@@ -1087,6 +1087,30 @@ class AddRelu:
                                         C.c_int64(o.rows), o.cols))
 
 
+class SelectByGroup:
+    """out[b] = the feature block of row b's own group (model/hinet.py:71-74)."""
+
+    def __init__(self, plan, feas, n_group, H, out=None):
+        assert feas.cols == n_group * H
+        self.feas, self.n_group, self.H = feas, n_group, H
+        self.group = torch.zeros(plan.B, dtype=torch.int64, device=plan.device)
+        self.out = out if out is not None else plan.new(H)
+        if feas.mask is not None:
+            raise RuntimeError("group selection cannot consume an activation-fused linear output")
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        plan.fwd_steps.append(plan.call("cdc_group_select_fwd", self.feas.cptr(), C.c_int64(self.feas.ld), _p(self.group), self.out.cptr(),
+                                        C.c_int64(self.out.ld), C.c_int64(plan.B), self.n_group, self.H))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        acc = gs.claim(self.feas)
+        og, fg = self.out.grad, self.feas.grad
+        plan.bwd_steps.append(plan.call("cdc_group_select_bwd", og.cptr(), C.c_int64(og.ld), _p(self.group), fg.cptr(), C.c_int64(fg.ld),
+                                        C.c_int64(plan.B), self.n_group, self.H, 1 if acc else 0))
+
+
 class FMInteraction:
     """Second-order FM term over the gathered embeddings (model/layer.py:160-175): [B, F*D] -> [B, 1]."""
 

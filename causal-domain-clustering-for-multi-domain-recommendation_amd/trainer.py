@@ -21,6 +21,7 @@ class TrainStep:
          "multi"   multi-tower models (PLE / MMoE / CDC split): pred = model(X).gather(1, group)  (run.py:481-484)
          "single"  DCN / DCNv2: pred = model(X)                                                   (run.py:486-488)
          "mean"    CDC warm-up: pred = mean over the towers of model(X)                           (cdc.py:100-102, run.py:616)
+         "single_group"  one output column, but the model itself reads the row's group (HiNet: model(X, group))  (run.py:476-479)
          "star"    STAR: pred, y = model(X, group, targets=y) — rows partitioned by domain, every   (run.py:476-479,
                    partition through its own tower, loss on the group-ordered targets              star.py:109-181)
        train_mode=False: the step runs with the module in EVAL mode (BatchNorm on its running statistics, no dropout) but
@@ -43,7 +44,7 @@ class TrainStep:
         dev = optimizer.device
         self.device = dev
         self.train_mode = bool(train_mode)
-        assert mode in ("multi", "single", "mean", "star")
+        assert mode in ("multi", "single", "mean", "star", "single_group")
         # the plan shares the optimiser's step counter (dropout stream) and its flat gradient arena
         self.holder = self._build_plan()
         self.plan = self.holder.plan
@@ -51,6 +52,8 @@ class TrainStep:
         self.out = self.holder.outputs[0]
         self.y = torch.zeros(self.B, dtype=torch.int16, device=dev)
         self.group = torch.zeros(self.B, dtype=torch.int64, device=dev) if mode == "multi" else None
+        if mode == "single_group":
+            self.group_in = self.holder.inputs[1]                 # int64 [B] read by the plan's group-selection launch
         if mode == "star":
             self.group = self.holder.inputs[1]                    # the partition kernel reads the domain of every row here
             self.order = self.holder.extra_outputs[0]             # row order after the partition (ascending group)
@@ -333,6 +336,8 @@ class TrainStep:
         self.y.copy_(y.reshape(-1))
         if self.group is not None:
             self.group.copy_(group.reshape(-1))
+        if self.mode == "single_group":
+            self.group_in.copy_(group.reshape(-1))
         if self.world > 1:
             self._step_dp()
         elif self.use_graph and self._warm >= 2:

@@ -423,6 +423,14 @@ int cdc_fm_fwd(const float* e, int64_t lde, float* out, int64_t ldo, int64_t B, 
 int cdc_fm_bwd(const float* e, int64_t lde, const float* dout, int64_t ldd, float* de, int64_t ldde, int64_t B, int32_t F,
                int32_t D, int32_t accumulate, void* stream);
 
+/* Per-row choice among n_group side-by-side feature blocks (reference: model/hinet.py:71-74, `con_feas[mask_g] =
+ * specific_feas[g][mask_g]`): out[b,:] = feas[b, group[b]*H:(group[b]+1)*H] (zeros for a group id outside [0,n_group));
+ * backward: d_feas gets d_out in the chosen block and nothing elsewhere (zeros are stored unless `accumulate`). */
+int cdc_group_select_fwd(const float* feas, int64_t ldf, const int64_t* group, float* out, int64_t ldo, int64_t B,
+                         int32_t n_group, int32_t H, void* stream);
+int cdc_group_select_bwd(const float* dout, int64_t ldd, const int64_t* group, float* dfeas, int64_t ldf, int64_t B,
+                         int32_t n_group, int32_t H, int32_t accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * CrossNetwork (DCN v1) layer (reference: model/layer.py:321-329): out = x0 * (xl·w) + b + xl
  * ---------------------------------------------------------------------------------------- */

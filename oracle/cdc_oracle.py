@@ -304,6 +304,35 @@ def deepfm_forward(sd, x_i32, field_dims, training=True, stats_out=None):
     return torch.sigmoid(wide_logit(e, sd) + fm_term(e.reshape(e.shape[0], -1, D)) + deep).squeeze(1)
 
 
+def _sei(e, sd, prefix, training, stats_out):
+    """SEI.forward (model/hinet.py:16-21): expert MLPs mixed by a softmax gate."""
+    n = _count(sd, re.escape(prefix) + r"\.experts\.(\d+)\.")
+    fea = torch.stack([mlp(e, sd, f"{prefix}.experts.{k}", training, stats_out) for k in range(n)], dim=1)
+    gate = torch.softmax(_lin(e, sd, f"{prefix}.gate.0"), dim=1)
+    return (gate.unsqueeze(-1) * fea).sum(1)
+
+
+def hinet_forward(sd, x_i32, field_dims, x_group, domain_idx, training=True, stats_out=None):
+    """HiNet.forward (model/hinet.py:61-92)."""
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    D = sd["embedding.embedding_dict.weight"].shape[1]
+    n_tower = _count(sd, r"specific_seis\.(\d+)\.")
+    spec = [_sei(e, sd, f"specific_seis.{i}", training, stats_out) for i in range(n_tower)]
+    shared = _sei(e, sd, "shared_seis", training, stats_out)
+    dom = e[:, domain_idx * D:(domain_idx + 1) * D]
+    san_gate = torch.softmax(_lin(dom, sd, "san_gate.0"), dim=1)
+    stacked = torch.stack(spec, dim=1)
+    san = (san_gate.unsqueeze(-1) * stacked).sum(1)
+    g = torch.as_tensor(x_group).reshape(-1)
+    onehot = torch.stack([(g == i).float() for i in range(n_tower)], dim=1)
+    con = (onehot.unsqueeze(-1) * stacked).sum(1)
+    tower = mlp(torch.cat([shared, con, san], dim=1), sd, "tower", training, stats_out)
+    logit = tower @ sd["tower_linear.weight"].t()
+    for o in other_logits(e, sd):
+        logit = logit + o
+    return torch.sigmoid(logit).squeeze(1)
+
+
 def dcnv2_forward(sd, x_i32, field_dims, training=True, stats_out=None, model_structure="parallel"):
     e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
     if "crossnet.u_list.0" in sd:
@@ -438,6 +467,8 @@ def reg_names(names, model_kind):
         elif model_kind == "deepfm" and top == "mlp" and "weight" in rel and "bn" not in rel:
             out.append(n)
         elif model_kind == "autoint" and top == "dnn" and "weight" in rel and "bn" not in rel:
+            out.append(n)
+        elif model_kind == "hinet" and top in ("specific_seis", "shared_seis", "san_gate", "tower") and "weight" in rel and "bn" not in rel:
             out.append(n)
         elif model_kind == "dcnv2":
             if top == "dnn" and "weight" in rel and "bn" not in rel:

@@ -139,7 +139,7 @@ def test_mirror_state_dict_keys_equal_the_reference_goldens():
 
 
 def test_import_safe_placeholders_for_the_rest_of_the_zoo():
-    from cdcmdr_amd.model import pepnet, adl, hinet, adasparse  # noqa: F401  (run.py:15-26 imports all of them)
+    from cdcmdr_amd.model import pepnet, adl, adasparse  # noqa: F401  (run.py:15-26 imports all of them)
     with pytest.raises(NotImplementedError):
         pepnet.PEPNet()
 

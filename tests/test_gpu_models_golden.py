@@ -290,3 +290,43 @@ def test_attention_core_against_torch(cuda, B, F, A, H):
     lhs = out2.reshape(B, F, H, dh).sum(dim=1)
     rhs = (dv[..., :1] * vsum).sum(dim=1)
     assert_close(lhs, rhs, 1e-4, 1e-5, "dropout mask consistent between forward and backward")
+
+
+def test_hinet_matches_reference_golden(cuda):
+    """G14: HiNet(x, x_group, targets) -> (pred, targets): forward, BCE, regularisation term, every gradient, BatchNorm
+    statistics, eval forward against the reference; plus one TrainStep(mode="single_group") step equal to the drop-in path."""
+    import types
+    from cdcmdr_amd.model.hinet import HiNet
+    d = load("g14_hinet")
+    cfg = types.SimpleNamespace(use_atten=False, use_dcn=False)
+    model = HiNet(FD, 4, n_tower=3, sei_dims=(16, 8), tower_dims=(8, 4), domain_idx=2, device=cuda, dropout=0.0, config=cfg).to(cuda).set_precision("f32")
+    model.load_state_dict(sd_of(d))
+    names = set(model.state_dict().keys())
+    x = torch.from_numpy(d["x"]).to(cuda)
+    y = torch.from_numpy(d["y"]).to(cuda)
+    g = torch.from_numpy(d["group"]).to(cuda)
+    model.train()
+    pred, tt = model(x, g, targets=y)
+    assert tt is y
+    bce = torch.nn.BCELoss()(pred, tt.reshape(-1).float())
+    reg = model.get_regularization_loss(device=cuda)
+    model.zero_grad()
+    (bce + reg).backward()
+    assert_close(pred, d["train_pred"], RTOL, ATOL, "train_pred")
+    assert_close(bce, d["bce"], RTOL, ATOL, "bce")
+    assert_close(reg.reshape(-1), d["reg"].reshape(-1), 1e-5, 1e-7, "reg")
+    check_grads(model, d, names)
+    sd = model.state_dict()
+    for k in d.files:
+        if k.startswith("sd_after/"):
+            assert_close(sd[k[9:]], d[k], RTOL, ATOL, k)
+    model.eval()
+    with torch.no_grad():
+        assert_close(model(x, g)[0], d["eval_pred"], RTOL, ATOL, "eval_pred")
+    # fast path: same loss on the same parameters
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    model.load_state_dict(sd_of(d))
+    ts = TrainStep(model, FusedAdam(model, table_mode="dense"), x.shape[0], mode="single_group")
+    got, _ = ts.step(x, y, g)
+    assert_close(got, d["bce"].reshape(1), 1e-4, 1e-6, "fast-path bce")

@@ -52,6 +52,7 @@ MODELS = {
     "g12_mmoe4_atten_nores": ("mmoe", lambda sd, x, tr, so: O.mmoe_forward(sd, x, FD, 3, tr, so)),
     "g12_star3_atten": ("star", lambda sd, x, tr, so: O.star_forward(sd, x, FD, 3, training=tr, stats_out=so)),
     "g13_autoint": ("autoint", lambda sd, x, tr, so: O.autoint_forward(sd, x, FD, tr, so)),
+    "g14_hinet": ("hinet", lambda sd, x, tr, so: O.hinet_forward(sd, x, FD, load("g14_hinet")["group"], 2, tr, so)),
     "g11_deepfm": ("deepfm", lambda sd, x, tr, so: O.deepfm_forward(sd, x, FD13, tr, so)),
 }
 FD = [7, 100, 3, 50, 11, 29]
@@ -68,7 +69,7 @@ def test_g2_model_forward_backward(name):
     d = load(name)
     sd = sd_of(d)
     x, y = d["x"], torch.from_numpy(d["y"]).reshape(-1)
-    group = torch.from_numpy(d["group"]) if "group" in d.files else None
+    group = torch.from_numpy(d["group"]) if "group" in d.files and name != "g14_hinet" else None    # HiNet reads the group itself
     stats = {}
 
     def loss_fn(s):
