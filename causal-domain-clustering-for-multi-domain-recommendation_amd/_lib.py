@@ -194,6 +194,8 @@ _SIGNATURES = {
     "cdc_attn_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),
     "cdc_add_relu_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_p]),
     "cdc_add_relu_bwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i32, c_p, c_i64, c_i32, c_i64, c_i32, c_p]),
+    "cdc_sigmoid_gate_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_f, c_f, c_f, c_p]),
+    "cdc_sigmoid_gate_bwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i32, c_p, c_i64, c_i32, c_i64, c_i32, c_f, c_f, c_f, c_p]),
     "cdc_group_select_fwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
     "cdc_group_select_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_fm_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),

@@ -844,6 +844,71 @@ extern "C" int cdc_group_select_bwd(const float* dout, int64_t ldd, const int64_
 }
 
 // =================================================================================================
+// sigmoid gate:  pi = beta * sigmoid(alpha * p);  pi = 0 where |pi| <= eps;  out = a * pi
+//   AdaSparse's pruner (model/adasparse.py:52-56: beta 2, alpha 1, eps 0.25) and PEPNet's GateNN output applied to its
+//   input (model/pepnet.py:79-80,125: beta 2, alpha 1, no threshold: eps < 0).
+// backward: d a = d out * pi;  d p = d out * a * beta*alpha*s*(1-s) where the gate is not pruned, 0 where it is.
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_sigmoid_gate_fwd(const float* __restrict__ a, int64_t lda, const float* __restrict__ p, int64_t ldp,
+                                                          float* __restrict__ out, int64_t ldo, int64_t rows, int32_t cols, float beta,
+                                                          float alpha, float eps) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        float pi = beta / (1.f + expf(-alpha * p[r * ldp + c]));
+        if (fabsf(pi) - eps <= 0.f) pi = 0.f;
+        out[r * ldo + c] = a[r * lda + c] * pi;
+    }
+}
+__global__ void __launch_bounds__(256) k_sigmoid_gate_bwd(const float* __restrict__ a, int64_t lda, const float* __restrict__ p, int64_t ldp,
+                                                          const float* __restrict__ dout, int64_t lddo, float* __restrict__ da, int64_t ldda,
+                                                          int32_t acc_a, float* __restrict__ dp, int64_t lddp, int32_t acc_p, int64_t rows,
+                                                          int32_t cols, float beta, float alpha, float eps) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float s = 1.f / (1.f + expf(-alpha * p[r * ldp + c]));
+        float pi = beta * s;
+        const bool pruned = fabsf(pi) - eps <= 0.f;
+        if (pruned) pi = 0.f;
+        const float g = dout[r * lddo + c];
+        if (da) {
+            float* d = da + r * ldda + c;
+            const float v = g * pi;
+            *d = acc_a ? *d + v : v;
+        }
+        if (dp) {
+            float* d = dp + r * lddp + c;
+            const float v = pruned ? 0.f : g * a[r * lda + c] * beta * alpha * s * (1.f - s);
+            *d = acc_p ? *d + v : v;
+        }
+    }
+}
+extern "C" int cdc_sigmoid_gate_fwd(const float* a, int64_t lda, const float* p, int64_t ldp, float* out, int64_t ldo, int64_t rows,
+                                    int32_t cols, float beta, float alpha, float eps, void* stream) {
+    CDC_CHECK_ARG(a && p && out && rows >= 0 && cols > 0 && lda >= cols && ldp >= cols && ldo >= cols, CDC_E_BADARG, "sigmoid_gate_fwd: bad argument");
+    if (rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(rows * cols, 256), 8192);
+    hipLaunchKernelGGL(k_sigmoid_gate_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, lda, p, ldp, out, ldo, rows, cols, beta, alpha, eps);
+    CDC_LAUNCH_CHECK("sigmoid_gate_fwd");
+    return 0;
+}
+extern "C" int cdc_sigmoid_gate_bwd(const float* a, int64_t lda, const float* p, int64_t ldp, const float* dout, int64_t lddo, float* da,
+                                    int64_t ldda, int32_t acc_a, float* dp, int64_t lddp, int32_t acc_p, int64_t rows, int32_t cols,
+                                    float beta, float alpha, float eps, void* stream) {
+    CDC_CHECK_ARG(a && p && dout && (da || dp) && rows >= 0 && cols > 0 && lda >= cols && ldp >= cols && lddo >= cols &&
+                      (!da || ldda >= cols) && (!dp || lddp >= cols), CDC_E_BADARG, "sigmoid_gate_bwd: bad argument");
+    if (rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(rows * cols, 256), 8192);
+    hipLaunchKernelGGL(k_sigmoid_gate_bwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, lda, p, ldp, dout, lddo, da, ldda, acc_a, dp,
+                       lddp, acc_p, rows, cols, beta, alpha, eps);
+    CDC_LAUNCH_CHECK("sigmoid_gate_bwd");
+    return 0;
+}
+
+// =================================================================================================
 // DCN-v1 cross layer  (model/layer.py:321-329):  out = x0 * (xl . w) + b + xl
 // =================================================================================================
 __global__ void __launch_bounds__(ROW_THREADS) k_cross_fwd(const float* __restrict__ x0, int64_t ld0, const float* __restrict__ xl,

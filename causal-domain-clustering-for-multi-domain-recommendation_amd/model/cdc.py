@@ -4,7 +4,7 @@ Mirror of the reference's model/cdc.py (CDC.__init__ 24-93, forward 95-111, get_
 121-236, get_source_domain 238-293, update_p_weight 295-304, calc_metric_in_source_group 306-310,
 get_center_domain_in_group 312-318, calc_domain_lambda_in_group 320-341, save/load_model_state 343-354,
 get_regularization_loss 356-357, kmeans_group 359-362, calc_causal_matrix 364-396, save_draw_matrix 398-403).
-The base model (MMoE / PLE / STAR) runs on the HIP kernels; CDC itself only selects a tower output per row.  The
+The base model (MMoE / PLE / STAR / PEPNet / EPNet) runs on the HIP kernels; CDC itself only selects a tower output per row.  The
 clustering arithmetic (O(n_domain^2) numpy/scipy/sklearn/torch work on 30x30 matrices, host side) lives in
 `clustering.py` and is pinned against the reference's own outputs (tests/test_cdc_group.py)."""
 import copy
@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from .. import clustering
 from .layer import BaseModel
 from .mmoe import MMoE
+from .pepnet import PEPNet
 from .ple import PLE
 from .star import STAR
 
@@ -40,8 +41,10 @@ class CDC(BaseModel):
         elif base_model == 'star':
             self.base_model_instance = STAR(feature_dims, embed_dim, n_tower, tower_dims, domain_idx, dropout, config,
                                             l2_reg_embedding, l2_reg_linear, l2_reg_dnn, l2_reg_cross, device)
-        elif base_model in ('pepnet', 'epnet'):
-            raise NotImplementedError("PEPNet/EPNet bases are outside the HIP hot path (SURVEY.md §8f row N4)")
+        elif base_model in ('pepnet', 'epnet'):                       # cdc.py:43-50
+            self.base_model_instance = PEPNet(feature_dims, embed_dim, n_tower, tower_dims, config.gate_hidden_dim, domain_idx,
+                                              base_model == 'pepnet', dropout, config, l2_reg_embedding, l2_reg_linear,
+                                              l2_reg_dnn, l2_reg_cross)
         else:
             raise ValueError('Unknown base model: ' + str(base_model))
         self.use_dcn = getattr(config, 'use_dcn', False)

@@ -1087,6 +1087,82 @@ class AddRelu:
                                         C.c_int64(o.rows), o.cols))
 
 
+class HostStep:
+    """A few torch ops inside the launch sequence (they run on the current stream and are captured with the graph):
+    fwd and/or bwd are callables without arguments.  In the backward the step runs where reverse op order puts it."""
+
+    def __init__(self, plan, fwd=None, bwd=None):
+        self.fwd, self.bwd = fwd, bwd
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        if self.fwd is not None:
+            plan.fwd_steps.append(lambda stream, fn=self.fwd: fn())
+
+    def build_bwd(self, plan, gs):
+        if self.bwd is not None:
+            plan.bwd_steps.append(lambda stream, fn=self.bwd: fn())
+
+
+class CopyCols:
+    """dst <- src for two [rows, cols] views of any row stride (one piece of a torch.cat); detach=True: no gradient flows
+    back (`.detach()` in the reference, e.g. model/pepnet.py:79, model/adasparse.py:96)."""
+
+    def __init__(self, plan, src, dst, detach=False):
+        assert src.rows == dst.rows and src.cols == dst.cols
+        self.src, self.dst, self.detach = src, dst, detach
+        if src.mask is not None:
+            raise RuntimeError("a concatenation piece cannot be an activation-fused linear output")
+        plan.add(self)
+
+    def build_fwd(self, plan):
+        s_, d_ = self.src, self.dst
+        plan.fwd_steps.append(plan.call("cdc_copy_or_add", d_.cptr(), C.c_int64(d_.ld), s_.cptr(), C.c_int64(s_.ld), C.c_int64(s_.rows), s_.cols, 0))
+
+    def build_bwd(self, plan, gs):
+        if self.detach:
+            return
+        plan.ensure_grad(self.dst, gs)
+        acc = gs.claim(self.src)
+        dg, sg = self.dst.grad, self.src.grad
+        plan.bwd_steps.append(plan.call("cdc_copy_or_add", sg.cptr(), C.c_int64(sg.ld), dg.cptr(), C.c_int64(dg.ld), C.c_int64(sg.rows), sg.cols,
+                                        1 if acc else 0))
+
+
+class SigmoidGate:
+    """out = a * (beta * sigmoid(alpha * p), zeroed where <= eps)  (AdaSparse's pruner, PEPNet's GateNN product)."""
+
+    def __init__(self, plan, a, p, beta=2.0, alpha=1.0, eps=-1.0, detach_a=False, out=None):
+        assert a.rows == p.rows and a.cols == p.cols
+        self.a, self.p, self.beta, self.alpha, self.eps, self.detach_a = a, p, float(beta), float(alpha), float(eps), detach_a
+        self.out = out if out is not None else plan.new(a.cols, rows=a.rows)
+        if a.mask is not None or p.mask is not None:
+            raise RuntimeError("the sigmoid gate cannot consume an activation-fused linear output")
+        plan.add(self)
+
+    def _consts(self):
+        return C.c_float(self.beta), C.c_float(self.alpha), C.c_float(self.eps)
+
+    def build_fwd(self, plan):
+        a, p, o = self.a, self.p, self.out
+        plan.fwd_steps.append(plan.call("cdc_sigmoid_gate_fwd", a.cptr(), C.c_int64(a.ld), p.cptr(), C.c_int64(p.ld), o.cptr(), C.c_int64(o.ld),
+                                        C.c_int64(a.rows), a.cols, *self._consts()))
+
+    def build_bwd(self, plan, gs):
+        plan.ensure_grad(self.out, gs)
+        a, p, og = self.a, self.p, self.out.grad
+        acc_p = gs.claim(p)
+        pg = p.grad
+        if self.detach_a:
+            da, ldda, acc_a = None, C.c_int64(0), 0
+        else:
+            acc_a = 1 if gs.claim(a) else 0
+            da, ldda = a.grad.cptr(), C.c_int64(a.grad.ld)
+        plan.bwd_steps.append(plan.call("cdc_sigmoid_gate_bwd", a.cptr(), C.c_int64(a.ld), p.cptr(), C.c_int64(p.ld), og.cptr(), C.c_int64(og.ld),
+                                        da, ldda, acc_a, pg.cptr(), C.c_int64(pg.ld), 1 if acc_p else 0, C.c_int64(a.rows), a.cols,
+                                        *self._consts()))
+
+
 class SelectByGroup:
     """out[b] = the feature block of row b's own group (model/hinet.py:71-74)."""
 

@@ -431,6 +431,15 @@ int cdc_group_select_fwd(const float* feas, int64_t ldf, const int64_t* group, f
 int cdc_group_select_bwd(const float* dout, int64_t ldd, const int64_t* group, float* dfeas, int64_t ldf, int64_t B,
                          int32_t n_group, int32_t H, int32_t accumulate, void* stream);
 
+/* Sigmoid gate (reference: model/adasparse.py:52-56 — the pruner: beta 2, alpha 1, eps 0.25; model/pepnet.py:79-80,125 —
+ * GateNN's `sigmoid(.) * 2` applied to its input: eps < 0):  pi = beta*sigmoid(alpha*p), pi = 0 where |pi| <= eps,
+ * out = a * pi.  Backward: da (+)= dout*pi, dp (+)= dout*a*d(pi)/dp (0 where pruned); da or dp may be NULL (detached). */
+int cdc_sigmoid_gate_fwd(const float* a, int64_t lda, const float* p, int64_t ldp, float* out, int64_t ldo, int64_t rows,
+                         int32_t cols, float beta, float alpha, float eps, void* stream);
+int cdc_sigmoid_gate_bwd(const float* a, int64_t lda, const float* p, int64_t ldp, const float* dout, int64_t lddo, float* da,
+                         int64_t ldda, int32_t acc_a, float* dp, int64_t lddp, int32_t acc_p, int64_t rows, int32_t cols,
+                         float beta, float alpha, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * CrossNetwork (DCN v1) layer (reference: model/layer.py:321-329): out = x0 * (xl·w) + b + xl
  * ---------------------------------------------------------------------------------------- */

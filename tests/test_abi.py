@@ -139,9 +139,9 @@ def test_mirror_state_dict_keys_equal_the_reference_goldens():
 
 
 def test_import_safe_placeholders_for_the_rest_of_the_zoo():
-    from cdcmdr_amd.model import pepnet, adl, adasparse  # noqa: F401  (run.py:15-26 imports all of them)
+    from cdcmdr_amd.model import adl  # noqa: F401  (run.py:15-26 imports every model module; ADL is the one still a placeholder)
     with pytest.raises(NotImplementedError):
-        pepnet.PEPNet()
+        adl.ADL()
 
 
 def test_compat_package_serves_the_reference_import_names():

@@ -47,8 +47,23 @@ def build(name):
         "g12_star3_atten": lambda: STAR(FD, 4, 3, (32, 16, 8), None, 0.0, _atten_cfg(True)),
         "g13_autoint": lambda: __import__("cdcmdr_amd.model.autoint", fromlist=["AutoInt"]).AutoInt(
             FD, 4, atten_embed_dim=8, att_layer_num=2, att_head_num=2, att_res=True, mlp_dims=(32, 16), dropout=0.0),
+        "g13_adasparse": lambda: __import__("cdcmdr_amd.model.adasparse", fromlist=["AdaSparse"]).AdaSparse(
+            FD, 4, (32, 16, 8), domain_idx=2, dropout=0.0, config=_atten_cfg_off()),
+        "g16_pepnet": lambda: _pepnet(3, True),
+        "g16_epnet": lambda: _pepnet(3, False),
+        "g13_epnet_single": lambda: _pepnet(1, False),
         "g11_deepfm": lambda: __import__("cdcmdr_amd.model.dfm", fromlist=["DeepFM"]).DeepFM(FD13, 4, (32, 16, 8), dropout=0.0),
     }[name]()
+
+
+def _pepnet(n_tower, use_ppnet):
+    from cdcmdr_amd.model.pepnet import PEPNet
+    return PEPNet(FD, 4, n_tower, (16, 8), gate_hidden_dim=8, domain_idx=2, use_ppnet=use_ppnet, dropout=0.0, config=_atten_cfg_off())
+
+
+def _atten_cfg_off():
+    import types
+    return types.SimpleNamespace(use_atten=False, use_dcn=False)
 
 
 def _atten_cfg(att_res):
@@ -79,7 +94,7 @@ def check_grads(model, d, names):
 
 @pytest.mark.parametrize("name", ["g2_ple3", "g2_mmoe4", "g2_mmoe8", "g2_dcn13", "g2_dcnv2_mix", "g2_dcnv2_stacked",
                                   "g2_star5_all", "g2_star30_all", "g11_deepfm", "g12_ple3_atten", "g12_mmoe4_atten_nores",
-                                  "g12_star3_atten", "g13_autoint"])
+                                  "g12_star3_atten", "g13_autoint", "g13_adasparse", "g16_pepnet", "g16_epnet", "g13_epnet_single"])
 def test_model_matches_reference_golden(cuda, name):
     d = load(name)
     model = build(name).to(cuda).set_precision("f32")
