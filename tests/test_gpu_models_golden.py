@@ -345,3 +345,39 @@ def test_hinet_matches_reference_golden(cuda):
     ts = TrainStep(model, FusedAdam(model, table_mode="dense"), x.shape[0], mode="single_group")
     got, _ = ts.step(x, y, g)
     assert_close(got, d["bce"].reshape(1), 1e-4, 1e-6, "fast-path bce")
+
+
+def test_adl_matches_reference_golden(cuda):
+    """G17: ADL — routing by the moving cluster centres, rows partitioned by their tower, per-tower BatchNorm statistics,
+    fused output layers; training forward (predictions in tower order + permuted targets), every gradient, the centres after
+    each call, BatchNorm statistics, `is_training=False` forward in batch order."""
+    from cdcmdr_amd.model.adl import ADL
+    d = load("g17_adl")
+    model = ADL(FD, 4, n_tower=3, tower_dims=(16, 8), domain_idx=2, dropout=0.0, device=cuda, config=_atten_cfg_off()).to(cuda).set_precision("f32")
+    model.load_state_dict(sd_of(d))
+    assert "cluster_centers" not in model.state_dict()                     # a plain attribute in the reference
+    model.cluster_centers = torch.from_numpy(d["centers0"]).to(cuda)
+    names = set(model.state_dict().keys())
+    x = torch.from_numpy(d["x"]).to(cuda)
+    y = torch.from_numpy(d["y"]).to(cuda)
+    model.train()
+    pred, tt = model(x, None, targets=y, is_training=True)
+    assert torch.equal(tt.cpu(), torch.from_numpy(d["train_targets"]))     # same routing, stable partition
+    assert_close(model.cluster_centers, d["centers1"], 1e-5, 1e-6, "centres after the training forward")
+    bce = torch.nn.BCELoss()(pred.squeeze(1), tt.reshape(-1).float())
+    reg = model.get_regularization_loss(device=cuda)
+    model.zero_grad()
+    (bce + reg).backward()
+    assert_close(pred, d["train_pred"], RTOL, ATOL, "train_pred")
+    assert_close(bce, d["bce"], RTOL, ATOL, "bce")
+    assert_close(reg.reshape(-1), d["reg"].reshape(-1), 1e-5, 1e-7, "reg")
+    check_grads(model, d, names)
+    sd = model.state_dict()
+    for k in d.files:
+        if k.startswith("sd_after/"):
+            assert_close(sd[k[9:]], d[k], RTOL, ATOL, k)
+    model.eval()
+    with torch.no_grad():
+        ev = model(x, is_training=False)
+    assert_close(ev, d["eval_pred"], RTOL, ATOL, "eval_pred")
+    assert_close(model.cluster_centers, d["centers2"], 1e-5, 1e-6, "centres after the eval forward")
