@@ -174,3 +174,27 @@ extern "C" int cdc_add_inplace(float* dst, int64_t ld_dst, const float* src, int
     CDC_LAUNCH_CHECK("add_inplace");
     return 0;
 }
+
+
+// one launch instead of three device-to-device copies: a batch (ids int32 [B,F], labels int16 [B], tower index int64 [B] or
+// NULL) into the buffers a replayed launch sequence reads (run.py:476-479 hands the step exactly these three tensors)
+__global__ void __launch_bounds__(256) k_stage_batch(const int32_t* __restrict__ ids, const int16_t* __restrict__ y,
+                                                     const int64_t* __restrict__ group, int32_t* __restrict__ ids_dst,
+                                                     int16_t* __restrict__ y_dst, int64_t* __restrict__ group_dst, int64_t B, int32_t F) {
+    const int64_t n = B * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        ids_dst[i] = ids[i];
+        if (i < B) {
+            y_dst[i] = y[i];
+            if (group) group_dst[i] = group[i];
+        }
+    }
+}
+extern "C" int cdc_stage_batch(const int32_t* ids, const int16_t* y, const int64_t* group, int32_t* ids_dst, int16_t* y_dst,
+                               int64_t* group_dst, int64_t B, int32_t F, void* stream) {
+    CDC_CHECK_ARG(ids && y && ids_dst && y_dst && B > 0 && F > 0 && (!group || group_dst), CDC_E_BADARG, "stage_batch: bad argument");
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(B * F, 256), 2048);
+    hipLaunchKernelGGL(k_stage_batch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, y, group, ids_dst, y_dst, group_dst, B, F);
+    CDC_LAUNCH_CHECK("stage_batch");
+    return 0;
+}

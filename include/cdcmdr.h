@@ -522,7 +522,11 @@ int cdc_sum_slices(const float* in, int64_t ld_in, float* out, int64_t ld_out, i
 
 /* small utilities used by the step driver */
 int cdc_step_increment(int32_t* step_dev, void* stream);                 /* ++*step_dev */
-int cdc_begin_step(int32_t* step_dev, double* accumulators, int32_t n_acc, void* stream);   /* ++*step_dev and zero n_acc doubles */
+int cdc_begin_step(int32_t* step_dev, double* accumulators, int32_t n_acc, void* stream);
+/* one batch into the static buffers of a replayed launch sequence: ids int32 [B,F], labels int16 [B], tower index int64 [B]
+ * (group / group_dst may be NULL) — the three tensors run.py:476-479 hands to a step; one launch instead of three copies */
+int cdc_stage_batch(const int32_t* ids, const int16_t* y, const int64_t* group, int32_t* ids_dst, int16_t* y_dst,
+                    int64_t* group_dst, int64_t B, int32_t F, void* stream);   /* ++*step_dev and zero n_acc doubles */
 int cdc_fill_f32(float* p, float value, int64_t n, void* stream);
 int cdc_fill_f64(double* p, double value, int64_t n, void* stream);
 /* dst[r*ld_dst + c] += src[r*ld_src + c]  (gradient fan-in where a kernel cannot accumulate itself) */
