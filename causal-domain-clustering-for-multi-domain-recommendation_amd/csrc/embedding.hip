@@ -538,7 +538,8 @@ template <bool FAST, int VEC>
 __global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
                                                       float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                       int32_t* __restrict__ last, cdc_adam_hp hp,
-                                                      const int32_t* __restrict__ step_dev, int32_t B, int32_t F, int32_t D) {
+                                                      const int32_t* __restrict__ step_dev, int32_t B, int32_t F, int32_t D,
+                                                      int32_t mark) {
     const AdamConsts c = make_consts(hp);
     const int target = *step_dev - 1;
     const int chunks = D / VEC;
@@ -572,7 +573,10 @@ __global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict_
         } else {
             w[e0] = wv[0]; m[e0] = mv[0]; v[e0] = vv[0];
         }
-        // last[row] is advanced by k_lazy_mark afterwards: every lane of the row reads it here
+        // every lane of the row has read last[row] above.  mark: the row's `chunks` lanes sit in ONE wave (chunks divides 64),
+        // whose load of last[row] has completed for all of them before this later store issues — lane 0 of the row
+        // advances it here; otherwise k_lazy_mark does it in a separate launch.
+        if (mark && d == 0) last[row] = target;
     }
 }
 __global__ void __launch_bounds__(256) k_lazy_mark(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
@@ -601,17 +605,21 @@ extern "C" int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* un
     const int64_t total = (int64_t)F * B * (vec ? D / 4 : D);
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
     CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_catchup: fast_replay needs the inv_bc2 table");
+    const int32_t chunks = vec ? D / 4 : D;
+    const int32_t mark = (64 % chunks == 0) ? 1 : 0;
 #define CDC_CATCHUP(FASTV, VECV)                                                                                                 \
     hipLaunchKernelGGL((k_lazy_catchup<FASTV, VECV>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, w, m, \
-                       v, last, hp, step_dev, (int32_t)B, F, D)
+                       v, last, hp, step_dev, (int32_t)B, F, D, mark)
     if (hp.fast_replay) { if (vec) CDC_CATCHUP(true, 4); else CDC_CATCHUP(true, 1); }
     else                { if (vec) CDC_CATCHUP(false, 4); else CDC_CATCHUP(false, 1); }
 #undef CDC_CATCHUP
     CDC_LAUNCH_CHECK("embed_lazy_catchup");
-    int blocks2 = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 256 * 16);
-    hipLaunchKernelGGL(k_lazy_mark, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, last, step_dev,
-                       (int32_t)B, F);
-    CDC_LAUNCH_CHECK("embed_lazy_mark");
+    if (!mark) {
+        int blocks2 = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 256 * 16);
+        hipLaunchKernelGGL(k_lazy_mark, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, last, step_dev,
+                           (int32_t)B, F);
+        CDC_LAUNCH_CHECK("embed_lazy_mark");
+    }
     return 0;
 }
 
@@ -661,9 +669,9 @@ extern "C" int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_r
 // Rows not looked up since their last flush share one `last`, so whole waves replay the same steps.
 template <bool FAST, int VEC>
 __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
-                                                    const int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
+                                                    int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
                                                     const int32_t* __restrict__ step_dev, int32_t step_bias, int32_t period,
-                                                    int32_t own_mod, int32_t own_rem) {
+                                                    int32_t own_mod, int32_t own_rem, int32_t mark) {
     const int target = *step_dev + step_bias;
     // period > 1: this call handles one slice of the table, slice (target mod period) — every row is brought up to date
     // once per `period` steps, a 1/period share of the work in every step instead of a burst
@@ -706,6 +714,7 @@ __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float
         } else {
             w[e0] = wv[0]; m[e0] = mv[0]; v[e0] = vv[0];
         }
+        if (mark && (i % chunks) == 0) last[row] = target;        // the row's lanes share one wave (see k_lazy_catchup)
     }
 }
 __global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ last, int64_t R, const int32_t* __restrict__ step_dev,
@@ -735,17 +744,21 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
     if (own_mod > 1) rows_call = cdc_ceil_div(rows_call, own_mod) + 1;
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdc_ceil_div(rows_call * D / (vec ? 4 : 1), 256), 256 * 16));
     hipStream_t st = (hipStream_t)stream;
+    const int32_t chunks = vec ? D / 4 : D;
+    const int32_t mark = (64 % chunks == 0) ? 1 : 0;             // last[] advanced inside the kernel; else by k_lazy_set_last
     if (hp.fast_replay) {
-        if (vec) hipLaunchKernelGGL((k_lazy_flush<true, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
-        else     hipLaunchKernelGGL((k_lazy_flush<true, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
+        if (vec) hipLaunchKernelGGL((k_lazy_flush<true, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark);
+        else     hipLaunchKernelGGL((k_lazy_flush<true, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark);
     } else {
-        if (vec) hipLaunchKernelGGL((k_lazy_flush<false, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
-        else     hipLaunchKernelGGL((k_lazy_flush<false, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem);
+        if (vec) hipLaunchKernelGGL((k_lazy_flush<false, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark);
+        else     hipLaunchKernelGGL((k_lazy_flush<false, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark);
     }
     CDC_LAUNCH_CHECK("embed_lazy_flush");
-    int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>(cdc_ceil_div(period > 1 ? cdc_ceil_div(R, period) : R, 256), 256 * 16));
-    hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias, period, own_mod, own_rem);
-    CDC_LAUNCH_CHECK("embed_lazy_set_last");
+    if (!mark) {
+        int blocks2 = (int)std::max<int64_t>(1, std::min<int64_t>(cdc_ceil_div(period > 1 ? cdc_ceil_div(R, period) : R, 256), 256 * 16));
+        hipLaunchKernelGGL(k_lazy_set_last, dim3(blocks2), dim3(256), 0, (hipStream_t)stream, last, R, step_dev, step_bias, period, own_mod, own_rem);
+        CDC_LAUNCH_CHECK("embed_lazy_set_last");
+    }
     return 0;
 }
 
