@@ -333,6 +333,112 @@ def hinet_forward(sd, x_i32, field_dims, x_group, domain_idx, training=True, sta
     return torch.sigmoid(logit).squeeze(1)
 
 
+def adasparse_forward(sd, x_i32, field_dims, domain_idx, training=True, stats_out=None):
+    """AdaSparse.forward + DNN_w_Pruner.forward (model/adasparse.py:45-65,94-116): per layer fc * pi with
+    pi = 2*sigmoid(pruner(cat[h, dom.detach()])), pi <= 0.25 cut to 0 (no gradient through the cut), then BN, ReLU."""
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    D = sd["embedding.embedding_dict.weight"].shape[1]
+    dom = e[:, domain_idx * D:(domain_idx + 1) * D].detach()
+    h = e
+    for i in range(_count(sd, r"dnn\.linears\.(\d+)\.")):
+        fc = _lin(h, sd, f"dnn.linears.{i}")
+        pi = 2.0 * torch.sigmoid(_lin(torch.cat([h, dom], dim=1), sd, f"dnn.pruners.{i}"))
+        pi = torch.where(pi.abs() - 0.25 <= 0, torch.zeros_like(pi), pi)
+        h = torch.relu(_bn(fc * pi, sd, f"dnn.bn.{i}", training, stats_out))
+    logit = _lin(h, sd, "dnn_linear", mfma=False)
+    for o in other_logits(e, sd):
+        logit = logit + o
+    return torch.sigmoid(logit).squeeze(1)
+
+
+def _gate_nn(x, sd, prefix):
+    """GateNN.forward (model/pepnet.py:117-134) with dropout 0: Linear, ReLU, Linear, Sigmoid, times 2."""
+    ids = sorted(int(m.group(1)) for k in sd for m in [re.match(re.escape(prefix) + r"\.gate\.(\d+)\.weight$", k)] if m)
+    h = torch.relu(_lin(x, sd, f"{prefix}.gate.{ids[0]}"))
+    return 2.0 * torch.sigmoid(_lin(h, sd, f"{prefix}.gate.{ids[1]}"))
+
+
+def pepnet_forward(sd, x_i32, field_dims, domain_idx, n_tower, training=True, stats_out=None):
+    """PEPNet.forward + PPNetBlock.forward (model/pepnet.py:74-114,169-180).  PPNet's tower layers are ONE module applied to
+    every tower in turn: shared weights, the tower's own batch statistics, running statistics updated once per tower in
+    order (each update starts from the previous tower's result)."""
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    D = sd["embedding.embedding_dict.weight"].shape[1]
+    dom = e[:, domain_idx * D:(domain_idx + 1) * D]
+    ep = e * _gate_nn(torch.cat([e.detach(), dom], dim=-1), sd, "epnet")
+    others = other_logits(e, sd)
+    tops = []
+    if any(k.startswith("ppnet.") for k in sd):
+        n_layer = _count(sd, r"ppnet\.gate_layers\.(\d+)\.")
+        cur = [e] * n_tower
+        gate_in = torch.cat([e.detach(), ep], dim=-1)
+        live = dict(sd)                                            # running statistics move from tower to tower
+        for l in range(n_layer):
+            gws = torch.chunk(_gate_nn(gate_in, sd, f"ppnet.gate_layers.{l}"), n_tower, dim=1)
+            nxt = []
+            for t in range(n_tower):
+                y = _lin(cur[t] * gws[t], sd, f"ppnet.tower_layers.{l}.0.0")
+                upd = {}
+                y = _bn(y, live, f"ppnet.tower_layers.{l}.0.1", training, upd)
+                live.update(upd)
+                nxt.append(torch.relu(y))
+            cur = nxt
+            if stats_out is not None and training:
+                for t in range(n_tower):                           # the state_dict lists the shared module once per tower
+                    for k in ("running_mean", "running_var", "num_batches_tracked"):
+                        stats_out[f"ppnet.tower_layers.{l}.{t}.1.{k}"] = live[f"ppnet.tower_layers.{l}.0.1.{k}"]
+        tops = cur
+        lin_names = [f"ppnet_linears.{t}" for t in range(n_tower)]
+    elif n_tower > 1:
+        tops = [mlp(ep, sd, f"towers.{t}", training, stats_out) for t in range(n_tower)]
+        lin_names = [f"ppnet_linears.{t}" for t in range(n_tower)]
+    else:
+        tops = [mlp(ep, sd, "towers", training, stats_out)]
+        lin_names = ["ppnet_linears"]
+    ys = []
+    for top, name in zip(tops, lin_names):
+        logit = top @ sd[name + ".weight"].t()
+        for o in others:
+            logit = logit + o
+        ys.append(torch.sigmoid(logit))
+    pred = torch.cat(ys, dim=1)
+    return pred.squeeze(1) if (n_tower == 1 and not any(k.startswith("ppnet.") for k in sd)) else pred
+
+
+def adl_forward(sd, x_i32, field_dims, centers, n_tower, targets=None, is_training=True, training=True, stats_out=None,
+                dlm_iters=3, rate=0.9):
+    """ADL.forward + DLM_routing (model/adl.py:62-126).  Returns (pred, grouped targets, new centres) when is_training,
+    (ys in batch order, None, new centres) otherwise."""
+    e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
+    with torch.no_grad():
+        ed = e.detach()
+        for _ in range(dlm_iters):                                 # every iteration scores against the incoming centres
+            coeff = torch.softmax(ed @ centers.t(), dim=1)
+            tmp = F.normalize(coeff.t() @ ed, p=2, dim=1)
+        new_centers = F.normalize(rate * centers + (1 - rate) * tmp, p=2, dim=1)
+    tower_of = torch.argmax(coeff, dim=1)
+    others = other_logits(e, sd)
+    ys, ts = [], []
+    out = torch.zeros((e.shape[0], 1))
+    for t in range(n_tower):
+        mask = tower_of == t
+        h = mlp(e[mask], sd, f"domain_mlps.{t}", training, stats_out) if int(mask.sum()) > 0 else torch.zeros((0, sd[f"domain_mlps_linears.{t}.weight"].shape[1]))
+        w = sd[f"domain_mlps_linears.{t}.weight"] * sd["shared_mlps_linear.weight"]
+        b = sd[f"domain_mlps_linears.{t}.bias"] + sd["shared_mlps_linear.bias"]
+        logit = h @ w.t() + b
+        for o in others:
+            logit = logit + o[mask]
+        y = torch.sigmoid(logit)
+        if is_training:
+            ys.append(y)
+            ts.append(None if targets is None else torch.as_tensor(targets)[mask])
+        else:
+            out[mask] = y.detach()
+    if is_training:
+        return torch.cat(ys, dim=0), (None if targets is None else torch.cat(ts, dim=0)), new_centers
+    return out, None, new_centers
+
+
 def dcnv2_forward(sd, x_i32, field_dims, training=True, stats_out=None, model_structure="parallel"):
     e = embed(sd["embedding.embedding_dict.weight"], x_i32, field_dims)
     if "crossnet.u_list.0" in sd:
@@ -467,6 +573,13 @@ def reg_names(names, model_kind):
         elif model_kind == "deepfm" and top == "mlp" and "weight" in rel and "bn" not in rel:
             out.append(n)
         elif model_kind == "autoint" and top == "dnn" and "weight" in rel and "bn" not in rel:
+            out.append(n)
+        elif model_kind == "adasparse" and top == "dnn" and "weight" in rel and "bn" not in rel:
+            out.append(n)
+        elif model_kind == "pepnet" and top in ("epnet", "ppnet", "towers") and "weight" in rel and "bn" not in rel:
+            if not (top == "ppnet" and re.match(r"tower_layers\.\d+\.[1-9]\d*\.", rel)):      # the shared module counts once
+                out.append(n)
+        elif model_kind == "adl" and top in ("domain_mlps", "shared_mlps") and "weight" in rel and "bn" not in rel:
             out.append(n)
         elif model_kind == "hinet" and top in ("specific_seis", "shared_seis", "san_gate", "tower") and "weight" in rel and "bn" not in rel:
             out.append(n)

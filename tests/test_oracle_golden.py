@@ -53,6 +53,10 @@ MODELS = {
     "g12_star3_atten": ("star", lambda sd, x, tr, so: O.star_forward(sd, x, FD, 3, training=tr, stats_out=so)),
     "g13_autoint": ("autoint", lambda sd, x, tr, so: O.autoint_forward(sd, x, FD, tr, so)),
     "g14_hinet": ("hinet", lambda sd, x, tr, so: O.hinet_forward(sd, x, FD, load("g14_hinet")["group"], 2, tr, so)),
+    "g13_adasparse": ("adasparse", lambda sd, x, tr, so: O.adasparse_forward(sd, x, FD, 2, tr, so)),
+    "g16_pepnet": ("pepnet", lambda sd, x, tr, so: O.pepnet_forward(sd, x, FD, 2, 3, tr, so)),
+    "g16_epnet": ("pepnet", lambda sd, x, tr, so: O.pepnet_forward(sd, x, FD, 2, 3, tr, so)),
+    "g13_epnet_single": ("pepnet", lambda sd, x, tr, so: O.pepnet_forward(sd, x, FD, 2, 1, tr, so)),
     "g11_deepfm": ("deepfm", lambda sd, x, tr, so: O.deepfm_forward(sd, x, FD13, tr, so)),
 }
 FD = [7, 100, 3, 50, 11, 29]
@@ -89,9 +93,9 @@ def test_g2_model_forward_backward(name):
         if k.startswith("grad/"):
             g = grads[k[5:]]
             assert g is not None, k
-            if is_pre_bn_bias(k[5:], set(sd)):
-                assert float(g.abs().max()) < 1e-4 and float(np.abs(d[k]).max()) < 1e-4, k   # rounding noise on both sides
-                continue
+            if is_pre_bn_bias(k[5:], set(sd)) and float(np.abs(d[k]).max()) < 1e-4:
+                assert float(g.abs().max()) < 1e-4, k       # rounding noise on both sides
+                continue                                    # (a gated Linear -> BatchNorm, as in AdaSparse, has a real bias gradient)
             scale = max(float(np.abs(d[k]).max()), 1.0)
             assert_close(g, d[k], 1e-4, 1e-6 * scale + 2e-7, k)
             n_checked += 1
@@ -289,3 +293,40 @@ def test_g9_metrics_match_sklearn():
         else:
             assert abs(O.auc(t[mk], s[mk]) - float(d[f"auc_d{k}"])) < 1e-12
             assert abs(O.logloss(t[mk], s[mk]) - float(d[f"logloss_d{k}"])) < 1e-13
+
+
+def test_g17_adl_forward_backward():
+    """ADL: routing + per-tower MLPs on their own rows, centres after each call (tests/golden/g17_adl.npz)."""
+    d = load("g17_adl")
+    sd = sd_of(d)
+    x, y = d["x"], torch.from_numpy(d["y"])
+    c0 = torch.from_numpy(d["centers0"])
+    stats, keep = {}, {}
+
+    def loss_fn(s):
+        p, t, keep["c1"] = O.adl_forward(s, x, FD, c0, 3, targets=y, is_training=True, training=True, stats_out=stats)
+        keep["pred"], keep["t"] = p, t
+        keep["bce"] = O.bce_mean(p.squeeze(1), t.reshape(-1).float())
+        keep["reg"] = O.reg_loss(s, _l2_map(s, "adl"))
+        return (keep["bce"] + keep["reg"]).sum()
+
+    _, grads = oracle_grads(loss_fn, sd, torch.tensor(1.0))
+    assert torch.equal(keep["t"], torch.from_numpy(d["train_targets"]))
+    assert_close(keep["pred"], d["train_pred"], RTOL, ATOL, "train_pred")
+    assert_close(keep["bce"], d["bce"], RTOL, ATOL, "bce")
+    assert_close(keep["reg"], d["reg"], RTOL, ATOL, "reg")
+    assert_close(keep["c1"], d["centers1"], 1e-6, 1e-7, "centres")
+    for k in d.files:
+        if k.startswith("grad/") and not is_pre_bn_bias(k[5:], set(sd)):
+            assert_close(grads[k[5:]], d[k], 1e-4, 1e-6 * max(float(np.abs(d[k]).max()), 1.0) + 2e-7, k)
+    for k in d.files:
+        if k.startswith("sd_after/") and "num_batches" not in k:
+            if k[9:] in stats:
+                assert_close(stats[k[9:]], d[k], RTOL, ATOL, k)
+            else:                                           # shared_mlps: constructed, never called (model/adl.py:92-93)
+                assert_close(sd[k[9:]], d[k], 0, 0, k)
+    sd_eval = dict(sd)
+    sd_eval.update(stats)
+    ev, _, c2 = O.adl_forward(sd_eval, x, FD, keep["c1"], 3, is_training=False, training=False)
+    assert_close(ev, d["eval_pred"], RTOL, ATOL, "eval_pred")
+    assert_close(c2, d["centers2"], 1e-6, 1e-7, "centres after eval")
