@@ -207,7 +207,7 @@ class TrainStep:
 
     def _dp_sequence_sharded(self):
         """Row-sharded table: [(is_comm, [fn...])].  Per step and rank the table work is that of the LOCAL batch:
-            sort local rows -> bucket by owner | a2a ids | owner: periodic flush of its rows, sort, catch-up, gather |
+            sort local rows -> bucket by owner | a2a ids | owner: merge the sorted lists, catch-up, gather |
             a2a rows | expand, forward, BCE, backward, per-row gradient sums, pack | all-reduce arena, a2a grads |
             owner: per-row sums over the senders, Adam update of its rows; dense Adam."""
         opt, plan, emb, dp = self.opt, self.plan, self.emb, self.dist
