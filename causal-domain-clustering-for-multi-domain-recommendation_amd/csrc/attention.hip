@@ -108,11 +108,13 @@ __global__ void __launch_bounds__(ATTN_THREADS) k_attn_bwd(const float* __restri
     extern __shared__ __attribute__((aligned(16))) float attn_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t pair = (int64_t)blockIdx.x * ATTN_WAVES + wave;
-    float* Qs = attn_smem + (int64_t)wave * (4 * F * DH + 2 * F * (F + 1));
-    float* Ks = Qs + F * DH;
+    // phase 1 (per query row) reads K and V, phase 2 (per key row) reads Q and dO: the two pairs share one LDS region, which
+    // keeps a wave at 12 KB (F = 26, dh = 32) and thirteen waves resident per CU instead of eight
+    float* Ks = attn_smem + (int64_t)wave * (2 * F * DH + 2 * F * (F + 1));
     float* Vs = Ks + F * DH;
-    float* Os = Vs + F * DH;                                                // dO
-    float* Pd = Os + F * DH;                                                // dropped probabilities  [F][F+1]
+    float* Qs = Ks;                                                         // phase 2 aliases
+    float* Os = Vs;                                                         // dO
+    float* Pd = Vs + F * DH;                                                // dropped probabilities  [F][F+1]
     float* Ds = Pd + F * (F + 1);                                           // dS                     [F][F+1]
     const bool live = pair < B * H;
     const int64_t b = live ? pair / H : 0;
@@ -121,10 +123,8 @@ __global__ void __launch_bounds__(ATTN_THREADS) k_attn_bwd(const float* __restri
     const float scale = rsqrtf((float)DH);
     for (int i = lane; i < F * DH; i += 64) {
         const int f = i / DH, d = i % DH;
-        Qs[i] = base[(int64_t)f * ld + d] * scale;
         Ks[i] = base[(int64_t)f * ld + A + d];
         Vs[i] = base[(int64_t)f * ld + 2 * A + d];
-        Os[i] = dout[(b * F + f) * lddo + h * DH + d];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -158,6 +158,13 @@ __global__ void __launch_bounds__(ATTN_THREADS) k_attn_bwd(const float* __restri
         float* dst = dqkv + (b * F + lane) * lddq + h * DH;
 #pragma unroll
         for (int d = 0; d < DH; ++d) dst[d] = dq[d] * scale;                 // q was scaled before the product
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < F * DH; i += 64) {                               // K and V are done: their space takes Q and dO
+        const int f = i / DH, d = i % DH;
+        Qs[i] = base[(int64_t)f * ld + d] * scale;
+        Os[i] = dout[(b * F + f) * lddo + h * DH + d];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -220,7 +227,7 @@ extern "C" int cdc_attn_bwd(const float* qkv, int64_t ld, const float* probs, co
     CDC_CHECK_ARG(qkv && probs && dout && dqkv && attn_args_ok(B, F, A, H, drop_p) && ld >= 3 * (int64_t)A && lddo >= A &&
                       lddq >= 3 * (int64_t)A, CDC_E_BADARG, "attn_bwd: bad argument (F <= 64, head dim in {4,8,16,32,64})");
     if (B == 0) return 0;
-    ATTN_DISPATCH(k_attn_bwd, 4 * F * (A / H) + 2 * F * (F + 1), qkv, ld, probs, dout, lddo, dqkv, lddq, B, F, A, H, drop_p, seed,
+    ATTN_DISPATCH(k_attn_bwd, 2 * F * (A / H) + 2 * F * (F + 1), qkv, ld, probs, dout, lddo, dqkv, lddq, B, F, A, H, drop_p, seed,
                   seed_offset_dev);
     CDC_LAUNCH_CHECK("attn_bwd");
     return 0;
