@@ -137,6 +137,14 @@ class Loopback:
             out.copy_(inp)
         return out
 
+    def all_to_all_start(self, out, inp):
+        self.all_to_all(out, inp)
+        return None
+
+    @staticmethod
+    def wait(handle):
+        pass
+
     def all_gather_rows(self, out, local):
         out.view(self.world_size, *local.shape).copy_(local.unsqueeze(0).expand(self.world_size, *local.shape))
         return out
@@ -160,7 +168,8 @@ def main():
     # CDC_BENCH_REHEARSAL=1: all ranks on cuda:0 with gloo (host-staged) collectives — exercises the N>1 code path of this
     # script on a one-GPU box; the throughput it prints is meaningless
     rehearsal = os.environ.get("CDC_BENCH_REHEARSAL") == "1"
-    dp = (DataParallel(backend="gloo") if rehearsal else DataParallel()) if world > 1 else None
+    forced = bool(int(os.environ.get("CDC_FORCE_COLLECTIVES", "0")))      # the RCCL call path with a single rank
+    dp = (DataParallel(backend="gloo") if rehearsal else DataParallel()) if (world > 1 or forced) else None
     sim = None
     if args.simulate_world > 1 and world == 1:
         sim = Loopback(args.simulate_world)

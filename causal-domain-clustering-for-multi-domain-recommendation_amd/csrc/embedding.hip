@@ -109,6 +109,29 @@ __device__ __forceinline__ void lds_bitonic_sort(uint64_t* keys, int n_pad, int 
     __syncthreads();
 }
 
+// block-wide exclusive scan of one int per thread (SORT_THREADS threads): shuffles inside a wave, the 16 wave totals through LDS
+__device__ __forceinline__ int block_exclusive_scan(int v, int32_t* wave_tot, int tid, int& total) {
+    const int lane = tid & 63, wave = tid >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_THREADS / 64; ++w) {
+        const int t = wave_tot[w];
+        base += (w < wave) ? t : 0;
+        all += t;
+    }
+    __syncthreads();                                                     // wave_tot may be reused by the caller
+    total = all;
+    return base + inc - v;
+}
+
 // head flags + block-wide exclusive scan over n sorted keys (LDS or global): unique rows, segment starts, permutation
 __device__ __forceinline__ void dedupe_sorted(const uint64_t* keys, int n, int32_t* scan, int32_t* __restrict__ urow,
                                               int32_t* __restrict__ sst, int32_t* __restrict__ prm, int32_t* __restrict__ cnt_out,
@@ -120,16 +143,8 @@ __device__ __forceinline__ void dedupe_sorted(const uint64_t* keys, int n, int32
         const bool head = (i == 0) || ((keys[i] >> 32) != (keys[i - 1] >> 32));
         local += head ? 1 : 0;
     }
-    scan[tid] = local;
-    __syncthreads();
-    for (int off = 1; off < SORT_THREADS; off <<= 1) {
-        int v = (tid >= off) ? scan[tid - off] : 0;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
-    }
-    int u = scan[tid] - local;                                           // exclusive prefix
-    const int total = scan[SORT_THREADS - 1];
+    int total;
+    int u = block_exclusive_scan(local, scan, tid, total);
     for (int i = begin; i < begin + per && i < n; ++i) {
         const uint64_t k = keys[i];
         const bool head = (i == 0) || ((k >> 32) != (keys[i - 1] >> 32));
@@ -763,6 +778,62 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
 }
 
 
+// Segment sum without the sorted copy, for batches whose segments are known to be short (the owner side of the row-sharded
+// table: at most one entry per sending rank): one thread per (unique row, 16-byte chunk) adds its segment's gradient rows
+// straight from d_out in segment order — the same serial ascending sum cdc_embed_segment_sum forms for segments shorter than
+// SEG_SPLIT, so the two agree to the last bit there.
+template <int VEC>
+__global__ void __launch_bounds__(256) k_segment_sum_direct(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                                            const int32_t* __restrict__ uniq_row, float* __restrict__ rowgrad,
+                                                            int32_t B, int32_t F, int32_t D) {
+    const int chunks = D / VEC;
+    const int64_t total = (int64_t)F * B * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const int64_t slot = i / chunks;
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        if (uniq_row && uniq_row[slot] < 0) continue;                  // the padding entries of the row lists: one long segment nobody reads
+        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+        const int32_t* prm = perm + (int64_t)f * B;
+        const int k0 = sst[j], k1 = sst[j + 1];
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+        for (int k = k0; k < k1; ++k) {
+            const float* src = d_out + ((int64_t)prm[k] * F + f) * D + c * VEC;
+            if (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                acc[0] = __fadd_rn(acc[0], v.x); acc[1] = __fadd_rn(acc[1], v.y);
+                acc[2] = __fadd_rn(acc[2], v.z); acc[3] = __fadd_rn(acc[3], v.w);
+            } else {
+                acc[0] = __fadd_rn(acc[0], src[0]);
+            }
+        }
+        float* dst = rowgrad + slot * D + c * VEC;
+        if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else dst[0] = acc[0];
+    }
+}
+extern "C" int cdc_embed_segment_sum_direct(const float* d_out, const int32_t* seg_start, const int32_t* perm,
+                                            const int32_t* uniq_cnt, const int32_t* uniq_row, float* rowgrad, int64_t B, int32_t F,
+                                            int32_t D, void* stream) {
+    CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && rowgrad, CDC_E_BADARG, "embed_segment_sum_direct: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_segment_sum_direct: bad sizes");
+    const bool vec = (D % 4 == 0) && (((uintptr_t)d_out | (uintptr_t)rowgrad) % 16 == 0);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
+    if (vec)
+        hipLaunchKernelGGL(k_segment_sum_direct<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, seg_start, perm, uniq_cnt, uniq_row,
+                           rowgrad, (int32_t)B, F, D);
+    else
+        hipLaunchKernelGGL(k_segment_sum_direct<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, seg_start, perm, uniq_cnt, uniq_row,
+                           rowgrad, (int32_t)B, F, D);
+    CDC_LAUNCH_CHECK("embed_segment_sum_direct");
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Row-sharded table under data parallelism (row r is owned by rank r % n_rank).  The per-field unique rows of the local
 // batch are bucketed by owner into fixed-capacity send lists [n_rank][cap][F] (row id, -1 = padding); slots are assigned
@@ -771,71 +842,44 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
 // update kernels above unchanged.
 // ------------------------------------------------------------------------------------------------
 #define SHARD_MAX_RANKS 16
+// one workgroup per (field, owner): flags the field's unique rows that belong to the owner, ranks them with a block scan
+// (ascending row order = slot order), writes the owner's send list (padding included) and the rows' slot numbers
 __global__ void __launch_bounds__(SORT_THREADS) k_shard_bucket(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
                                                                int32_t* __restrict__ send_ids, int32_t* __restrict__ slot_of,
                                                                int32_t* __restrict__ overflow, int32_t B, int32_t F, int32_t n_rank,
                                                                int32_t cap) {
-    __shared__ int32_t cnt[SHARD_MAX_RANKS][SORT_THREADS];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    __shared__ int32_t wave_tot[SORT_THREADS / 64];
+    const int f = blockIdx.x, o = blockIdx.y, tid = threadIdx.x;
     const int n = uniq_cnt[f];
-    for (int o = 0; o < n_rank; ++o)
-        for (int s_ = tid; s_ < cap; s_ += SORT_THREADS) send_ids[((int64_t)o * cap + s_) * F + f] = -1;
     const int per = (B + SORT_THREADS - 1) / SORT_THREADS;
     const int begin = tid * per;
-    int local[SHARD_MAX_RANKS];
-#pragma unroll
-    for (int o = 0; o < SHARD_MAX_RANKS; ++o) local[o] = 0;
     const int32_t* ur = uniq_row + (int64_t)f * B;
+    int local = 0;
     for (int j = begin; j < begin + per && j < n; ++j) {
         const int32_t row = ur[j];
-        if (row < 0) continue;
-        const int o = row % n_rank;
-#pragma unroll
-        for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) local[k]++;
+        local += (row >= 0 && row % n_rank == o) ? 1 : 0;
     }
-    for (int o = 0; o < n_rank; ++o) {
-        int v = 0;
-#pragma unroll
-        for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) v = local[k];
-        cnt[o][tid] = v;
-    }
-    __syncthreads();
-    for (int off = 1; off < SORT_THREADS; off <<= 1) {
-        int add[SHARD_MAX_RANKS];
-        for (int o = 0; o < n_rank; ++o) add[o] = (tid >= off) ? cnt[o][tid - off] : 0;
-        __syncthreads();
-        for (int o = 0; o < n_rank; ++o) cnt[o][tid] += add[o];
-        __syncthreads();
-    }
-    int next[SHARD_MAX_RANKS];
-#pragma unroll
-    for (int k = 0; k < SHARD_MAX_RANKS; ++k) next[k] = 0;
-    for (int o = 0; o < n_rank; ++o) {
-        int lv = 0;
-#pragma unroll
-        for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) lv = local[k];
-        const int ex = cnt[o][tid] - lv;                           // exclusive prefix for this owner
-#pragma unroll
-        for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) next[k] = ex;
-    }
+    int total;
+    int slot = block_exclusive_scan(local, wave_tot, tid, total);
     for (int j = begin; j < begin + per && j < n; ++j) {
         const int32_t row = ur[j];
-        int slot = -1;
-        if (row >= 0) {
-            const int o = row % n_rank;
-#pragma unroll
-            for (int k = 0; k < SHARD_MAX_RANKS; ++k) if (k == o) slot = next[k]++;
-            if (slot < cap) send_ids[((int64_t)o * cap + slot) * F + f] = row;
-            else { atomicMax(overflow, slot + 1); slot = -1; }
+        if (row < 0) {
+            if (o == 0) slot_of[(int64_t)f * B + j] = -1;
+            continue;
         }
-        slot_of[(int64_t)f * B + j] = slot;
+        if (row % n_rank != o) continue;
+        int s_ = slot++;
+        if (s_ < cap) send_ids[((int64_t)o * cap + s_) * F + f] = row;
+        else { atomicMax(overflow, s_ + 1); s_ = -1; }
+        slot_of[(int64_t)f * B + j] = s_;
     }
+    for (int s_ = min(total, cap) + tid; s_ < cap; s_ += SORT_THREADS) send_ids[((int64_t)o * cap + s_) * F + f] = -1;
 }
 extern "C" int cdc_shard_bucket(const int32_t* uniq_row, const int32_t* uniq_cnt, int32_t* send_ids, int32_t* slot_of,
                                 int32_t* overflow, int64_t B, int32_t F, int32_t n_rank, int32_t cap, void* stream) {
     CDC_CHECK_ARG(uniq_row && uniq_cnt && send_ids && slot_of && overflow && B > 0 && F > 0 && cap > 0 && n_rank > 0 &&
                       n_rank <= SHARD_MAX_RANKS && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "shard_bucket: bad argument");
-    hipLaunchKernelGGL(k_shard_bucket, dim3(F), dim3(SORT_THREADS), 0, (hipStream_t)stream, uniq_row, uniq_cnt, send_ids, slot_of, overflow,
+    hipLaunchKernelGGL(k_shard_bucket, dim3(F, n_rank), dim3(SORT_THREADS), 0, (hipStream_t)stream, uniq_row, uniq_cnt, send_ids, slot_of, overflow,
                        (int32_t)B, F, n_rank, cap);
     CDC_LAUNCH_CHECK("shard_bucket");
     return 0;
@@ -896,30 +940,40 @@ extern "C" int cdc_shard_expand(const float* rows_recv, const int32_t* uniq_row,
 }
 
 // requester, backward: rowgrad [F][B][D] (per unique row) -> send_grads [n_rank (owner)][cap][F][D]
+template <int VEC>
 __global__ void __launch_bounds__(256) k_shard_pack(const float* __restrict__ rowgrad, const int32_t* __restrict__ uniq_row,
                                                     const int32_t* __restrict__ uniq_cnt, const int32_t* __restrict__ slot_of,
                                                     float* __restrict__ send, int32_t B, int32_t F, int32_t D, int32_t n_rank,
                                                     int32_t cap) {
-    const int64_t total = (int64_t)F * B * D;
+    const int chunks = D / VEC;
+    const int64_t total = (int64_t)F * B * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % D);
-        const int64_t slotj = i / D;
+        const int c = (int)(i % chunks);
+        const int64_t slotj = i / chunks;
         const int f = (int)(slotj / B);
         const int j = (int)(slotj - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
         const int32_t row = uniq_row[slotj];
         const int s_ = slot_of[slotj];
         if (row < 0 || s_ < 0) continue;
-        send[((((int64_t)(row % n_rank)) * cap + s_) * F + f) * D + d] = rowgrad[i];
+        float* dst = send + ((((int64_t)(row % n_rank)) * cap + s_) * F + f) * D + c * VEC;
+        const float* src = rowgrad + slotj * D + c * VEC;
+        if (VEC == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        else dst[0] = src[0];
     }
 }
 extern "C" int cdc_shard_pack(const float* rowgrad, const int32_t* uniq_row, const int32_t* uniq_cnt, const int32_t* slot_of,
                               float* send, int64_t B, int32_t F, int32_t D, int32_t n_rank, int32_t cap, void* stream) {
     CDC_CHECK_ARG(rowgrad && uniq_row && uniq_cnt && slot_of && send && B > 0 && F > 0 && D > 0 && cap > 0 && n_rank > 0, CDC_E_BADARG,
                   "shard_pack: bad argument");
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * D, 256), 8192);
-    hipLaunchKernelGGL(k_shard_pack, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, slot_of, send,
-                       (int32_t)B, F, D, n_rank, cap);
+    const bool vec = (D % 4 == 0) && (((uintptr_t)rowgrad | (uintptr_t)send) % 16 == 0);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
+    if (vec)
+        hipLaunchKernelGGL(k_shard_pack<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, slot_of, send,
+                           (int32_t)B, F, D, n_rank, cap);
+    else
+        hipLaunchKernelGGL(k_shard_pack<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, slot_of, send,
+                           (int32_t)B, F, D, n_rank, cap);
     CDC_LAUNCH_CHECK("shard_pack");
     return 0;
 }

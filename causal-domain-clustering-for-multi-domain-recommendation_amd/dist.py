@@ -17,21 +17,27 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, force=None):
+        """force (default: env CDC_FORCE_COLLECTIVES=1): create the process group and issue every collective even when the
+        world has ONE rank — the way to run the real RCCL call path (communicator streams, async handles, graph segments
+        between collectives) on a single-GPU machine; results equal the single-process step."""
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.force = bool(int(os.environ.get("CDC_FORCE_COLLECTIVES", "0"))) if force is None else bool(force)
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         self.backend = backend
-        if self.world_size > 1 and not dist.is_initialized():
+        self.active = self.world_size > 1 or self.force
+        if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
-                dist.init_process_group(backend, device_id=torch.device("cuda", self.local_rank))
+                dist.init_process_group(backend, device_id=torch.device("cuda", self.local_rank), rank=self.rank,
+                                        world_size=self.world_size)
             else:
-                dist.init_process_group(backend)
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world_size)
         self.device = device
 
     def _staged(self, t):
@@ -39,7 +45,7 @@ class DataParallel:
         return self.backend == "gloo" and t.is_cuda
 
     def all_reduce_sum(self, t):
-        if self.world_size > 1:
+        if self.active:
             if self._staged(t):
                 h = t.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
@@ -49,7 +55,7 @@ class DataParallel:
         return t
 
     def all_reduce_max(self, t):
-        if self.world_size > 1:
+        if self.active:
             if self._staged(t):
                 h = t.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.MAX)
@@ -60,7 +66,7 @@ class DataParallel:
 
     def all_gather_rows(self, out, local):
         """out [world*B, C] <- concat over ranks of local [B, C] (rank order)."""
-        if self.world_size > 1:
+        if self.active:
             if self._staged(out):
                 parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(self.world_size)]
                 dist.all_gather(parts, local.detach().cpu().contiguous())
@@ -76,7 +82,7 @@ class DataParallel:
 
     def all_to_all(self, out, inp):
         """equal-split exchange along dim 0: chunk r of `inp` goes to rank r; chunk r of `out` came from rank r."""
-        if self.world_size > 1:
+        if self.active:
             if self._staged(out):
                 h_in = inp.detach().cpu().contiguous()
                 h_out = torch.empty_like(h_in)
@@ -92,7 +98,7 @@ class DataParallel:
         """all_to_all whose completion the caller awaits later with wait(): over RCCL the exchange runs on the
         communicator's stream while the launches issued in between run on the compute stream.  Host-staged backends (the
         gloo rehearsal) complete at once and return None."""
-        if self.world_size > 1 and not self._staged(out) and self.backend != "gloo":
+        if self.active and not self._staged(out) and self.backend != "gloo":
             return dist.all_to_all_single(out, inp, async_op=True)
         self.all_to_all(out, inp)
         return None
@@ -103,7 +109,7 @@ class DataParallel:
             handle.wait()                      # orders the current stream after the collective; does not block the host
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.active:
             dist.barrier()
 
     def shard(self, n):
@@ -112,5 +118,5 @@ class DataParallel:
         return self.rank * per, (self.rank + 1) * per
 
     def close(self):
-        if self.world_size > 1 and dist.is_initialized():
+        if self.active and dist.is_initialized():
             dist.destroy_process_group()

@@ -175,8 +175,9 @@ class FusedAdam:
                  (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), None, B, F, self.table.shape[0]), self._stream())
         self.table_catchup_rows(idx, B, F, D, flush=flush)
 
-    def table_step(self, idx, d_out, B, F, D, tag=""):
-        """Adam step t on the table from the batch's row indices [B,F] and the gradient of the gathered rows [B,F*D]."""
+    def table_step(self, idx, d_out, B, F, D, tag="", short_segments=False):
+        """Adam step t on the table from the batch's row indices [B,F] and the gradient of the gathered rows [B,F*D].
+        short_segments: no row occurs more than a few times in idx (an owner's received lists: once per sender)."""
         s = self._stream()
         hp = self._hp()
         w, m, v = self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr()
@@ -193,12 +194,18 @@ class FusedAdam:
                      (ws["side"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), w, m, v, B, F, D), s)
         else:
             ws = self._workspace(B, F, D, tag)   # rows were sorted by table_catchup of this step
-            self._segment_sum(ws, d_out, B, F, D, s)
+            self._segment_sum(ws, d_out, B, F, D, s, short=short_segments)
             L.launch("cdc_embed_lazy_update", self.lib.cdc_embed_lazy_update,
                      (ws["rowgrad"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(),
                       w, m, v, self.table_last.data_ptr(), hp, self.step_dev.data_ptr(), None, 0, B, F, D), s)
 
-    def _segment_sum(self, ws, d_out, B, F, D, s):
+    def _segment_sum(self, ws, d_out, B, F, D, s, short=False):
+        """short: every segment is known to hold only a few entries (an owner's merged row lists) — no sorted copy"""
+        if short:
+            L.launch("cdc_embed_segment_sum", self.lib.cdc_embed_segment_sum_direct,
+                     (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["uniq"].data_ptr(),
+                      ws["rowgrad"].data_ptr(), B, F, D), s)
+            return
         L.launch("cdc_embed_segment_sum", self.lib.cdc_embed_segment_sum,
                  (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["sorted"].data_ptr(),
                   ws["rowgrad"].data_ptr(), B, F, D), s)

@@ -170,7 +170,7 @@ class Plan:
         self._arena_used = 0
         # data parallel: BatchNorm statistics are exchanged between ranks (global-batch statistics, like the reference's
         # single process); the exchange steps are marked so the step driver can cut its launch graphs around them
-        self.dist = dist if (dist is not None and dist.world_size > 1) else None
+        self.dist = dist if (dist is not None and (dist.world_size > 1 or getattr(dist, "force", False))) else None
         self._bn_ws = None
         self._bn_ws_need = 0
         self._rowdot_ws = None

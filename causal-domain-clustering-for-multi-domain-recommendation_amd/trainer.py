@@ -40,6 +40,7 @@ class TrainStep:
         self.dist = dist
         self.sync_bn = bool(sync_bn)
         self.world = 1 if dist is None else dist.world_size
+        self.dp_on = self.world > 1 or bool(getattr(dist, "force", False))     # force: the collective path with one rank
         self.global_B = self.B * self.world
         dev = optimizer.device
         self.device = dev
@@ -68,12 +69,12 @@ class TrainStep:
         if table_dist is None:
             table_dist = "sharded" if optimizer.table_mode == "lazy" else "replicated"
         assert table_dist in ("sharded", "replicated")
-        self.table_dist = table_dist if self.world > 1 else "replicated"
-        if self.world > 1 and self.table_dist == "replicated":
+        self.table_dist = table_dist if self.dp_on else "replicated"
+        if self.dp_on and self.table_dist == "replicated":
             F, D = self.emb.F, self.emb.D
             self.idx_all = torch.empty((self.global_B, F), dtype=torch.int32, device=dev)
             self.dE_all = torch.empty((self.global_B, F * D), dtype=torch.float32, device=dev)
-        if self.world > 1 and self.table_dist == "sharded":
+        if self.dp_on and self.table_dist == "sharded":
             if optimizer.table_mode != "lazy":
                 raise ValueError("the row-sharded table needs table_mode='lazy'")
             F, D, N = self.emb.F, self.emb.D, self.world
@@ -255,7 +256,7 @@ class TrainStep:
             dp.all_reduce_sum(self.arena_and_loss)                      # dense gradients + the loss scalar behind them
 
         def update():
-            opt.table_step(self.recv_ids, self.grads_recv, Bv, F, D, "owner")
+            opt.table_step(self.recv_ids, self.grads_recv, Bv, F, D, "owner", short_segments=True)
             opt.flush_slice()                           # off the rows-exchange critical path: after the owner's update
             opt.dense_step(plan.param_grads, plan._param_refs)
             self._reg()
@@ -291,7 +292,7 @@ class TrainStep:
         moments) — before state_dict(), evaluation, or a switch to another trainer.  Host-synchronising collectives."""
         opt = self.opt
         opt.flush_table()
-        if self.world == 1 or self.table_dist != "sharded":
+        if not self.dp_on or self.table_dist != "sharded":
             return
         R = opt.table.shape[0]
         own = (torch.arange(R, device=self.device) % self.world == self.dist.rank).to(torch.float32).unsqueeze(1)
@@ -347,7 +348,7 @@ class TrainStep:
             self.y.copy_(yf)
             if gdst is not None:
                 gdst.copy_(gf)
-        if self.world > 1:
+        if self.dp_on:
             self._step_dp()
         elif self.use_graph and self._warm >= 2:
             if self.graph is None:
@@ -413,7 +414,7 @@ class TrainStep:
         if bad:
             self.emb.err.zero_()
             raise IndexError(f"index out of range in self (flat position {bad - 1})")
-        if self.world > 1 and self.table_dist == "sharded":
+        if self.dp_on and self.table_dist == "sharded":
             over = int(self.overflow.item())
             if over:
                 self.overflow.zero_()

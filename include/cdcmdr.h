@@ -83,6 +83,12 @@ int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_st
  * sorted_scratch and rowgrad are [F, B, D] floats. */
 int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
                           float* sorted_scratch, float* rowgrad, int64_t B, int32_t F, int32_t D, void* stream);
+/* The same sums without the sorted copy, for batches whose segments are short (the owner side of the row-sharded table:
+ * at most one entry per sending rank, see cdc_shard_bucket): every (unique row, 16-byte chunk) adds its segment straight
+ * from d_out in segment order — bit-identical to cdc_embed_segment_sum for segments shorter than 64 entries.  uniq_row (may
+ * be NULL): unique rows < 0 (the -1 padding of the lists, one long segment) are skipped and their rowgrad left untouched. */
+int cdc_embed_segment_sum_direct(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
+                                 const int32_t* uniq_row, float* rowgrad, int64_t B, int32_t F, int32_t D, void* stream);
 
 /* Dense gradient of the table as the reference's nn.Embedding produces it (drop-in path feeding
  * torch.optim.Adam): grad[uniq_row[f,j], :] += rowgrad[f,j,:]. */

@@ -230,3 +230,29 @@ def test_shard_ranges_partition_the_batch():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def _worker_forced(rank, port, out_dir):
+    os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    from cdcmdr_amd.dist import DataParallel
+    dp = DataParallel(backend="gloo", force=True)
+    assert dp.active and torch.distributed.is_initialized() and torch.distributed.get_world_size() == 1
+    a = torch.arange(12, dtype=torch.float32).reshape(1, 4, 3)
+    out = torch.zeros_like(a)
+    dp.all_to_all(out, a)
+    h = dp.all_to_all_start(torch.zeros_like(a), a)
+    dp.wait(h)
+    t = dp.all_reduce_sum(a.clone())
+    g = dp.all_gather_rows(torch.zeros(4, 3), a[0])
+    dp.barrier()
+    dp.close()
+    torch.save({"a2a": out, "sum": t, "gather": g, "ref": a}, os.path.join(out_dir, "forced.pt"))
+
+
+def test_forced_one_rank_group_runs_every_collective(tmp_path):
+    """CDC_FORCE_COLLECTIVES / force=True: a world of one still creates the process group and issues the collectives (how the
+    RCCL call path is exercised on a one-GPU machine); every exchange is then the identity."""
+    mp.spawn(_worker_forced, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(os.path.join(tmp_path, "forced.pt"), weights_only=False)
+    assert torch.equal(r["a2a"], r["ref"]) and torch.equal(r["sum"], r["ref"]) and torch.equal(r["gather"], r["ref"][0])

@@ -66,7 +66,7 @@ def _single_process_reference(table_mode, kind="mmoe", world=2):
     return {k: v.cpu() for k, v in model.state_dict().items()}, losses
 
 
-def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_bn=True, kind="mmoe"):
+def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_bn=True, kind="mmoe", backend="gloo", force=False):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     sys.path.insert(0, ROOT)
     from cdcmdr_amd.dist import DataParallel
@@ -74,7 +74,7 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_
     from cdcmdr_amd.optim import FusedAdam
     from cdcmdr_amd.trainer import TrainStep
     dev = torch.device("cuda:0")
-    dp = DataParallel(backend="gloo")
+    dp = DataParallel(backend=backend, force=force)
     torch.manual_seed(5)
     model, mode = _build(kind, dev)
     opt = FusedAdam(model, table_mode=table_mode, flush_every=2)
@@ -206,3 +206,23 @@ def test_three_ranks_row_sharded_table(cuda, tmp_path):
             continue
         atol = 5e-4 if k.endswith("running_mean") else 2e-5
         assert_close(outs[0]["sd"][k], v, 5e-4, atol, f"3-rank vs 1-rank: {k}")
+
+
+@pytest.mark.parametrize("table_dist,use_graph", [("sharded", True), ("sharded", False), ("replicated", True)])
+def test_one_rank_through_rccl(cuda, tmp_path, table_dist, use_graph):
+    """The collective call path itself over RCCL ("nccl" backend): a forced one-rank process group issues every all-to-all /
+    all-reduce / all-gather of the data-parallel step on the communicator's stream (async row-gradient exchange, launch
+    segments between the collectives replayed as graphs).  With one rank the step must equal the single-process step."""
+    mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), "lazy", use_graph, table_dist, True, "mmoe", "nccl", True), nprocs=1, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    from helpers import assert_close, is_pre_bn_bias
+    ref_sd, ref_losses = _single_process_reference("lazy", world=1)
+    assert all(np.isfinite(r0["losses"]))
+    for a, b in zip(r0["losses"], ref_losses):
+        assert abs(a - b) < 2e-5, (r0["losses"], ref_losses)
+    names = set(ref_sd)
+    for k, v in ref_sd.items():
+        if is_pre_bn_bias(k, names) or "num_batches" in k:
+            continue
+        atol = 5e-4 if k.endswith("running_mean") else 2e-5
+        assert_close(r0["sd"][k], v, 5e-4, atol, f"1-rank RCCL vs single process: {k}")

@@ -434,3 +434,18 @@ def test_merge_dedupe_equals_sort_dedupe(cuda, n_runs, run_len):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
     for f in range(F):
         assert np.array_equal(a[1][f], b[1][f]) and np.array_equal(a[2][f], b[2][f])
+    # the owner's per-row sums without the sorted copy == the general segment sum (bit for bit) on every real row
+    D = 16
+    g = torch.from_numpy(rng.standard_normal((B, F * D)).astype(np.float32)).to(cuda)
+    sorted_scratch = torch.empty((F, B, D), dtype=torch.float32, device=cuda)
+    rg_a = torch.zeros((F, B, D), dtype=torch.float32, device=cuda)
+    rg_b = torch.full((F, B, D), 7.0, dtype=torch.float32, device=cuda)
+    L.check(lib.cdc_embed_segment_sum(g.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(), sorted_scratch.data_ptr(),
+                                      rg_a.data_ptr(), B, F, D, s), "segment_sum")
+    L.check(lib.cdc_embed_segment_sum_direct(g.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(), uniq.data_ptr(),
+                                             rg_b.data_ptr(), B, F, D, s), "segment_sum_direct")
+    c = cnt.cpu().numpy()
+    for f in range(F):
+        real = int((uniq[f, :c[f]] >= 0).sum())
+        assert torch.equal(rg_a[f, :real], rg_b[f, :real])
+        assert bool((rg_b[f, real:] == 7.0).all())                 # padding segment and unused slots stay untouched
