@@ -203,30 +203,80 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunk(const int32_t* __re
     uint64_t* out = runs + (int64_t)f * B + r0;
     for (int i = tid; i < n; i += SORT_THREADS) out[i] = keys[i];
 }
+// P (a power of two >= n_runs, <= 16) neighbouring lanes share one key: lane q counts the smaller keys of run q with its own
+// binary search (the searches of a key run side by side instead of one after the other), a butterfly adds the counts
+__device__ __forceinline__ int group_sum(int v, int P) {
+    for (int off = 1; off < P; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 __global__ void __launch_bounds__(256) k_merge_runs(const uint64_t* __restrict__ runs, uint64_t* __restrict__ merged, int32_t B,
-                                                    int32_t F, int32_t chunk) {
-    const int64_t total = (int64_t)F * B;
-    const int n_runs = (B + chunk - 1) / chunk;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(t / B);
-        const int i = (int)(t - (int64_t)f * B);
-        const uint64_t* a = runs + (int64_t)f * B;
-        const uint64_t key = a[i];
-        const int r = i / chunk;
-        int pos = i - r * chunk;
-        for (int q = 0; q < n_runs; ++q) {
-            if (q == r) continue;
+                                                    int32_t F, int32_t chunk, int32_t n_runs, int32_t P) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = t / P;
+    const int q = (int)(t - item * P);
+    const bool valid = item < (int64_t)F * B;
+    const int f = valid ? (int)(item / B) : 0;
+    const int i = valid ? (int)(item - (int64_t)f * B) : 0;
+    const uint64_t* a = runs + (int64_t)f * B;
+    const uint64_t key = a[i];
+    const int r = i / chunk;
+    int lo = 0;
+    if (valid && q < n_runs) {
+        if (q == r) lo = i - r * chunk;
+        else {
             const uint64_t* other = a + (int64_t)q * chunk;
-            int lo = 0, hi = min(chunk, B - q * chunk);            // number of keys of run q that are smaller
+            int hi = min(chunk, B - q * chunk);                    // number of keys of run q that are smaller
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (other[mid] < key) lo = mid + 1; else hi = mid;
             }
-            pos += lo;
         }
-        merged[(int64_t)f * B + pos] = key;
+    }
+    const int pos = group_sum(lo, P);
+    if (valid && q == 0) merged[(int64_t)f * B + pos] = key;
+}
+// The same rank merge with the field's keys staged in LDS: one workgroup per (field, run) loads all runs of its field once
+// (the probes of the binary searches then cost an LDS access instead of an L2 round trip each) and places its run's keys.
+// IDX: the keys are the uint32 rows of an id batch [B,F] made of ascending runs (ties between runs go to the earlier run);
+// otherwise they are the unique 64-bit (row, position) keys the chunk sort wrote.
+template <typename K, bool IDX>
+__global__ void __launch_bounds__(SORT_THREADS) k_merge_lds(const void* __restrict__ src, uint64_t* __restrict__ merged, int32_t B,
+                                                            int32_t F, int32_t n_runs, int32_t run_len, int32_t P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    K* keys = reinterpret_cast<K*>(smem_raw);
+    const int f = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+    if (IDX) {
+        const int32_t* idx = static_cast<const int32_t*>(src);
+        for (int i = tid; i < B; i += SORT_THREADS) keys[i] = (K)(uint32_t)idx[(int64_t)i * F + f];
+    } else {
+        const uint64_t* a = static_cast<const uint64_t*>(src) + (int64_t)f * B;
+        for (int i = tid; i < B; i += SORT_THREADS) keys[i] = (K)a[i];
+    }
+    __syncthreads();
+    const int base = r * run_len;
+    const int n_r = min(run_len, B - base);
+    const int rounds = (n_r * P + SORT_THREADS - 1) / SORT_THREADS;      // uniform: every lane takes part in the butterflies
+    for (int it = 0; it < rounds; ++it) {
+        const int t = it * SORT_THREADS + tid;
+        const int item = t / P, q = t - item * P;
+        const bool valid = item < n_r;
+        const K key = keys[valid ? base + item : base];
+        int lo = 0;
+        if (valid && q < n_runs) {
+            if (q == r) lo = item;
+            else {
+                const K* other = keys + q * run_len;
+                int hi = min(run_len, B - q * run_len);
+                if (IDX && q < r) { while (lo < hi) { const int mid = (lo + hi) >> 1; if (other[mid] <= key) lo = mid + 1; else hi = mid; } }
+                else              { while (lo < hi) { const int mid = (lo + hi) >> 1; if (other[mid] <  key) lo = mid + 1; else hi = mid; } }
+            }
+        }
+        const int pos = group_sum(lo, P);
+        if (valid && q == 0)
+            merged[(int64_t)f * B + pos] = IDX ? (((uint64_t)key << 32) | (uint32_t)(base + item)) : (uint64_t)key;
     }
 }
+#define MERGE_LDS_MAX (144 * 1024)
 __global__ void __launch_bounds__(SORT_THREADS) k_dedupe_merged(const uint64_t* __restrict__ merged, int32_t* __restrict__ uniq_row,
                                                                 int32_t* __restrict__ seg_start, int32_t* __restrict__ perm,
                                                                 int32_t* __restrict__ uniq_cnt, int32_t B, int32_t F) {
@@ -246,6 +296,7 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_sort_dedupe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_sort_chunk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_merge_lds<uint64_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { cdc_set_error("embed_sort_dedupe: cannot raise LDS limit: %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
@@ -265,8 +316,16 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
     uint64_t* merged = scratch + (int64_t)F * B;
     hipLaunchKernelGGL(k_sort_chunk, dim3(F, n_runs), dim3(SORT_THREADS), (size_t)chunk * 8, st, idx, runs, (int32_t)B, F, chunk);
     CDC_LAUNCH_CHECK("embed_sort_chunk");
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 8192);
-    hipLaunchKernelGGL(k_merge_runs, dim3(blocks), dim3(256), 0, st, runs, merged, (int32_t)B, F, chunk);
+    int P = 1;
+    while (P < n_runs) P <<= 1;
+    CDC_CHECK_ARG(P <= 64, CDC_E_TOOBIG, "embed_sort_dedupe: %d runs", n_runs);
+    if ((size_t)B * 8 <= MERGE_LDS_MAX) {
+        hipLaunchKernelGGL((k_merge_lds<uint64_t, false>), dim3(F, n_runs), dim3(SORT_THREADS), (size_t)B * 8, st, runs, merged, (int32_t)B, F,
+                           n_runs, chunk, P);
+    } else {
+        const int64_t blocks = cdc_ceil_div((int64_t)F * B * P, 256);
+        hipLaunchKernelGGL(k_merge_runs, dim3((unsigned)blocks), dim3(256), 0, st, runs, merged, (int32_t)B, F, chunk, n_runs, P);
+    }
     CDC_LAUNCH_CHECK("embed_merge_runs");
     hipLaunchKernelGGL(k_dedupe_merged, dim3(F), dim3(SORT_THREADS), 0, st, merged, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F);
     CDC_LAUNCH_CHECK("embed_dedupe_merged");
@@ -277,24 +336,27 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
 // per field (as unsigned: -1 padding last) — the row lists an owner receives from the ranks.  No sort: every key's final
 // position is the sum over the runs of the number of smaller keys (binary searches), then the usual dedupe.
 __global__ void __launch_bounds__(256) k_merge_n(const int32_t* __restrict__ idx, uint64_t* __restrict__ merged, int32_t B, int32_t F,
-                                                 int32_t n_runs, int32_t run_len) {
-    const int64_t total = (int64_t)F * B;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int f = (int)(t / B);
-        const int i = (int)(t - (int64_t)f * B);
-        const uint32_t row = (uint32_t)idx[(int64_t)i * F + f];
-        const int r = i / run_len;
-        int pos = i - r * run_len;
-        for (int q = 0; q < n_runs; ++q) {
-            if (q == r) continue;
+                                                 int32_t n_runs, int32_t run_len, int32_t P) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = t / P;
+    const int q = (int)(t - item * P);
+    const bool valid = item < (int64_t)F * B;
+    const int f = valid ? (int)(item / B) : 0;
+    const int i = valid ? (int)(item - (int64_t)f * B) : 0;
+    const uint32_t row = (uint32_t)idx[(int64_t)i * F + f];
+    const int r = i / run_len;
+    int lo = 0;
+    if (valid && q < n_runs) {
+        if (q == r) lo = i - r * run_len;
+        else {
             const int32_t* col = idx + (int64_t)q * run_len * F + f;
-            int lo = 0, hi = run_len;
+            int hi = run_len;
             if (q < r) { while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)col[(int64_t)mid * F] <= row) lo = mid + 1; else hi = mid; } }
             else       { while (lo < hi) { const int mid = (lo + hi) >> 1; if ((uint32_t)col[(int64_t)mid * F] <  row) lo = mid + 1; else hi = mid; } }
-            pos += lo;
         }
-        merged[(int64_t)f * B + pos] = ((uint64_t)row << 32) | (uint32_t)i;
     }
+    const int pos = group_sum(lo, P);
+    if (valid && q == 0) merged[(int64_t)f * B + pos] = ((uint64_t)row << 32) | (uint32_t)i;
 }
 extern "C" int cdc_embed_merge_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm, int32_t* uniq_cnt,
                                       uint64_t* scratch, int64_t B, int32_t F, int32_t n_runs, void* stream) {
@@ -302,8 +364,22 @@ extern "C" int cdc_embed_merge_dedupe(const int32_t* idx, int32_t* uniq_row, int
     CDC_CHECK_ARG(B > 0 && F > 0 && n_runs > 0 && B % n_runs == 0, CDC_E_BADARG, "embed_merge_dedupe: bad sizes");
     CDC_CHECK_ARG(B <= CDC_SORT_MAX_ROWS, CDC_E_TOOBIG, "embed_merge_dedupe: B=%ld exceeds %d", (long)B, CDC_SORT_MAX_ROWS);
     hipStream_t st = (hipStream_t)stream;
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B, 256), 8192);
-    hipLaunchKernelGGL(k_merge_n, dim3(blocks), dim3(256), 0, st, idx, scratch, (int32_t)B, F, n_runs, (int32_t)(B / n_runs));
+    int P = 1;
+    while (P < n_runs) P <<= 1;
+    CDC_CHECK_ARG(P <= 64, CDC_E_TOOBIG, "embed_merge_dedupe: %d runs", n_runs);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_merge_lds<uint32_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { cdc_set_error("embed_merge_dedupe: cannot raise LDS limit: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    if ((size_t)B * 4 <= MERGE_LDS_MAX) {
+        hipLaunchKernelGGL((k_merge_lds<uint32_t, true>), dim3(F, n_runs), dim3(SORT_THREADS), (size_t)B * 4, st, idx, scratch, (int32_t)B, F,
+                           n_runs, (int32_t)(B / n_runs), P);
+    } else {
+        const int64_t blocks = cdc_ceil_div((int64_t)F * B * P, 256);
+        hipLaunchKernelGGL(k_merge_n, dim3((unsigned)blocks), dim3(256), 0, st, idx, scratch, (int32_t)B, F, n_runs, (int32_t)(B / n_runs), P);
+    }
     CDC_LAUNCH_CHECK("embed_merge_n");
     hipLaunchKernelGGL(k_dedupe_merged, dim3(F), dim3(SORT_THREADS), 0, st, scratch, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F);
     CDC_LAUNCH_CHECK("embed_dedupe_merged");
