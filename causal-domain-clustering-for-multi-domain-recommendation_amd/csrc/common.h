@@ -164,3 +164,39 @@ __device__ __forceinline__ void step_scalars_at(const float* tab, int n, int t, 
     step_size = tab[2 * i];
     bc2s = tab[2 * i + 1];
 }
+
+// Which group owns work item `id`?  Walking the descriptors in the argument block one group at a time costs a scalar cache
+// miss per group before the first load of the tile can be issued; here lane g reads group g's item count (one vector load
+// of the argument block for the whole search), a wave scan turns the counts into offsets and a ballot names the owner.
+// Every lane of the wave must call this.  Returns the group (wave-uniform) or -1; local = id - first item of the group;
+// if PREFIX: *prefix_out = sum of extra(g') over the groups before the owner.
+template <bool PREFIX, typename Count, typename Extra>
+__device__ __forceinline__ int find_group(int n_groups, int id, Count count, Extra extra, int& local, int64_t* prefix_out) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane < n_groups ? count(lane) : 0;
+    int inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    const int exc = inc - c;
+    const unsigned long long owner = __ballot(id >= exc && id < inc);
+    if (owner == 0ull) return -1;
+    const int g = __builtin_amdgcn_readfirstlane(__ffsll((long long)owner) - 1);
+    local = id - __builtin_amdgcn_readlane(exc, g);
+    if constexpr (PREFIX) {
+        const int64_t x = lane < n_groups ? extra(lane) : 0;
+        int64_t xi = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t t = __shfl_up(xi, off, 64);
+            if (lane >= off) xi += t;
+        }
+        const int64_t xe = xi - x;
+        const int lo = __builtin_amdgcn_readlane((int)(uint32_t)xe, g), hi = __builtin_amdgcn_readlane((int)(xe >> 32), g);
+        *prefix_out = ((int64_t)hi << 32) | (uint32_t)lo;
+    }
+    return g;
+}
+

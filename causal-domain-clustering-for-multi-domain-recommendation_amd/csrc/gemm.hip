@@ -324,15 +324,11 @@ template <bool BF16, int BM, int BN, int DEPTH>
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int g = 0, tn_cnt = 1;
-    for (; g < a.n_groups; ++g) {
-        tn_cnt = (a.g[g].N + BN - 1) / BN;
-        const int t = ((a.g[g].M + BM - 1) / BM) * tn_cnt;
-        if (tile < t) break;
-        tile -= t;
-    }
-    if (g >= a.n_groups) return;
+    const int g = find_group<false>(a.n_groups, tile, [&](int l) { return ((a.g[l].M + BM - 1) / BM) * ((a.g[l].N + BN - 1) / BN); },
+                                    [](int) { return (int64_t)0; }, tile, nullptr);
+    if (g < 0) return;
     const cdc_lin_group& G = a.g[g];
+    const int tn_cnt = (G.N + BN - 1) / BN;
     int row_lo = 0, M = G.M;
     if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
     const int i0 = (tile / tn_cnt) * BM, j0 = (tile % tn_cnt) * BN;
@@ -523,17 +519,12 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int split = id % S;
     int tile = id / S;
-    int g = 0, tn_cnt = 1;
     int64_t g_off = 0;
-    for (; g < a.n_groups; ++g) {
-        tn_cnt = (a.g[g].K + BN - 1) / BN;
-        const int t = ((a.g[g].N + BM - 1) / BM) * tn_cnt;
-        if (tile < t) break;
-        tile -= t;
-        g_off += (int64_t)a.g[g].N * a.g[g].K + a.g[g].N;
-    }
-    if (g >= a.n_groups) return;
+    const int g = find_group<true>(a.n_groups, tile, [&](int l) { return ((a.g[l].N + BM - 1) / BM) * ((a.g[l].K + BN - 1) / BN); },
+                                   [&](int l) { return (int64_t)a.g[l].N * a.g[l].K + a.g[l].N; }, tile, &g_off);
+    if (g < 0) return;
     const cdc_bwdw_group& G = a.g[g];
+    const int tn_cnt = (G.K + BN - 1) / BN;
     int row_lo = 0, M = G.M;
     if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
     // this workgroup's slice of the batch rows (multiple of BK so every slice but the last is whole K-slabs)
@@ -600,6 +591,20 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
 
 __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a, int64_t slab_stride, int64_t total) {
     // one flat index space over all groups: a slab IS the concatenation [dW_0 | db_0 | dW_1 | db_1 | ...]
+    __shared__ int64_t first[CDC_MAX_GROUPS + 1];                      // first flat index of every group (scan by wave 0)
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int64_t sz = lane < a.n_groups ? (int64_t)a.g[lane].N * a.g[lane].K + a.g[lane].N : 0;
+        int64_t inc = sz;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane < a.n_groups) first[lane + 1] = inc;
+        if (lane == 0) first[0] = 0;
+    }
+    __syncthreads();
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         // slabs are added in slice order (deterministic); four loads are in flight per round
         float sum = 0.f;
@@ -611,12 +616,8 @@ __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a,
         }
         for (; s < a.split_k; ++s) sum += a.workspace[(int64_t)s * slab_stride + e];
         int g = 0;
-        int64_t local = e;
-        for (; g < a.n_groups; ++g) {
-            const int64_t sz = (int64_t)a.g[g].N * a.g[g].K + a.g[g].N;
-            if (local < sz) break;
-            local -= sz;
-        }
+        while (g + 1 < a.n_groups && e >= first[g + 1]) ++g;
+        const int64_t local = e - first[g];
         const cdc_bwdw_group& G = a.g[g];
         const int64_t nk = (int64_t)G.N * G.K;
         if (local < nk) {
@@ -660,17 +661,12 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w_tr(const cdc_lin
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int split = id % S;
     int tile = id / S;
-    int g = 0, tn_cnt = 1;
     int64_t g_off = 0;
-    for (; g < a.n_groups; ++g) {
-        tn_cnt = (a.g[g].K + 63) / 64;
-        const int t = ((a.g[g].N + 63) / 64) * tn_cnt;
-        if (tile < t) break;
-        tile -= t;
-        g_off += (int64_t)a.g[g].N * a.g[g].K + a.g[g].N;
-    }
-    if (g >= a.n_groups) return;
+    const int g = find_group<true>(a.n_groups, tile, [&](int l) { return ((a.g[l].N + 63) / 64) * ((a.g[l].K + 63) / 64); },
+                                   [&](int l) { return (int64_t)a.g[l].N * a.g[l].K + a.g[l].N; }, tile, &g_off);
+    if (g < 0) return;
     const cdc_bwdw_group& G = a.g[g];
+    const int tn_cnt = (G.K + 63) / 64;
     int row_lo = 0, M = G.M;
     if (a.row_offsets) { row_lo = a.row_offsets[g]; M = a.row_offsets[g + 1] - row_lo; }
     int chunk = ((M + S - 1) / S + TR_BK - 1) / TR_BK * TR_BK;
@@ -875,14 +871,11 @@ extern "C" int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void*
 // dst[c, r] = src[r, c] for a list of matrices: 32x32 tiles through LDS (padded), one launch for the whole list
 __global__ void __launch_bounds__(256) k_transpose_multi(const cdc_transpose_args a) {
     __shared__ float tile[32][33];
-    int blk = blockIdx.x, ti = 0, tc = 1;
-    for (; ti < a.n; ++ti) {
-        tc = (a.t[ti].cols + 31) / 32;
-        const int nb = ((a.t[ti].rows + 31) / 32) * tc;
-        if (blk < nb) break;
-        blk -= nb;
-    }
-    if (ti >= a.n) return;
+    int blk = blockIdx.x;
+    const int ti = find_group<false>(a.n, blk, [&](int l) { return ((a.t[l].rows + 31) / 32) * ((a.t[l].cols + 31) / 32); },
+                                     [](int) { return (int64_t)0; }, blk, nullptr);
+    if (ti < 0) return;
+    const int tc = (a.t[ti].cols + 31) / 32;
     const int rows = a.t[ti].rows, cols = a.t[ti].cols;
     const int r0 = (blk / tc) * 32, c0 = (blk % tc) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8

@@ -270,15 +270,11 @@ __device__ __forceinline__ bool bn_locate(const Args& a, int n_chunks, BnTile& t
     // blockIdx.x -> (segment, 64-column tile, row chunk)
     int tile = blockIdx.x / n_chunks;
     t.chunk = blockIdx.x % n_chunks;
-    int s = 0, col_base = 0;
-    for (; s < a.n_seg; ++s) {
-        const int ct = (a.s[s].C + 63) / 64;
-        if (tile < ct) break;
-        tile -= ct;
-        col_base += a.s[s].C;
-    }
-    if (s >= a.n_seg) return false;
-    t.seg = s; t.c0 = tile * 64; t.col_base = col_base;
+    int64_t col_base = 0;
+    const int s = find_group<true>(a.n_seg, tile, [&](int l) { return (a.s[l].C + 63) / 64; }, [&](int l) { return (int64_t)a.s[l].C; },
+                                   tile, &col_base);
+    if (s < 0) return false;
+    t.seg = s; t.c0 = tile * 64; t.col_base = (int)col_base;
     t.row_lo = 0; t.M = (int)a.M;
     if (a.row_offsets) { const int rg = a.s[s].row_group; t.row_lo = a.row_offsets[rg]; t.M = a.row_offsets[rg + 1] - t.row_lo; }
     return true;
@@ -1003,14 +999,25 @@ extern "C" int cdc_cross_bwd(const float* d_out, int64_t ldo, const float* x0, i
 // dense-parameter Adam, multi-tensor (run.py:720-721 + the L2 term of model/layer.py:96-112)
 // =================================================================================================
 #define ADAM_CHUNK 4096
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args a) {
-    int chunk = blockIdx.x, ti = 0;
-    for (; ti < a.n_tensors; ++ti) {
-        const int nc = (int)((a.t[ti].n + ADAM_CHUNK - 1) / ADAM_CHUNK);
-        if (chunk < nc) break;
-        chunk -= nc;
+    // Which tensor does this workgroup's chunk belong to?  Walking the argument block one tensor at a time costs a scalar
+    // cache miss per tensor (12 us for the last of 48); instead lane i reads tensor i's size, a wave scan turns the chunk
+    // counts into offsets and a ballot names the tensor — one vector load for the whole search, the same in every wave.
+    const int lane = threadIdx.x & 63;
+    const int64_t n_l = lane < a.n_tensors ? a.t[lane].n : 0;
+    const int nc = (int)((n_l + ADAM_CHUNK - 1) / ADAM_CHUNK);
+    int inc = nc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
     }
-    if (ti >= a.n_tensors) return;
+    const int exc = inc - nc;
+    const unsigned long long owner = __ballot((int)blockIdx.x >= exc && (int)blockIdx.x < inc);
+    if (owner == 0ull) return;
+    const int ti = __builtin_amdgcn_readfirstlane(__ffsll((long long)owner) - 1);
+    const int chunk = (int)blockIdx.x - __builtin_amdgcn_readlane(exc, ti);
     const cdc_adam_tensor& T = a.t[ti];
     AdamConsts c;
     c.lerp_w = a.lerp_w; c.beta2 = a.beta2; c.omb2 = a.one_minus_beta2; c.eps = a.eps; c.wd = a.weight_decay;
@@ -1020,25 +1027,55 @@ __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args 
     const int64_t begin = (int64_t)chunk * ADAM_CHUNK;
     const int64_t end = min(begin + ADAM_CHUNK, T.n);
     double sq = 0.0;
-    // four elements per round with all their loads issued first; one workgroup covers ADAM_CHUNK elements so that the
-    // launch ends in a few hundred (not thousands of) same-address double atomics for the regularisation sum
-    for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += 4 * ROW_THREADS) {
-        float w[4], m[4], v[4], g[4];
+    // One workgroup covers ADAM_CHUNK elements so that the launch ends in a few hundred (not thousands of) same-address
+    // double atomics for the regularisation sum; with so few workgroups the launch lives on memory-level parallelism, so
+    // every thread issues ALL its loads (16 elements x 4 arrays, as 16-byte loads when the tensors allow) before it computes.
+    const bool vec = ((((uintptr_t)T.w | (uintptr_t)T.m | (uintptr_t)T.v | (uintptr_t)T.g) & 15) == 0);
+    if (vec && begin + ADAM_CHUNK <= T.n) {
+        constexpr int R = ADAM_CHUNK / (4 * ROW_THREADS);
+        adam_f4 w[R], m[R], v[R], g[R];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t i = i0 + (int64_t)q * ROW_THREADS;
-            const bool ok = i < end;
-            w[q] = ok ? T.w[i] : 0.f; m[q] = ok ? T.m[i] : 0.f; v[q] = ok ? T.v[i] : 0.f;
-            g[q] = (ok && T.g) ? T.g[i] : 0.f;
+        for (int q = 0; q < R; ++q) {
+            const int64_t i = begin + ((int64_t)q * ROW_THREADS + threadIdx.x) * 4;
+            w[q] = *reinterpret_cast<const adam_f4*>(T.w + i);
+            m[q] = *reinterpret_cast<const adam_f4*>(T.m + i);
+            v[q] = *reinterpret_cast<const adam_f4*>(T.v + i);
+            g[q] = T.g ? *reinterpret_cast<const adam_f4*>(T.g + i) : adam_f4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t i = i0 + (int64_t)q * ROW_THREADS;
-            if (i >= end) continue;
-            if (a.grad_scale != 1.f) g[q] *= a.grad_scale;
-            sq += (double)(w[q] * w[q]);
-            adam_elem(w[q], m[q], v[q], g[q], c, step_size, bc2s);
-            T.w[i] = w[q]; T.m[i] = m[q]; T.v[i] = v[q];
+        for (int q = 0; q < R; ++q) {
+            const int64_t i = begin + ((int64_t)q * ROW_THREADS + threadIdx.x) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float we = w[q][e], me = m[q][e], ve = v[q][e], ge = g[q][e];
+                if (a.grad_scale != 1.f) ge *= a.grad_scale;
+                sq += (double)(we * we);
+                adam_elem(we, me, ve, ge, c, step_size, bc2s);
+                w[q][e] = we; m[q][e] = me; v[q][e] = ve;
+            }
+            *reinterpret_cast<adam_f4*>(T.w + i) = w[q];
+            *reinterpret_cast<adam_f4*>(T.m + i) = m[q];
+            *reinterpret_cast<adam_f4*>(T.v + i) = v[q];
+        }
+    } else {
+        for (int64_t i0 = begin + threadIdx.x; i0 < end; i0 += 4 * ROW_THREADS) {
+            float w[4], m[4], v[4], g[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t i = i0 + (int64_t)q * ROW_THREADS;
+                const bool ok = i < end;
+                w[q] = ok ? T.w[i] : 0.f; m[q] = ok ? T.m[i] : 0.f; v[q] = ok ? T.v[i] : 0.f;
+                g[q] = (ok && T.g) ? T.g[i] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t i = i0 + (int64_t)q * ROW_THREADS;
+                if (i >= end) continue;
+                if (a.grad_scale != 1.f) g[q] *= a.grad_scale;
+                sq += (double)(w[q] * w[q]);
+                adam_elem(w[q], m[q], v[q], g[q], c, step_size, bc2s);
+                T.w[i] = w[q]; T.m[i] = m[q]; T.v[i] = v[q];
+            }
         }
     }
     if (a.reg_sum && T.l2 != 0.f) {
