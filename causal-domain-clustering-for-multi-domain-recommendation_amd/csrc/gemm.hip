@@ -414,15 +414,11 @@ template <bool BF16, int BM, int BN, bool WT, int DEPTH>
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bwdx_args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile = xcd_remap(blockIdx.x, gridDim.x);
-    int o = 0, tn_cnt = 1;
-    for (; o < a.n_out; ++o) {
-        tn_cnt = (a.o[o].K + BN - 1) / BN;
-        const int t = ((a.o[o].M + BM - 1) / BM) * tn_cnt;
-        if (tile < t) break;
-        tile -= t;
-    }
-    if (o >= a.n_out) return;
+    const int o = find_group<false>(a.n_out, tile, [&](int l) { return ((a.o[l].M + BM - 1) / BM) * ((a.o[l].K + BN - 1) / BN); },
+                                    [](int) { return (int64_t)0; }, tile, nullptr);
+    if (o < 0) return;
     const cdc_bwdx_out& O = a.o[o];
+    const int tn_cnt = (O.K + BN - 1) / BN;
     int row_lo = 0, M = O.M;
     if (a.row_offsets) { row_lo = a.row_offsets[o]; M = a.row_offsets[o + 1] - row_lo; }
     const int i0 = (tile / tn_cnt) * BM, j0 = (tile % tn_cnt) * BN;
@@ -433,15 +429,37 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bw
     for (int mt = 0; mt < BM / 32; ++mt)
 #pragma unroll
         for (int nt = 0; nt < BN / 32; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < a.n_seg; ++s) {
-        if (a.s[s].out != o) continue;
-        const cdc_bwdx_seg& S = a.s[s];
-        Operand A{S.dz + (int64_t)row_lo * S.lddz, S.lddz, 1, M, S.N};   // (i=row, r=n)  r contiguous
+    // lane l fetches segment l's descriptor (one round of vector loads for the whole list instead of a scalar cache miss or
+    // two per segment, each in front of that segment's first tile load); the loop then reads them lane by lane
+    unsigned long long todo;
+    uint64_t v_dz, v_w;
+    int64_t v_lddz, v_ldw;
+    int v_n;
+    {
+        const int l = threadIdx.x & 63;
+        const bool has = l < a.n_seg;
+        const cdc_bwdx_seg& L = a.s[has ? l : 0];
+        v_dz = (uint64_t)L.dz; v_lddz = L.lddz; v_n = L.N;
+        v_w = WT ? (uint64_t)L.wt : (uint64_t)L.w;
+        v_ldw = WT ? L.ldwt : L.ldw;
+        todo = __ballot(has && L.out == o);
+    }
+    auto lane64 = [](uint64_t v, int l) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    };
+    while (todo) {
+        const int s = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const float* dz = reinterpret_cast<const float*>(lane64(v_dz, s));
+        const float* wp = reinterpret_cast<const float*>(lane64(v_w, s));
+        const int64_t lddz = (int64_t)lane64((uint64_t)v_lddz, s), ldw = (int64_t)lane64((uint64_t)v_ldw, s);
+        const int N = __builtin_amdgcn_readlane(v_n, s);
+        Operand A{dz + (int64_t)row_lo * lddz, lddz, 1, M, N};           // (i=row, r=n)  r contiguous
         if (WT) {
-            Operand B{S.wt, S.ldwt, 1, O.K, S.N};                         // W^T [K,N]: (j=k, r=n)  r contiguous
+            Operand B{wp, ldw, 1, O.K, N};                                // W^T [K,N]: (j=k, r=n)  r contiguous
             gemm_accumulate<BF16, BM, BN, true, true, false, DEPTH>(A, B, i0, j0, smem, acc, nullptr);
         } else {
-            Operand B{S.w, 1, S.ldw, O.K, S.N};                           // W [N,K]:   (j=k, r=n)  j contiguous
+            Operand B{wp, 1, ldw, O.K, N};                                // W [N,K]:   (j=k, r=n)  j contiguous
             gemm_accumulate<BF16, BM, BN, true, false, false>(A, B, i0, j0, smem, acc, nullptr);
         }
     }

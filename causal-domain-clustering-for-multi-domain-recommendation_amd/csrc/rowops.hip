@@ -593,20 +593,53 @@ __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd(const cdc_rowdot_bwd
     float* mine = sh + wave * (kmax + 1);
     for (int k = lane; k <= kmax; k += 64) mine[k] = 0.f;
     float db = 0.f;
-    for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
-        const int64_t gr = row_lo + r;
-        float d = G.dout[gr * G.ld_dout];
-        if (a.sigmoid) { const float o = G.out[gr * G.ld_out]; d = d * o * (1.f - o); }
-        if (lane == 0 && G.dlogit) G.dlogit[gr * G.ld_dlogit] = d;
-        db += d;
-        const float* x = G.x + gr * G.ldx;
+    // four rows per round: their d (and sigmoid outputs) are fetched together, then their x rows — the launch is a few
+    // dependent round trips long, so what counts is how many loads each of them carries
+    constexpr int RB = 4;
+    for (int r0 = r_begin + wave; r0 < r_end; r0 += RB * WAVES_PER_BLOCK) {
+        float d[RB];
+        int64_t gr[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int r = r0 + q * WAVES_PER_BLOCK;
+            gr[q] = row_lo + min(r, r_end - 1);
+            d[q] = G.dout[gr[q] * G.ld_dout];
+        }
+        if (a.sigmoid) {
+            float o[RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) o[q] = G.out[gr[q] * G.ld_out];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) d[q] = d[q] * o[q] * (1.f - o[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            if (r0 + q * WAVES_PER_BLOCK >= r_end) d[q] = 0.f;          // rows past the part: contribute nothing, store nothing
+            else if (lane == 0 && G.dlogit) G.dlogit[gr[q] * G.ld_dlogit] = d[q];
+            db += d[q];
+        }
         for (int k = lane; k < G.K; k += 64) {
-            mine[k] += d * x[k];
-            if (G.dx) {
-                float* dst = G.dx + gr * G.lddx + k;
-                const float v = d * G.w[k];
-                *dst = G.accumulate_dx ? *dst + v : v;
+            float xv[RB], old[RB];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) xv[q] = G.x[gr[q] * G.ldx + k];
+            if (G.dx && G.accumulate_dx) {
+#pragma unroll
+                for (int q = 0; q < RB; ++q) old[q] = G.dx[gr[q] * G.lddx + k];
             }
+            const float wk = G.dx ? G.w[k] : 0.f;
+            float acc = mine[k];
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const bool live = r0 + q * WAVES_PER_BLOCK < r_end;
+                if (live) {
+                    acc += d[q] * xv[q];                                // ascending row order, as before
+                    if (G.dx) {
+                        const float v = d[q] * wk;
+                        G.dx[gr[q] * G.lddx + k] = G.accumulate_dx ? old[q] + v : v;
+                    }
+                }
+            }
+            mine[k] = acc;
         }
     }
     if (lane == 0) mine[kmax] = db;
@@ -619,15 +652,22 @@ __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd(const cdc_rowdot_bwd
         ws[k] = s;
     }
 }
+// one wave per output element k: lane l adds parts l, l+64, ... in ascending order, a butterfly adds the 64 lane sums
 __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd_final(const cdc_rowdot_bwd_args a, int kmax) {
     const int g = blockIdx.y;
     const cdc_rowdot_bgroup& G = a.g[g];
-    const int k = blockIdx.x * ROW_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (k > kmax) return;
-    const float* ws = a.workspace + (int64_t)g * CDC_ROWDOT_PARTS * (kmax + 1);
+    const float* ws = a.workspace + (int64_t)g * CDC_ROWDOT_PARTS * (kmax + 1) + k;
+    float v[CDC_ROWDOT_PARTS / 64];
+#pragma unroll
+    for (int i = 0; i < CDC_ROWDOT_PARTS / 64; ++i) v[i] = ws[(int64_t)(lane + 64 * i) * (kmax + 1)];
     float s = 0.f;
-#pragma unroll 16
-    for (int p = 0; p < CDC_ROWDOT_PARTS; ++p) s += ws[(int64_t)p * (kmax + 1) + k];
+#pragma unroll
+    for (int i = 0; i < CDC_ROWDOT_PARTS / 64; ++i) s += v[i];
+    s = wave_sum(s);
+    if (lane != 0) return;
     if (k < G.K) { if (G.dw) G.dw[k] = s; }
     else if (k == kmax && G.dbias) G.dbias[0] = s;
 }
@@ -644,7 +684,7 @@ extern "C" int cdc_rowdot_bwd(const cdc_rowdot_bwd_args* a, void* stream) {
     hipLaunchKernelGGL(k_rowdot_bwd, dim3(CDC_ROWDOT_PARTS, a->n_groups), dim3(ROW_THREADS), WAVES_PER_BLOCK * (kmax + 1) * sizeof(float),
                        (hipStream_t)stream, *a, kmax);
     CDC_LAUNCH_CHECK("rowdot_bwd");
-    hipLaunchKernelGGL(k_rowdot_bwd_final, dim3(cdc_ceil_div(kmax + 1, ROW_THREADS), a->n_groups), dim3(ROW_THREADS), 0,
+    hipLaunchKernelGGL(k_rowdot_bwd_final, dim3(cdc_ceil_div(kmax + 1, WAVES_PER_BLOCK), a->n_groups), dim3(ROW_THREADS), 0,
                        (hipStream_t)stream, *a, kmax);
     CDC_LAUNCH_CHECK("rowdot_bwd_final");
     return 0;
