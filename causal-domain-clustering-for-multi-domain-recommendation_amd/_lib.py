@@ -152,6 +152,11 @@ class AdamTensor(C.Structure):
     _fields_ = [("w", c_p), ("g", c_p), ("m", c_p), ("v", c_p), ("n", c_i64), ("l2", c_f)]
 
 
+class AddNArgs(C.Structure):
+    _fields_ = [("dst", c_p), ("ld_dst", c_i64), ("rows", c_i64), ("cols", c_i32), ("n", c_i32), ("accumulate", c_i32),
+                ("src", c_p * MAX_GROUPS), ("ld_src", c_i64 * MAX_GROUPS)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("n_tensors", c_i32), ("lerp_w", c_f), ("beta2", c_f), ("one_minus_beta2", c_f), ("eps", c_f),
                 ("weight_decay", c_f), ("step_scalars", c_p), ("n_scalars", c_i32), ("grad_scale", c_f),
@@ -165,6 +170,7 @@ _SIGNATURES = {
     "cdc_embed_gather_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
     "cdc_embed_index": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i64, c_p]),
     "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "cdc_embed_sort_dedupe_ids": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_segment_sum": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_segment_sum_direct": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
@@ -221,6 +227,7 @@ _SIGNATURES = {
     "cdc_fill_f32": (c_i32, [c_p, c_f, c_i64, c_p]),
     "cdc_fill_f64": (c_i32, [c_p, C.c_double, c_i64, c_p]),
     "cdc_add_inplace": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_p]),
+    "cdc_add_n": (c_i32, [c_p, c_p]),
     "cdc_mul_bcast": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "cdc_mul_bcast_bwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "cdc_group_partition": (c_i32, [c_p, c_p, c_p, c_i64, c_i32, c_p]),

@@ -161,8 +161,32 @@ __device__ __forceinline__ void dedupe_sorted(const uint64_t* keys, int n, int32
     }
 }
 
+// What the sort kernels read: row indices [B,F], or (offsets != NULL) raw ids [B,F] that become rows by adding the field
+// offsets (out-of-range -> -1, as cdc_embed_index writes them).  step != NULL: the launch also does cdc_begin_step's work
+// (first kernel of a training step: ++*step, clear the accumulators) — two launches less per step.
+struct SortSrc {
+    const int32_t* idx;
+    const int32_t* offsets;
+    int64_t R;
+    int32_t* step;
+    double* acc;
+    int32_t n_acc;
+};
+__device__ __forceinline__ uint32_t sort_row(const SortSrc& s, int64_t i, int f, int F) {
+    const int32_t v = s.idx[i * F + f];
+    if (!s.offsets) return (uint32_t)v;
+    const int32_t row = (int32_t)((uint32_t)v + (uint32_t)s.offsets[f]);
+    return (row >= 0 && (int64_t)row < s.R) ? (uint32_t)row : 0xffffffffu;
+}
+__device__ __forceinline__ void sort_begin_step(const SortSrc& s, int tid) {
+    if (s.step && blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid == 0) *s.step += 1;
+        if (tid < s.n_acc) s.acc[tid] = 0.0;
+    }
+}
+
 // B <= SORT_CHUNK: sort + dedupe in one workgroup per field
-__global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __restrict__ idx, int32_t* __restrict__ uniq_row,
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const SortSrc src, int32_t* __restrict__ uniq_row,
                                                               int32_t* __restrict__ seg_start, int32_t* __restrict__ perm,
                                                               int32_t* __restrict__ uniq_cnt, int32_t B, int32_t F,
                                                               int32_t n_pad) {
@@ -173,9 +197,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __r
     const int tid = threadIdx.x;
     for (int i = tid; i < n_pad; i += SORT_THREADS) {
         uint64_t k = ~0ull;                                               // padding sorts last
-        if (i < B) k = ((uint64_t)(uint32_t)idx[(int64_t)i * F + f] << 32) | (uint32_t)i;
+        if (i < B) k = ((uint64_t)sort_row(src, i, f, F) << 32) | (uint32_t)i;
         keys[i] = k;
     }
+    sort_begin_step(src, tid);
     __syncthreads();
     lds_bitonic_sort(keys, n_pad, tid);
     dedupe_sorted(keys, B, scan, uniq_row + (int64_t)f * B, seg_start + (int64_t)f * (B + 1), perm + (int64_t)f * B, uniq_cnt + f, tid);
@@ -186,7 +211,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_dedupe(const int32_t* __r
 // busy).  So (1) chunks of `chunk` rows are sorted by separate workgroups (fewer stages, more CUs) and written out,
 // (2) the sorted runs are merged by rank — a key's final position is the sum over the runs of the number of smaller keys;
 // keys are unique, the batch row is part of them — and (3) dedupe runs from global memory.
-__global__ void __launch_bounds__(SORT_THREADS) k_sort_chunk(const int32_t* __restrict__ idx, uint64_t* __restrict__ runs, int32_t B,
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_chunk(const SortSrc src, uint64_t* __restrict__ runs, int32_t B,
                                                              int32_t F, int32_t chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
@@ -195,9 +220,10 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_chunk(const int32_t* __re
     const int n = min(chunk, B - r0);
     for (int i = tid; i < chunk; i += SORT_THREADS) {
         uint64_t k = ~0ull;
-        if (i < n) k = ((uint64_t)(uint32_t)idx[(int64_t)(r0 + i) * F + f] << 32) | (uint32_t)(r0 + i);
+        if (i < n) k = ((uint64_t)sort_row(src, r0 + i, f, F) << 32) | (uint32_t)(r0 + i);
         keys[i] = k;
     }
+    sort_begin_step(src, tid);
     __syncthreads();
     lds_bitonic_sort(keys, chunk, tid);
     uint64_t* out = runs + (int64_t)f * B + r0;
@@ -286,8 +312,9 @@ __global__ void __launch_bounds__(SORT_THREADS) k_dedupe_merged(const uint64_t* 
                   uniq_cnt + f, threadIdx.x);
 }
 
-extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
-                                     int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream) {
+static int sort_dedupe_launch(const SortSrc& src, int32_t* uniq_row, int32_t* seg_start, int32_t* perm, int32_t* uniq_cnt,
+                              uint64_t* scratch, int64_t B, int32_t F, void* stream) {
+    const int32_t* idx = src.idx;
     CDC_CHECK_ARG(idx && uniq_row && seg_start && perm && uniq_cnt, CDC_E_BADARG, "embed_sort_dedupe: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0, CDC_E_BADARG, "embed_sort_dedupe: bad sizes");
     CDC_CHECK_ARG(B <= CDC_SORT_MAX_ROWS, CDC_E_TOOBIG, "embed_sort_dedupe: B=%ld exceeds %d", (long)B, CDC_SORT_MAX_ROWS);
@@ -305,7 +332,7 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
         int n_pad = SORT_THREADS;   // at least one key per thread keeps the chunking simple
         while (n_pad < B) n_pad <<= 1;
         const size_t lds = (size_t)n_pad * 8 + SORT_THREADS * 4;
-        hipLaunchKernelGGL(k_sort_dedupe, dim3(F), dim3(SORT_THREADS), lds, st, idx, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F, n_pad);
+        hipLaunchKernelGGL(k_sort_dedupe, dim3(F), dim3(SORT_THREADS), lds, st, src, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F, n_pad);
         CDC_LAUNCH_CHECK("embed_sort_dedupe");
         return 0;
     }
@@ -314,7 +341,7 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
     const int n_runs = (int)cdc_ceil_div(B, chunk);
     uint64_t* runs = scratch;
     uint64_t* merged = scratch + (int64_t)F * B;
-    hipLaunchKernelGGL(k_sort_chunk, dim3(F, n_runs), dim3(SORT_THREADS), (size_t)chunk * 8, st, idx, runs, (int32_t)B, F, chunk);
+    hipLaunchKernelGGL(k_sort_chunk, dim3(F, n_runs), dim3(SORT_THREADS), (size_t)chunk * 8, st, src, runs, (int32_t)B, F, chunk);
     CDC_LAUNCH_CHECK("embed_sort_chunk");
     int P = 1;
     while (P < n_runs) P <<= 1;
@@ -330,6 +357,20 @@ extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int3
     hipLaunchKernelGGL(k_dedupe_merged, dim3(F), dim3(SORT_THREADS), 0, st, merged, uniq_row, seg_start, perm, uniq_cnt, (int32_t)B, F);
     CDC_LAUNCH_CHECK("embed_dedupe_merged");
     return 0;
+}
+
+extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
+                                     int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream) {
+    const SortSrc src = {idx, nullptr, 0, nullptr, nullptr, 0};
+    return sort_dedupe_launch(src, uniq_row, seg_start, perm, uniq_cnt, scratch, B, F, stream);
+}
+extern "C" int cdc_embed_sort_dedupe_ids(const int32_t* ids, const int32_t* offsets, int64_t R, int32_t* step_dev, double* accumulators,
+                                         int32_t n_acc, int32_t* uniq_row, int32_t* seg_start, int32_t* perm, int32_t* uniq_cnt,
+                                         uint64_t* scratch, int64_t B, int32_t F, void* stream) {
+    CDC_CHECK_ARG(offsets && R > 0 && n_acc >= 0 && n_acc <= 64 && (n_acc == 0 || accumulators) && (step_dev || n_acc == 0), CDC_E_BADARG,
+                  "embed_sort_dedupe_ids: bad argument");
+    const SortSrc src = {ids, offsets, R, step_dev, accumulators, n_acc};
+    return sort_dedupe_launch(src, uniq_row, seg_start, perm, uniq_cnt, scratch, B, F, stream);
 }
 
 // Same result as cdc_embed_sort_dedupe for a batch that already consists of n_runs runs of run_len rows, each ascending

@@ -175,6 +175,34 @@ extern "C" int cdc_add_inplace(float* dst, int64_t ld_dst, const float* src, int
     return 0;
 }
 
+// dst (=|+=) src_0 + src_1 + ... (added in list order): the fan-in of one gradient from several producers in ONE launch
+__global__ void __launch_bounds__(256) k_add_n(const cdc_add_n_args a) {
+    const int64_t total = a.rows * a.cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / a.cols;
+        const int c = (int)(i - r * a.cols);
+        float* d = a.dst + r * a.ld_dst + c;
+        float v[CDC_MAX_GROUPS];
+#pragma unroll
+        for (int k = 0; k < CDC_MAX_GROUPS; ++k)
+            if (k < a.n) v[k] = a.src[k][r * a.ld_src[k] + c];
+        float s = a.accumulate ? *d : 0.f;
+#pragma unroll
+        for (int k = 0; k < CDC_MAX_GROUPS; ++k)
+            if (k < a.n) s = (k == 0 && !a.accumulate) ? v[0] : s + v[k];
+        *d = s;
+    }
+}
+extern "C" int cdc_add_n(const cdc_add_n_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->dst && a->n > 0 && a->n <= CDC_MAX_GROUPS && a->rows >= 0 && a->cols > 0, CDC_E_BADARG, "add_n: bad argument");
+    for (int k = 0; k < a->n; ++k) CDC_CHECK_ARG(a->src[k], CDC_E_BADARG, "add_n: source %d is NULL", k);
+    if (a->rows == 0) return 0;
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(a->rows * a->cols, 256), 4096);
+    hipLaunchKernelGGL(k_add_n, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("add_n");
+    return 0;
+}
+
 
 // one launch instead of three device-to-device copies: a batch (ids int32 [B,F], labels int16 [B], tower index int64 [B] or
 // NULL) into the buffers a replayed launch sequence reads (run.py:476-479 hands the step exactly these three tensors)

@@ -698,16 +698,34 @@ __global__ void __launch_bounds__(1024) k_bce(const float* __restrict__ p, int64
                                               float* __restrict__ loss, float* __restrict__ dp, int64_t lddp, int64_t B,
                                               int32_t n_col, float inv_count) {
     double acc = 0.0;
-    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
-        int64_t col = group ? group[b] : 0;
-        if (col < 0 || col >= n_col) col = 0;
-        const float x = p[b * ldp + col];
-        const float t = y_i16 ? (float)y_i16[b] : y_f32[b];
-        const float l = (t - 1.f) * fmaxf(log1pf(-x), -100.f) - t * fmaxf(logf(x), -100.f);
-        acc += (double)l;
-        if (dp) {
-            for (int c = 0; c < n_col; ++c) dp[b * lddp + c] = 0.f;
-            dp[b * lddp + col] = inv_count * (x - t) / fmaxf((1.f - x) * x, 1e-12f);
+    // one workgroup (the loss is one ordered sum), so the launch is as long as its chain of dependent loads: four rows per
+    // thread and round, their tower indices fetched together, then their probabilities and labels
+    constexpr int RB = 4;
+    for (int64_t b0 = threadIdx.x; b0 < B; b0 += (int64_t)RB * blockDim.x) {
+        int64_t col[RB];
+        float x[RB], t[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int64_t b = b0 + (int64_t)q * blockDim.x;
+            col[q] = (b < B && group) ? group[b] : 0;
+            if (col[q] < 0 || col[q] >= n_col) col[q] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int64_t b = b0 + (int64_t)q * blockDim.x;
+            x[q] = b < B ? p[b * ldp + col[q]] : 0.5f;
+            t[q] = b < B ? (y_i16 ? (float)y_i16[b] : y_f32[b]) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int64_t b = b0 + (int64_t)q * blockDim.x;
+            if (b >= B) continue;
+            const float l = (t[q] - 1.f) * fmaxf(log1pf(-x[q]), -100.f) - t[q] * fmaxf(logf(x[q]), -100.f);
+            acc += (double)l;
+            if (dp) {
+                for (int c = 0; c < n_col; ++c) dp[b * lddp + c] = 0.f;
+                dp[b * lddp + col[q]] = inv_count * (x[q] - t[q]) / fmaxf((1.f - x[q]) * x[q], 1e-12f);
+            }
         }
     }
     __shared__ double sh[16];

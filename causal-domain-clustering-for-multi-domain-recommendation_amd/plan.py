@@ -924,17 +924,29 @@ class RowDot:
                 G.dbias = None
             if self.addends:
                 G.dlogit, G.ld_dlogit = self.dlogit[i].ptr, self.dlogit[i].ld
-                for ad in (self.addends if (self.row_offsets is None or i == 0) else []):
-                    adg = ad.grad
-                    if gs.claim(ad):
-                        post.append(plan.call("cdc_add_inplace", adg.cptr(), C.c_int64(adg.ld), self.dlogit[i].cptr(),
-                                              C.c_int64(self.dlogit[i].ld), C.c_int64(self.M), 1))
-                    else:
-                        t_dst, t_src = adg.tensor(), self.dlogit[i].tensor()
-                        post.append(lambda st, d=t_dst, s_=t_src: d.copy_(s_))
+                if self.row_offsets is not None and i == 0:
+                    for ad in self.addends:
+                        adg = ad.grad
+                        if gs.claim(ad):
+                            post.append(plan.call("cdc_add_inplace", adg.cptr(), C.c_int64(adg.ld), self.dlogit[i].cptr(),
+                                                  C.c_int64(self.dlogit[i].ld), C.c_int64(self.M), 1))
+                        else:
+                            t_dst, t_src = adg.tensor(), self.dlogit[i].tensor()
+                            post.append(lambda st, d=t_dst, s_=t_src: d.copy_(s_))
             else:
                 G.dlogit = None
             G.K = g["w"].numel()
+        if self.addends and self.row_offsets is None:
+            # every group's logit gradient flows into every addend: one fan-in launch per addend, this launch's groups added in order
+            for ad in self.addends:
+                adg = ad.grad
+                n = L.AddNArgs()
+                n.dst, n.ld_dst, n.rows, n.cols, n.n = adg.ptr, adg.ld, self.M, 1, len(idxs)
+                n.accumulate = 1 if gs.claim(ad) else 0
+                for k, i in enumerate(idxs):
+                    n.src[k], n.ld_src[k] = self.dlogit[i].ptr, self.dlogit[i].ld
+                self._keep.append(n)
+                post.append(plan.call("cdc_add_n", C.byref(n)))
         self._keep.append(a)
         plan.bwd_steps.append(plan.call("cdc_rowdot_bwd", C.byref(a)))
         plan.bwd_steps.extend(post)

@@ -148,9 +148,10 @@ class TrainStep:
         """single GPU: the whole step is one launch sequence (one hipGraph when use_graph)."""
         opt, plan, emb = self.opt, self.plan, self.emb
         B, F, D = self.B, emb.F, emb.D
-        opt.begin_step()
         if opt.table_mode == "lazy":
-            opt.table_catchup(emb.ids, emb.offsets, emb.idx, B, F, D)     # + this step's slice of the whole-table replay
+            opt.begin_step_catchup(emb.ids, emb.offsets, B, F, D)         # + this step's slice of the whole-table replay
+        else:
+            opt.begin_step()
         plan.forward()
         self._bce()
         plan.backward()

@@ -77,6 +77,12 @@ int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out
 #define CDC_SORT_MAX_ROWS 32768
 int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
                           int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream);
+/* The same from the raw ids of a batch: row = ids[b,f] + offsets[f] (model/layer.py:139), ids outside [0,R) sort as -1 —
+ * cdc_embed_index fused into the sort's first launch.  step_dev != NULL: that launch also does cdc_begin_step's work
+ * (++*step_dev, accumulators[0..n_acc) = 0) — for a training step whose first launch this is. */
+int cdc_embed_sort_dedupe_ids(const int32_t* ids, const int32_t* offsets, int64_t R, int32_t* step_dev, double* accumulators,
+                              int32_t n_acc, int32_t* uniq_row, int32_t* seg_start, int32_t* perm, int32_t* uniq_cnt,
+                              uint64_t* scratch, int64_t B, int32_t F, void* stream);
 
 /* Per-row gradient of the batch: rowgrad[f, j, :] = sum over unique row j's segment of d_out[b, f*D:(f+1)*D],
  * summed in ascending b (the order aten::embedding_dense_backward uses on the CPU, model/layer.py:140,153).
@@ -537,6 +543,17 @@ int cdc_fill_f32(float* p, float value, int64_t n, void* stream);
 int cdc_fill_f64(double* p, double value, int64_t n, void* stream);
 /* dst[r*ld_dst + c] += src[r*ld_src + c]  (gradient fan-in where a kernel cannot accumulate itself) */
 int cdc_add_inplace(float* dst, int64_t ld_dst, const float* src, int64_t ld_src, int64_t rows, int32_t cols, void* stream);
+/* dst (=|+=) src_0 + src_1 + ... + src_{n-1}, added in list order: the same fan-in from several producers in one launch
+ * (the towers' logit gradients into the gradient of a shared addend, model/layer.py FeaturesLinear under every tower). */
+typedef struct {
+    float* dst; int64_t ld_dst;
+    int64_t rows; int32_t cols;
+    int32_t n;                        /* sources (<= CDC_MAX_GROUPS) */
+    int32_t accumulate;               /* 1: dst += sum, 0: dst = sum */
+    const float* src[CDC_MAX_GROUPS];
+    int64_t ld_src[CDC_MAX_GROUPS];
+} cdc_add_n_args;
+int cdc_add_n(const cdc_add_n_args* a, void* stream);
 /* out[i] = a[i] * b[i % nb]  (STAR: W_d ⊙ W_s, model/star.py:90) ; and its two gradients */
 int cdc_mul_bcast(const float* a, const float* b, float* out, int64_t na, int64_t nb, void* stream);
 int cdc_mul_bcast_bwd(const float* d_out, const float* a, const float* b, float* da, float* db,

@@ -449,3 +449,75 @@ def test_merge_dedupe_equals_sort_dedupe(cuda, n_runs, run_len):
         real = int((uniq[f, :c[f]] >= 0).sum())
         assert torch.equal(rg_a[f, :real], rg_b[f, :real])
         assert bool((rg_b[f, real:] == 7.0).all())                 # padding segment and unused slots stay untouched
+
+
+@pytest.mark.parametrize("B", [300, 4096])
+def test_sort_dedupe_from_raw_ids_with_begin_step(cuda, B):
+    """cdc_embed_sort_dedupe_ids == cdc_embed_index + cdc_embed_sort_dedupe (out-of-range ids sort as -1), and its first
+    launch does cdc_begin_step's work."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    F = 5
+    fd = np.array([7, 1000, 3, 50000, 90], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(fd)[:-1]]).astype(np.int32)
+    R = int(fd.sum())
+    rng = np.random.default_rng(B)
+    ids = np.stack([rng.integers(0, d, size=B) for d in fd], axis=1).astype(np.int32)
+    ids[3, 4] = 10 ** 6                                   # past the table
+    ids[5, 0] = -9                                        # before it
+    d_ids, d_off = torch.from_numpy(ids).to(cuda), torch.from_numpy(offsets).to(cuda)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    step = torch.tensor([41], dtype=torch.int32, device=cuda)
+    acc = torch.full((2,), 3.5, dtype=torch.float64, device=cuda)
+    for fused in (False, True):
+        uniq = torch.full((F, B), -7, dtype=torch.int32, device=cuda)
+        seg = torch.full((F, B + 1), -7, dtype=torch.int32, device=cuda)
+        perm = torch.full((F, B), -7, dtype=torch.int32, device=cuda)
+        cnt = torch.zeros(F, dtype=torch.int32, device=cuda)
+        scratch = torch.empty(2 * F * B, dtype=torch.int64, device=cuda)
+        if fused:
+            L.check(lib.cdc_embed_sort_dedupe_ids(d_ids.data_ptr(), d_off.data_ptr(), R, step.data_ptr(), acc.data_ptr(), 2,
+                                                  uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
+                                                  scratch.data_ptr(), B, F, s), "sort ids")
+        else:
+            idx = torch.empty((B, F), dtype=torch.int32, device=cuda)
+            L.check(lib.cdc_embed_index(d_ids.data_ptr(), d_off.data_ptr(), idx.data_ptr(), None, B, F, R, s), "index")
+            L.check(lib.cdc_embed_sort_dedupe(idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
+                                              scratch.data_ptr(), B, F, s), "sort")
+        c = cnt.cpu().numpy()
+        outs.append((c, [uniq[f, :c[f]].cpu().numpy() for f in range(F)], [seg[f, :c[f] + 1].cpu().numpy() for f in range(F)],
+                     perm.cpu().numpy()))
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+    for f in range(F):
+        assert np.array_equal(a[1][f], b[1][f]) and np.array_equal(a[2][f], b[2][f])
+    assert a[1][4][-1] == -1 and a[1][0][-1] == -1        # the two bad ids
+    assert int(step.item()) == 42 and float(acc.abs().sum()) == 0.0
+
+
+def test_add_n_matches_sequential_adds(cuda):
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    rows, n = 1000, 3
+    torch.manual_seed(3)
+    srcs = [torch.randn(rows, 5, device=cuda) for _ in range(n)]           # column 2 of a wider buffer each
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for accumulate in (0, 1):
+        dst = torch.randn(rows, 4, device=cuda)
+        ref = dst.clone()
+        if accumulate:
+            for t in srcs:
+                ref[:, 1] += t[:, 2]
+        else:
+            ref[:, 1] = srcs[0][:, 2]
+            for t in srcs[1:]:
+                ref[:, 1] += t[:, 2]
+        a = L.AddNArgs()
+        a.dst, a.ld_dst, a.rows, a.cols, a.n, a.accumulate = dst.data_ptr() + 4, 4, rows, 1, n, accumulate
+        for k, t in enumerate(srcs):
+            a.src[k], a.ld_src[k] = t.data_ptr() + 8, 5
+        L.check(lib.cdc_add_n(C.byref(a), s), "add_n")
+        assert torch.equal(dst, ref)
