@@ -429,80 +429,196 @@ extern "C" int cdc_embed_merge_dedupe(const int32_t* idx, int32_t* uniq_row, int
 
 // ------------------------------------------------------------------------------------------------
 // per-row gradient: rowgrad[f, j, :] = sum over the segment of unique row j of d_out[b, f*D:(f+1)*D]
-// Two launches so that skewed fields (a domain column has a handful of rows, each thousands of entries long)
-// do not serialise on dependent random loads: (1) the batch gradient rows are gathered into sorted order
-// (fully parallel random reads), (2) every (row, d) sums its now CONTIGUOUS segment in ascending batch order —
-// the order aten::embedding_dense_backward uses on the CPU.
+// A batch has ~F*B unique rows and nearly all of their segments hold one or two entries; a launch with a wave per row
+// spends its time starting 100 K waves that each wait on three dependent loads.  So:
+//  (1) k_segment_sum_direct: one THREAD per (unique row, 16-byte chunk) adds segments of fewer than SEG_DIRECT entries
+//      straight from d_out through perm, all of a segment's loads in flight together;
+//  (2) k_segment_sum_long: per field a few workgroups list the longer segments and give each a wave (sub-lanes split
+//      segments of >= SEG_SPLIT entries into 64/D contiguous parts) or, from SEG_BLOCK entries on (a domain column: three
+//      rows of a thousand entries each), the whole workgroup (256/D parts).
+// Sums run in ascending batch order inside a segment / part, parts are combined in part order: segments shorter than
+// SEG_SPLIT equal aten::embedding_dense_backward's CPU result to the last bit.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_sorted_gather(const float* __restrict__ d_out, const int32_t* __restrict__ perm,
-                                                       float* __restrict__ sorted, int32_t B, int32_t F, int32_t D) {
-    const int64_t total = (int64_t)F * B * D;
+#define SEG_SPLIT 64
+#define SEG_DIRECT 8
+#define SEG_BLOCK 512
+#define SEG_LONG_BLOCKS 64
+#define SEG_LIST_CAP (CDC_SORT_MAX_ROWS / SEG_LONG_BLOCKS)
+
+// One thread per (unique row, 16-byte chunk): the segment's gradient rows are added straight from d_out through perm in
+// segment order, eight entries' loads in flight per round.  max_len > 0: rows whose segment holds max_len entries or more
+// are left to k_segment_sum_long.  uniq_row != NULL: rows < 0 (the -1 padding of an owner's received lists) are skipped.
+template <int VEC>
+__global__ void __launch_bounds__(256) k_segment_sum_direct(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                                            const int32_t* __restrict__ uniq_row, float* __restrict__ rowgrad,
+                                                            int32_t B, int32_t F, int32_t D, int32_t max_len) {
+    const int chunks = D / VEC;
+    const int64_t total = (int64_t)F * B * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % D);
-        const int64_t pos = i / D;                 // f * B + sorted position
-        const int f = (int)(pos / B);
-        sorted[i] = d_out[((int64_t)perm[pos] * F + f) * D + d];
+        const int c = (int)(i % chunks);
+        const int64_t slot = i / chunks;
+        const int f = (int)(slot / B);
+        const int j = (int)(slot - (int64_t)f * B);
+        if (j >= uniq_cnt[f]) continue;
+        if (uniq_row && uniq_row[slot] < 0) continue;
+        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+        const int32_t* prm = perm + (int64_t)f * B;
+        const int k0 = sst[j], k1 = sst[j + 1];
+        if (max_len > 0 && k1 - k0 >= max_len) continue;
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+        for (int k = k0; k < k1; k += 8) {
+            int p[8];
+            float v[8][VEC];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p[q] = (k + q < k1) ? prm[k + q] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float* src = d_out + ((int64_t)(p[q] >= 0 ? p[q] : 0) * F + f) * D + c * VEC;
+                if (p[q] >= 0) {
+                    if (VEC == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(src);
+                        v[q][0] = t.x; v[q][1] = t.y; v[q][2] = t.z; v[q][3] = t.w;
+                    } else {
+                        v[q][0] = src[0];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (p[q] >= 0) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] = __fadd_rn(acc[e], v[q][e]);
+                }
+        }
+        float* dst = rowgrad + slot * D + c * VEC;
+        if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else dst[0] = acc[0];
     }
 }
-// one wave per unique row: lane = sub * D + d.  Short segments are summed by sub 0 alone in ascending batch order (the CPU
-// order of aten::embedding_dense_backward, so those rows equal torch's to the last bit); segments of >= SEG_SPLIT entries
-// are cut into 64/D contiguous parts summed by the sub-lanes in parallel and combined in part order.
-#define SEG_SPLIT 64
-__global__ void __launch_bounds__(256) k_segment_sum(const float* __restrict__ sorted, const int32_t* __restrict__ seg_start,
-                                                     const int32_t* __restrict__ uniq_cnt, float* __restrict__ rowgrad,
-                                                     int32_t B, int32_t F, int32_t D, int32_t subs) {
-    const int lane = threadIdx.x & 63;
-    const int64_t slot = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (slot >= (int64_t)F * B) return;
-    const int f = (int)(slot / B);
-    const int j = (int)(slot - (int64_t)f * B);
-    if (j >= uniq_cnt[f]) return;
-    const int32_t* sst = seg_start + (int64_t)f * (B + 1);
-    const int k0 = sst[j], len = sst[j + 1] - k0;
-    const float* base = sorted + ((int64_t)f * B + k0) * D;
-    if (subs <= 1) {                                               // general D: lanes stride over d, serial ascending sum
-        for (int d = lane; d < D; d += 64) {
-            float acc = 0.f;
-#pragma unroll 16
-            for (int k = 0; k < len; ++k) acc = __fadd_rn(acc, base[(int64_t)k * D + d]);
-            rowgrad[slot * D + d] = acc;
-        }
-        return;
-    }
-    const int sub = lane / D, d = lane - sub * D;                   // D divides 64: subs = 64 / D lanes per element
-    const bool split = len >= SEG_SPLIT;
-    int begin = 0, end = (sub == 0) ? len : 0;
-    if (split) {
-        const int q = (len + subs - 1) / subs;
-        begin = min(sub * q, len);
-        end = min(begin + q, len);
-    }
+extern "C" int cdc_embed_segment_sum_direct(const float* d_out, const int32_t* seg_start, const int32_t* perm,
+                                            const int32_t* uniq_cnt, const int32_t* uniq_row, float* rowgrad, int64_t B, int32_t F,
+                                            int32_t D, void* stream) {
+    CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && rowgrad, CDC_E_BADARG, "embed_segment_sum_direct: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_segment_sum_direct: bad sizes");
+    const bool vec = (D % 4 == 0) && (((uintptr_t)d_out | (uintptr_t)rowgrad) % 16 == 0);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
+    if (vec)
+        hipLaunchKernelGGL(k_segment_sum_direct<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, seg_start, perm, uniq_cnt, uniq_row,
+                           rowgrad, (int32_t)B, F, D, 0);
+    else
+        hipLaunchKernelGGL(k_segment_sum_direct<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, seg_start, perm, uniq_cnt, uniq_row,
+                           rowgrad, (int32_t)B, F, D, 0);
+    CDC_LAUNCH_CHECK("embed_segment_sum_direct");
+    return 0;
+}
+
+// sum of d_out rows perm[k], k in [begin, end), column d of field f — ascending k, BATCH loads in flight
+template <int BATCH = 16>
+__device__ __forceinline__ float seg_serial_sum(const float* __restrict__ d_out, const int32_t* __restrict__ prm, int begin, int end,
+                                                int F, int D, int f, int d) {
     float acc = 0.f;
-    const float* src = base + (int64_t)begin * D + d;
-#pragma unroll 16
-    for (int k = 0; k < end - begin; ++k) acc = __fadd_rn(acc, src[(int64_t)k * D]);
-    if (split) {
-        float total = __shfl(acc, d, 64);                          // part 0, then the others in order
-        for (int s2 = 1; s2 < subs; ++s2) total = __fadd_rn(total, __shfl(acc, s2 * D + d, 64));
-        acc = total;
+    for (int k = begin; k < end; k += BATCH) {
+        int p[BATCH];
+        float x[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) p[q] = (k + q < end) ? prm[k + q] : -1;
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) x[q] = p[q] >= 0 ? d_out[((int64_t)p[q] * F + f) * D + d] : 0.f;
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q)
+            if (p[q] >= 0) acc = __fadd_rn(acc, x[q]);
     }
-    if (sub == 0) rowgrad[slot * D + d] = acc;
+    return acc;
+}
+__global__ void __launch_bounds__(256) k_segment_sum_long(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                                          const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                                          float* __restrict__ rowgrad, int32_t B, int32_t F, int32_t D, int32_t subs,
+                                                          int32_t min_len) {
+    __shared__ int32_t list[SEG_LIST_CAP];
+    __shared__ int32_t n_list;
+    __shared__ float parts[256];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = uniq_cnt[f];
+    const int32_t* sst = seg_start + (int64_t)f * (B + 1);
+    const int32_t* prm = perm + (int64_t)f * B;
+    if (tid == 0) n_list = 0;
+    __syncthreads();
+    for (int j = blockIdx.y + SEG_LONG_BLOCKS * tid; j < n; j += SEG_LONG_BLOCKS * 256)
+        if (sst[j + 1] - sst[j] >= min_len) list[atomicAdd(&n_list, 1)] = j;       // order is irrelevant: rows are independent
+    __syncthreads();
+    const int count = n_list;
+    if (count == 0) return;
+    const bool block_rows = subs > 1;                                  // whole-workgroup treatment needs D | 64
+    // ---- a wave per listed row -----------------------------------------------------------------
+    for (int i = wave; i < count; i += 4) {
+        const int j = list[i];
+        const int k0 = sst[j], len = sst[j + 1] - k0;
+        if (block_rows && len >= SEG_BLOCK) continue;
+        float* dst = rowgrad + ((int64_t)f * B + j) * D;
+        if (subs <= 1) {                                               // general D: lanes stride over d, serial ascending sum
+            for (int d = lane; d < D; d += 64) dst[d] = seg_serial_sum(d_out, prm + k0, 0, len, F, D, f, d);
+            continue;
+        }
+        const int sub = lane / D, d = lane - sub * D;
+        const bool split = len >= SEG_SPLIT;
+        int begin = 0, end = (sub == 0) ? len : 0;
+        if (split) {
+            const int q = (len + subs - 1) / subs;
+            begin = min(sub * q, len);
+            end = min(begin + q, len);
+        }
+        float acc = seg_serial_sum(d_out, prm + k0, begin, end, F, D, f, d);
+        if (split) {
+            float total = __shfl(acc, d, 64);                          // part 0, then the others in order
+            for (int s2 = 1; s2 < subs; ++s2) total = __fadd_rn(total, __shfl(acc, s2 * D + d, 64));
+            acc = total;
+        }
+        if (sub == 0) dst[d] = acc;
+    }
+    if (!block_rows) return;
+    // ---- the workgroup per very long row: 256 / D parts ------------------------------------------
+    const int P = 256 / D;
+    const int part = tid / D, d = tid - part * D;
+    for (int i = 0; i < count; ++i) {
+        const int j = list[i];
+        const int k0 = sst[j], len = sst[j + 1] - k0;
+        if (len < SEG_BLOCK) continue;                                 // uniform over the workgroup
+        const int q = (len + P - 1) / P;
+        const int begin = min(part * q, len), end = min(begin + q, len);
+        parts[tid] = seg_serial_sum<32>(d_out, prm + k0, begin, end, F, D, f, d);
+        __syncthreads();
+        if (tid < D) {
+            float total = parts[tid];
+            for (int p2 = 1; p2 < P; ++p2) total = __fadd_rn(total, parts[p2 * D + tid]);
+            rowgrad[((int64_t)f * B + j) * D + tid] = total;
+        }
+        __syncthreads();
+    }
 }
 
 extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_start, const int32_t* perm,
                                      const int32_t* uniq_cnt, float* sorted_scratch, float* rowgrad, int64_t B, int32_t F,
                                      int32_t D, void* stream) {
-    CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && sorted_scratch && rowgrad, CDC_E_BADARG, "embed_segment_sum: null pointer");
+    (void)sorted_scratch;                                              // kept in the signature; no sorted copy is made any more
+    CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && rowgrad, CDC_E_BADARG, "embed_segment_sum: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_segment_sum: bad sizes");
-    const int64_t total = (int64_t)F * B * D;
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 32);
-    hipLaunchKernelGGL(k_sorted_gather, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, perm, sorted_scratch, (int32_t)B, F, D);
-    CDC_LAUNCH_CHECK("embed_sorted_gather");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (D % 4 == 0) && (((uintptr_t)d_out | (uintptr_t)rowgrad) % 16 == 0);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
+    if (vec)
+        hipLaunchKernelGGL(k_segment_sum_direct<4>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, nullptr, rowgrad,
+                           (int32_t)B, F, D, SEG_DIRECT);
+    else
+        hipLaunchKernelGGL(k_segment_sum_direct<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, nullptr, rowgrad,
+                           (int32_t)B, F, D, SEG_DIRECT);
+    CDC_LAUNCH_CHECK("embed_segment_sum_direct");
     const int subs = (D <= 64 && 64 % D == 0) ? 64 / D : 1;
-    const int64_t slots = (int64_t)F * B;
-    hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)cdc_ceil_div(slots, 4)), dim3(256), 0, (hipStream_t)stream, sorted_scratch, seg_start,
-                       uniq_cnt, rowgrad, (int32_t)B, F, D, subs);
-    CDC_LAUNCH_CHECK("embed_segment_sum");
+    hipLaunchKernelGGL(k_segment_sum_long, dim3(F, SEG_LONG_BLOCKS), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, rowgrad,
+                       (int32_t)B, F, D, subs, SEG_DIRECT);
+    CDC_LAUNCH_CHECK("embed_segment_sum_long");
     return 0;
 }
 
@@ -894,62 +1010,6 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
     return 0;
 }
 
-
-// Segment sum without the sorted copy, for batches whose segments are known to be short (the owner side of the row-sharded
-// table: at most one entry per sending rank): one thread per (unique row, 16-byte chunk) adds its segment's gradient rows
-// straight from d_out in segment order — the same serial ascending sum cdc_embed_segment_sum forms for segments shorter than
-// SEG_SPLIT, so the two agree to the last bit there.
-template <int VEC>
-__global__ void __launch_bounds__(256) k_segment_sum_direct(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
-                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
-                                                            const int32_t* __restrict__ uniq_row, float* __restrict__ rowgrad,
-                                                            int32_t B, int32_t F, int32_t D) {
-    const int chunks = D / VEC;
-    const int64_t total = (int64_t)F * B * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % chunks);
-        const int64_t slot = i / chunks;
-        const int f = (int)(slot / B);
-        const int j = (int)(slot - (int64_t)f * B);
-        if (j >= uniq_cnt[f]) continue;
-        if (uniq_row && uniq_row[slot] < 0) continue;                  // the padding entries of the row lists: one long segment nobody reads
-        const int32_t* sst = seg_start + (int64_t)f * (B + 1);
-        const int32_t* prm = perm + (int64_t)f * B;
-        const int k0 = sst[j], k1 = sst[j + 1];
-        float acc[VEC];
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-        for (int k = k0; k < k1; ++k) {
-            const float* src = d_out + ((int64_t)prm[k] * F + f) * D + c * VEC;
-            if (VEC == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(src);
-                acc[0] = __fadd_rn(acc[0], v.x); acc[1] = __fadd_rn(acc[1], v.y);
-                acc[2] = __fadd_rn(acc[2], v.z); acc[3] = __fadd_rn(acc[3], v.w);
-            } else {
-                acc[0] = __fadd_rn(acc[0], src[0]);
-            }
-        }
-        float* dst = rowgrad + slot * D + c * VEC;
-        if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        else dst[0] = acc[0];
-    }
-}
-extern "C" int cdc_embed_segment_sum_direct(const float* d_out, const int32_t* seg_start, const int32_t* perm,
-                                            const int32_t* uniq_cnt, const int32_t* uniq_row, float* rowgrad, int64_t B, int32_t F,
-                                            int32_t D, void* stream) {
-    CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && rowgrad, CDC_E_BADARG, "embed_segment_sum_direct: null pointer");
-    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_segment_sum_direct: bad sizes");
-    const bool vec = (D % 4 == 0) && (((uintptr_t)d_out | (uintptr_t)rowgrad) % 16 == 0);
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
-    if (vec)
-        hipLaunchKernelGGL(k_segment_sum_direct<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, seg_start, perm, uniq_cnt, uniq_row,
-                           rowgrad, (int32_t)B, F, D);
-    else
-        hipLaunchKernelGGL(k_segment_sum_direct<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_out, seg_start, perm, uniq_cnt, uniq_row,
-                           rowgrad, (int32_t)B, F, D);
-    CDC_LAUNCH_CHECK("embed_segment_sum_direct");
-    return 0;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Row-sharded table under data parallelism (row r is owned by rank r % n_rank).  The per-field unique rows of the local
