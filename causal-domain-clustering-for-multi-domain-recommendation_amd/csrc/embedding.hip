@@ -336,7 +336,7 @@ static int sort_dedupe_launch(const SortSrc& src, int32_t* uniq_row, int32_t* se
         CDC_LAUNCH_CHECK("embed_sort_dedupe");
         return 0;
     }
-    int chunk = 1024;                                       // about eight runs, each within one workgroup's LDS
+    int chunk = 512;                                        // about eight runs (more workgroups, fewer stages each)
     while (chunk < SORT_CHUNK && (int64_t)chunk * 8 < B) chunk <<= 1;
     const int n_runs = (int)cdc_ceil_div(B, chunk);
     uint64_t* runs = scratch;
@@ -873,6 +873,7 @@ extern "C" int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* un
 
 // step t for the batch's rows: rows are at t-1 after catchup (last[] still holds the older value,
 // which is ignored here); writes last[row] = t.
+template <int VEC>
 __global__ void __launch_bounds__(256) k_lazy_update(const float* __restrict__ rowgrad, const int32_t* __restrict__ uniq_row,
                                                      const int32_t* __restrict__ uniq_cnt, float* __restrict__ w,
                                                      float* __restrict__ m, float* __restrict__ v, int32_t* __restrict__ last,
@@ -882,18 +883,37 @@ __global__ void __launch_bounds__(256) k_lazy_update(const float* __restrict__ r
     const int t = *step_dev;
     float step_size, bc2s;
     step_scalars_at(hp.step_scalars, hp.n_scalars, t, step_size, bc2s);
-    const int64_t total = (int64_t)F * B * D;
+    const int chunks = D / VEC;
+    const int64_t total = (int64_t)F * B * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % D);
-        const int64_t slot = i / D;
+        const int d = (int)(i % chunks) * VEC;
+        const int64_t slot = i / chunks;
         const int f = (int)(slot / B);
         const int j = (int)(slot - (int64_t)f * B);
         if (j >= uniq_cnt[f]) continue;
         const int64_t row = uniq_row[slot];
         if (row < 0) continue;
-        float wv = w[row * D + d], mv = m[row * D + d], vv = v[row * D + d];
-        adam_elem(wv, mv, vv, rowgrad[i], c, step_size, bc2s);
-        w[row * D + d] = wv; m[row * D + d] = mv; v[row * D + d] = vv;
+        const int64_t e0 = row * D + d;
+        float wv[VEC], mv[VEC], vv[VEC], gv[VEC];
+        if (VEC == 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(w + e0), b4 = *reinterpret_cast<const float4*>(m + e0),
+                         c4 = *reinterpret_cast<const float4*>(v + e0), g4 = *reinterpret_cast<const float4*>(rowgrad + slot * D + d);
+            wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
+            mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
+            vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
+            gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+        } else {
+            wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0]; gv[0] = rowgrad[slot * D + d];
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) adam_elem(wv[k], mv[k], vv[k], gv[k], c, step_size, bc2s);
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(w + e0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            *reinterpret_cast<float4*>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+            w[e0] = wv[0]; m[e0] = mv[0]; v[e0] = vv[0];
+        }
         if (d == 0) last[row] = t;
     }
 }
@@ -905,10 +925,15 @@ extern "C" int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_r
     CDC_CHECK_ARG(rowgrad && uniq_row && uniq_cnt && w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0,
                   CDC_E_BADARG, "embed_lazy_update: null pointer");
     CDC_CHECK_ARG(B > 0 && F > 0 && D > 0, CDC_E_BADARG, "embed_lazy_update: bad sizes");
-    const int64_t total = (int64_t)F * B * D;
+    const bool vec = (D % 4 == 0) && ((((uintptr_t)w | (uintptr_t)m | (uintptr_t)v | (uintptr_t)rowgrad) & 15) == 0);
+    const int64_t total = (int64_t)F * B * (vec ? D / 4 : D);
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
-    hipLaunchKernelGGL(k_lazy_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, w, m, v, last, hp,
-                       step_dev, (int32_t)B, F, D);
+    if (vec)
+        hipLaunchKernelGGL(k_lazy_update<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, w, m, v, last, hp,
+                           step_dev, (int32_t)B, F, D);
+    else
+        hipLaunchKernelGGL(k_lazy_update<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rowgrad, uniq_row, uniq_cnt, w, m, v, last, hp,
+                           step_dev, (int32_t)B, F, D);
     CDC_LAUNCH_CHECK("embed_lazy_update");
     return 0;
 }
