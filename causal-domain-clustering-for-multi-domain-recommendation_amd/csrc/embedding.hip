@@ -449,13 +449,13 @@ extern "C" int cdc_embed_merge_dedupe(const int32_t* idx, int32_t* uniq_row, int
 // segment order, eight entries' loads in flight per round.  max_len > 0: rows whose segment holds max_len entries or more
 // are left to k_segment_sum_long.  uniq_row != NULL: rows < 0 (the -1 padding of an owner's received lists) are skipped.
 template <int VEC>
-__global__ void __launch_bounds__(256) k_segment_sum_direct(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
-                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
-                                                            const int32_t* __restrict__ uniq_row, float* __restrict__ rowgrad,
-                                                            int32_t B, int32_t F, int32_t D, int32_t max_len) {
+__device__ __forceinline__ void seg_direct_body(int bid, int nblocks, const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                                const int32_t* __restrict__ uniq_row, float* __restrict__ rowgrad,
+                                                int32_t B, int32_t F, int32_t D, int32_t max_len) {
     const int chunks = D / VEC;
     const int64_t total = (int64_t)F * B * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < total; i += (int64_t)nblocks * blockDim.x) {
         const int c = (int)(i % chunks);
         const int64_t slot = i / chunks;
         const int f = (int)(slot / B);
@@ -498,6 +498,13 @@ __global__ void __launch_bounds__(256) k_segment_sum_direct(const float* __restr
         else dst[0] = acc[0];
     }
 }
+template <int VEC>
+__global__ void __launch_bounds__(256) k_segment_sum_direct(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                                            const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                                            const int32_t* __restrict__ uniq_row, float* __restrict__ rowgrad,
+                                                            int32_t B, int32_t F, int32_t D, int32_t max_len) {
+    seg_direct_body<VEC>(blockIdx.x, gridDim.x, d_out, seg_start, perm, uniq_cnt, uniq_row, rowgrad, B, F, D, max_len);
+}
 extern "C" int cdc_embed_segment_sum_direct(const float* d_out, const int32_t* seg_start, const int32_t* perm,
                                             const int32_t* uniq_cnt, const int32_t* uniq_row, float* rowgrad, int64_t B, int32_t F,
                                             int32_t D, void* stream) {
@@ -533,20 +540,20 @@ __device__ __forceinline__ float seg_serial_sum(const float* __restrict__ d_out,
     }
     return acc;
 }
-__global__ void __launch_bounds__(256) k_segment_sum_long(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
-                                                          const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
-                                                          float* __restrict__ rowgrad, int32_t B, int32_t F, int32_t D, int32_t subs,
-                                                          int32_t min_len) {
+__device__ __forceinline__ void seg_long_body(int f, int by, const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                              const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                              float* __restrict__ rowgrad, int32_t B, int32_t F, int32_t D, int32_t subs,
+                                              int32_t min_len) {
     __shared__ int32_t list[SEG_LIST_CAP];
     __shared__ int32_t n_list;
     __shared__ float parts[256];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = uniq_cnt[f];
     const int32_t* sst = seg_start + (int64_t)f * (B + 1);
     const int32_t* prm = perm + (int64_t)f * B;
     if (tid == 0) n_list = 0;
     __syncthreads();
-    for (int j = blockIdx.y + SEG_LONG_BLOCKS * tid; j < n; j += SEG_LONG_BLOCKS * 256)
+    for (int j = by + SEG_LONG_BLOCKS * tid; j < n; j += SEG_LONG_BLOCKS * 256)
         if (sst[j + 1] - sst[j] >= min_len) list[atomicAdd(&n_list, 1)] = j;       // order is irrelevant: rows are independent
     __syncthreads();
     const int count = n_list;
@@ -599,6 +606,20 @@ __global__ void __launch_bounds__(256) k_segment_sum_long(const float* __restric
     }
 }
 
+// one launch for both: the first F * SEG_LONG_BLOCKS workgroups take the long segments (they start first and the few of
+// them that find work run longest), the others the short ones
+template <int VEC>
+__global__ void __launch_bounds__(256) k_segment_sum(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                                     const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                                     float* __restrict__ rowgrad, int32_t B, int32_t F, int32_t D, int32_t subs) {
+    const int n_long = F * SEG_LONG_BLOCKS;
+    if ((int)blockIdx.x < n_long)
+        seg_long_body(blockIdx.x / SEG_LONG_BLOCKS, blockIdx.x % SEG_LONG_BLOCKS, d_out, seg_start, perm, uniq_cnt, rowgrad, B, F, D, subs,
+                      SEG_DIRECT);
+    else
+        seg_direct_body<VEC>(blockIdx.x - n_long, gridDim.x - n_long, d_out, seg_start, perm, uniq_cnt, nullptr, rowgrad, B, F, D, SEG_DIRECT);
+}
+
 extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_start, const int32_t* perm,
                                      const int32_t* uniq_cnt, float* sorted_scratch, float* rowgrad, int64_t B, int32_t F,
                                      int32_t D, void* stream) {
@@ -607,18 +628,11 @@ extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_star
     CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_segment_sum: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (D % 4 == 0) && (((uintptr_t)d_out | (uintptr_t)rowgrad) % 16 == 0);
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
-    if (vec)
-        hipLaunchKernelGGL(k_segment_sum_direct<4>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, nullptr, rowgrad,
-                           (int32_t)B, F, D, SEG_DIRECT);
-    else
-        hipLaunchKernelGGL(k_segment_sum_direct<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, nullptr, rowgrad,
-                           (int32_t)B, F, D, SEG_DIRECT);
-    CDC_LAUNCH_CHECK("embed_segment_sum_direct");
+    const int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192) + F * SEG_LONG_BLOCKS;
     const int subs = (D <= 64 && 64 % D == 0) ? 64 / D : 1;
-    hipLaunchKernelGGL(k_segment_sum_long, dim3(F, SEG_LONG_BLOCKS), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, rowgrad,
-                       (int32_t)B, F, D, subs, SEG_DIRECT);
-    CDC_LAUNCH_CHECK("embed_segment_sum_long");
+    if (vec) hipLaunchKernelGGL(k_segment_sum<4>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, rowgrad, (int32_t)B, F, D, subs);
+    else     hipLaunchKernelGGL(k_segment_sum<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, rowgrad, (int32_t)B, F, D, subs);
+    CDC_LAUNCH_CHECK("embed_segment_sum");
     return 0;
 }
 
