@@ -313,7 +313,8 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
         roof["valu"] = {"element_steps_per_step": es, "element_steps_per_s": es / (d["ms_per_step"] * 1e-3),
                         "lane_cycles_per_element_step": lane_rate * d["ms_per_step"] * 1e-3 / es,
                         "instruction_floor_lane_cycles": 12.5,
-                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved"}
+                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved; element_steps is the nominal R*D per step "
+                                "(rows looked up since their last flush replay fewer), so the cycles figure is an upper-side estimate"}
     traffic, traffic_src = profiled_traffic(name)
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": traffic,
                  "traffic_source": traffic_src,

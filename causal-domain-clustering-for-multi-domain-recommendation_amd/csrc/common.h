@@ -145,6 +145,50 @@ __device__ __forceinline__ void adam_replay(float (&w)[N], float (&m)[N], float 
         }
     }
 }
+// The same for a whole wave whose lanes may start at different steps: ONE uniform loop from the earliest `from` of the wave
+// (step index and step scalars stay in SGPRs, fetched by scalar loads) with the update predicated on s > from — lanes that
+// start later simply sit out the first rounds.  Every lane of the wave must call this (from >= to: nothing to do): the
+// minimum is taken with shuffles.  Against adam_replay's per-lane loop this saves two vector loads and their address
+// arithmetic per replayed step whenever a wave is not uniform — which is nearly always (a quarter of the rows of a flush
+// slice were looked up since its last flush).
+template <bool FAST, int N>
+__device__ __forceinline__ void adam_replay_wave(float (&w)[N], float (&m)[N], float (&v)[N], int from, int to, const AdamConsts& c,
+                                                 const cdc_adam_hp& hp) {
+    const int last_i = hp.n_scalars - 1;
+    const float ss_conv = hp.step_scalars[2 * last_i];
+    const float bc_conv = FAST ? hp.inv_bc2[last_i] : hp.step_scalars[2 * last_i + 1];
+    int fmin = from < to ? from : to;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(fmin, o, 64);
+        fmin = other < fmin ? other : fmin;
+    }
+    fmin = __builtin_amdgcn_readfirstlane(fmin);
+    for (int s = fmin + 1; s <= to; ++s) {
+        float ss = ss_conv, bc = bc_conv;
+        if (s < last_i) {
+            ss = hp.step_scalars[2 * s];
+            bc = FAST ? hp.inv_bc2[s] : hp.step_scalars[2 * s + 1];
+        }
+        if (s > from) {
+            if constexpr (FAST && N % 2 == 0) {
+#pragma unroll
+                for (int k = 0; k < N; k += 2) {
+                    cdc_f2 w2 = {w[k], w[k + 1]}, m2 = {m[k], m[k + 1]}, v2 = {v[k], v[k + 1]};
+                    adam_elem_fast_pk(w2, m2, v2, c, ss, bc);
+                    w[k] = w2.x; w[k + 1] = w2.y; m[k] = m2.x; m[k + 1] = m2.y; v[k] = v2.x; v[k + 1] = v2.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    if (FAST) adam_elem_fast(w[k], m[k], v[k], c, ss, bc);
+                    else adam_elem(w[k], m[k], v[k], 0.f, c, ss, bc);
+                }
+            }
+        }
+    }
+}
+
 template <bool FAST>
 __device__ __forceinline__ void adam_replay(float& w, float& m, float& v, int from, int to, const AdamConsts& c,
                                             const cdc_adam_hp& hp) {

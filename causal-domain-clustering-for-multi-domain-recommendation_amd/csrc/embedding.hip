@@ -806,28 +806,42 @@ __global__ void __launch_bounds__(256) k_lazy_catchup(const int32_t* __restrict_
     const int target = *step_dev - 1;
     const int chunks = D / VEC;
     const int64_t total = (int64_t)F * B * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int d = (int)(i % chunks) * VEC;
-        const int64_t slot = i / chunks;
-        const int f = (int)(slot / B);
-        const int j = (int)(slot - (int64_t)f * B);
-        if (j >= uniq_cnt[f]) continue;
-        const int64_t row = uniq_row[(int64_t)f * B + j];
-        if (row < 0) continue;                                   // padding entry of an exchanged row list
-        const int from = last[row];
-        if (from >= target) continue;
-        const int64_t e0 = row * D + d;
-        float wv[VEC], mv[VEC], vv[VEC];
-        if (VEC == 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(w + e0), b4 = *reinterpret_cast<const float4*>(m + e0),
-                         c4 = *reinterpret_cast<const float4*>(v + e0);
-            wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
-            mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
-            vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
-        } else {
-            wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0];
+    // uniform trip count and no early exits: every lane of a wave reaches the replay (adam_replay_wave takes a wave minimum)
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        bool act = i < total;
+        int d = 0, from = target;
+        int64_t row = -1;
+        if (act) {
+            d = (int)(i % chunks) * VEC;
+            const int64_t slot = i / chunks;
+            const int f = (int)(slot / B);
+            const int j = (int)(slot - (int64_t)f * B);
+            act = j < uniq_cnt[f];
+            if (act) row = uniq_row[(int64_t)f * B + j];
+            act = act && row >= 0;                               // < 0: padding entry of an exchanged row list
         }
-        adam_replay<FAST, VEC>(wv, mv, vv, from, target, c, hp);
+        if (act) from = last[row];
+        act = act && from < target;
+        if (!act) from = target;
+        if (!__any(act)) continue;                               // wave-uniform
+        const int64_t e0 = act ? row * D + d : 0;
+        float wv[VEC], mv[VEC], vv[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { wv[k] = 0.f; mv[k] = 0.f; vv[k] = 1.f; }
+        if (act) {
+            if (VEC == 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(w + e0), b4 = *reinterpret_cast<const float4*>(m + e0),
+                             c4 = *reinterpret_cast<const float4*>(v + e0);
+                wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
+                mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
+                vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
+            } else {
+                wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0];
+            }
+        }
+        adam_replay_wave<FAST, VEC>(wv, mv, vv, from, target, c, hp);
+        if (!act) continue;
         if (VEC == 4) {
             *reinterpret_cast<float4*>(w + e0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
             *reinterpret_cast<float4*>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
@@ -978,22 +992,31 @@ __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float
     const int64_t n_rows = (row_hi - first + stride - 1) / stride;
     const int chunks = D / VEC;
     const int64_t total = n_rows * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = first + (i / chunks) * stride;
-        const int64_t e0 = row * D + (i % chunks) * VEC;
-        const int from = last[row];
-        if (from >= target) continue;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        bool act = i < total;
+        const int64_t row = act ? first + (i / chunks) * stride : first;
+        const int64_t e0 = row * D + (act ? (i % chunks) * VEC : 0);
+        int from = act ? last[row] : target;
+        act = act && from < target;
+        if (!act) from = target;
+        if (!__any(act)) continue;                               // wave-uniform
         float wv[VEC], mv[VEC], vv[VEC];
-        if (VEC == 4) {
-            const float4 a4 = *reinterpret_cast<const float4*>(w + e0), b4 = *reinterpret_cast<const float4*>(m + e0),
-                         c4 = *reinterpret_cast<const float4*>(v + e0);
-            wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
-            mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
-            vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
-        } else {
-            wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { wv[k] = 0.f; mv[k] = 0.f; vv[k] = 1.f; }
+        if (act) {
+            if (VEC == 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(w + e0), b4 = *reinterpret_cast<const float4*>(m + e0),
+                             c4 = *reinterpret_cast<const float4*>(v + e0);
+                wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
+                mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
+                vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
+            } else {
+                wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0];
+            }
         }
-        adam_replay<FAST, VEC>(wv, mv, vv, from, target, c, hp);
+        adam_replay_wave<FAST, VEC>(wv, mv, vv, from, target, c, hp);
+        if (!act) continue;
         if (VEC == 4) {
             *reinterpret_cast<float4*>(w + e0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
             *reinterpret_cast<float4*>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
