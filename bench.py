@@ -312,9 +312,12 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
         lane_rate = 256 * 64 * 2.4e9                       # fp32 lanes x clock
         roof["valu"] = {"element_steps_per_step": es, "element_steps_per_s": es / (d["ms_per_step"] * 1e-3),
                         "lane_cycles_per_element_step": lane_rate * d["ms_per_step"] * 1e-3 / es,
-                        "instruction_floor_lane_cycles": 12.5,
-                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved; element_steps is the nominal R*D per step "
-                                "(rows looked up since their last flush replay fewer), so the cycles figure is an upper-side estimate"}
+                        "instruction_estimate_lane_cycles": 12.5,
+                        "standalone_lane_cycles": 11.8,
+                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved.  instruction_estimate = 9 packed-fp32 "
+                                "ops at 2 elements per issue + v_sqrt_f32 + v_rcp_f32 counted at quarter rate; standalone = the replay alone "
+                                "on a uniform table (tools/flush_bench.py, 3.34 T element-steps/s).  element_steps is the nominal R*D per "
+                                "step: rows looked up since their last flush replay fewer, so the cycles figure here is on the high side"}
     traffic, traffic_src = profiled_traffic(name)
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": traffic,
                  "traffic_source": traffic_src,
