@@ -45,7 +45,8 @@ class LinFwdArgs(C.Structure):
 
 
 class BwdxSeg(C.Structure):
-    _fields_ = [("dz", c_p), ("lddz", c_i64), ("w", c_p), ("ldw", c_i64), ("wt", c_p), ("ldwt", c_i64), ("N", c_i32), ("out", c_i32)]
+    _fields_ = [("dz", c_p), ("lddz", c_i64), ("w", c_p), ("ldw", c_i64), ("wt", c_p), ("ldwt", c_i64), ("N", c_i32), ("out", c_i32),
+                ("wt_bf16", c_i32)]
 
 
 class BwdxOut(C.Structure):
@@ -63,7 +64,7 @@ class TransposeItem(C.Structure):
 
 
 class TransposeArgs(C.Structure):
-    _fields_ = [("n", c_i32), ("pad_", c_i32), ("t", TransposeItem * MAX_TENSORS)]
+    _fields_ = [("n", c_i32), ("dst_bf16", c_i32), ("t", TransposeItem * MAX_TENSORS)]
 
 
 class BwdwGroup(C.Structure):

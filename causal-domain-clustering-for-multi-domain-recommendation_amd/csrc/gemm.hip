@@ -32,6 +32,7 @@ struct Operand {
     const float* p;
     int64_t s_i, s_r;
     int I, Rn;      // valid extents
+    bool half = false;   // p really points at bf16 elements (strides in elements): a copy its producer already rounded
 };
 
 // ---- staging: global -> registers (fp32) -------------------------------------------------------
@@ -160,7 +161,64 @@ struct LeanStage {
     }
 };
 __device__ __forceinline__ bool lean_ok(const Operand& op) {
-    return op.s_r == 1 && op.I > 0 && ((((uintptr_t)op.p) & 15) == 0) && (op.s_i % 4 == 0);
+    return !op.half && op.s_r == 1 && op.I > 0 && ((((uintptr_t)op.p) & 15) == 0) && (op.s_i % 4 == 0);
+}
+// The same for an operand that already IS bf16 in memory (the per-step W^T copies): 16-byte loads of eight elements, half
+// the bytes from L2 and no conversion in the loop — the bits are those the fp32 path's convert would have produced.
+template <int ROWS, int BK>
+struct LeanStageH {
+    static constexpr int TPR = BK / 8;                    // threads per tile row
+    static constexpr int RSTEP = GEMM_THREADS / TPR;      // tile rows per pass
+    static constexpr int PER = (ROWS * BK / 8 + GEMM_THREADS - 1) / GEMM_THREADS;
+    bf16x8_t v[PER];
+    const __bf16* ptr[PER];
+
+    __device__ __forceinline__ void init(const Operand& op, int i0, int tid) {
+        const int r = (tid % TPR) * 8, i = tid / TPR;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int gi = i0 + i + p * RSTEP;
+            gi = gi < op.I ? gi : op.I - 1;
+            ptr[p] = reinterpret_cast<const __bf16*>(op.p) + (int64_t)gi * op.s_i + r;
+        }
+    }
+    __device__ __forceinline__ void load_full() {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            v[p] = *reinterpret_cast<const bf16x8_t*>(ptr[p]);
+            ptr[p] += BK;
+        }
+    }
+    __device__ __forceinline__ void stride2() {}
+    __device__ __forceinline__ void load2() {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            v[p] = *reinterpret_cast<const bf16x8_t*>(ptr[p]);
+            ptr[p] += 2 * BK;
+        }
+    }
+    __device__ __forceinline__ void load_tail(int r0, int Rn, int tid) {
+        const int r = r0 + (tid % TPR) * 8;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            bf16x8_t val;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) val[q] = (r + q < Rn) ? ptr[p][q] : (__bf16)0.f;
+            v[p] = val;
+        }
+    }
+    template <typename T>
+    __device__ __forceinline__ void store(T* lds, int stride, int tid) const {
+        static_assert(sizeof(T) == 2, "a bf16 operand feeds the bf16 MFMA path only");
+        const int r = (tid % TPR) * 8, i = tid / TPR;
+#pragma unroll
+        for (int p = 0; p < PER; ++p)
+            if (ROWS * BK / 8 >= GEMM_THREADS || i + p * RSTEP < ROWS)
+                *reinterpret_cast<bf16x8_t*>(lds + (i + p * RSTEP) * stride + r) = v[p];
+    }
+};
+__device__ __forceinline__ bool lean_ok_h(const Operand& op) {
+    return op.half && op.s_r == 1 && op.I > 0 && ((((uintptr_t)op.p) & 15) == 0) && (op.s_i % 8 == 0);
 }
 
 // ---- one K-slab of MFMAs for this wave ------------------------------------------------------------
@@ -200,6 +258,64 @@ __device__ __forceinline__ void mma_slab(const typename LdsElem<BF16, BK>::type*
     }
 }
 
+// ---- the lean loop with a B operand that is bf16 in memory (the host side guarantees lean_ok(A) and lean_ok_h(B)) ----
+template <int BM, int BN, int DEPTH>
+__device__ __forceinline__ void gemm_accumulate_half_b(const Operand& A, const Operand& B, int i0, int j0, unsigned char* smem,
+                                                       f32x4_t (&acc)[BM / 32][BN / 32]) {
+    constexpr int BK = GEMM_BK;
+    typedef __bf16 T;
+    constexpr int S = LdsElem<true, BK>::stride;
+    T* As = reinterpret_cast<T*>(smem);
+    T* Bs = As + BM * S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int nk = (A.Rn + BK - 1) / BK;
+    const int nfull = A.Rn / BK;
+    if constexpr (DEPTH == 2) {
+        if (nfull == nk && nk >= 2) {
+            LeanStage<BM, BK> a0, a1;
+            LeanStageH<BN, BK> b0, b1;
+            a0.init(A, i0, tid); b0.init(B, j0, tid);
+            a1 = a0; b1 = b0;
+#pragma unroll
+            for (int p = 0; p < LeanStage<BM, BK>::PER; ++p) a1.ptr[p] += BK;
+#pragma unroll
+            for (int p = 0; p < LeanStageH<BN, BK>::PER; ++p) b1.ptr[p] += BK;
+            a0.load2(); b0.load2(); a1.load2(); b1.load2();
+            for (int kt = 0; kt < nk; kt += 2) {
+                a0.store(As, S, tid); b0.store(Bs, S, tid);
+                __syncthreads();
+                if (kt + 2 < nk) { a0.load2(); b0.load2(); }
+                mma_slab<true, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
+                __syncthreads();
+                if (kt + 1 < nk) {
+                    a1.store(As, S, tid); b1.store(Bs, S, tid);
+                    __syncthreads();
+                    if (kt + 3 < nk) { a1.load2(); b1.load2(); }
+                    mma_slab<true, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
+                    __syncthreads();
+                }
+            }
+            return;
+        }
+    }
+    LeanStage<BM, BK> la;
+    LeanStageH<BN, BK> lb;
+    la.init(A, i0, tid);
+    lb.init(B, j0, tid);
+    if (nfull > 0) { la.load_full(); lb.load_full(); }
+    else if (nk > 0) { la.load_tail(0, A.Rn, tid); lb.load_tail(0, A.Rn, tid); }
+    for (int kt = 0; kt < nk; ++kt) {
+        la.store(As, S, tid);
+        lb.store(Bs, S, tid);
+        __syncthreads();
+        if (kt + 1 < nfull) { la.load_full(); lb.load_full(); }
+        else if (kt + 1 < nk) { la.load_tail((kt + 1) * BK, A.Rn, tid); lb.load_tail((kt + 1) * BK, A.Rn, tid); }
+        mma_slab<true, BM / 32, BN / 32, BK>(As, Bs, wm, wn, lane, acc);
+        __syncthreads();
+    }
+}
+
 // ---- accumulate A(i,r)·B(j,r) over r for one (A,B) operand pair into acc ---------------------------
 template <bool BF16, int BM, int BN, bool A_RC, bool B_RC, bool COLSUM, int DEPTH = 1>
 __device__ __forceinline__ void gemm_accumulate(const Operand& A, const Operand& B, int i0, int j0, unsigned char* smem,
@@ -213,6 +329,12 @@ __device__ __forceinline__ void gemm_accumulate(const Operand& A, const Operand&
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
     const int nk = (A.Rn + BK - 1) / BK;
     if constexpr (A_RC && B_RC && !COLSUM) {
+        if constexpr (BF16) {
+            if (B.half) {                                  // uniform over the workgroup; eligibility checked by the launcher
+                gemm_accumulate_half_b<BM, BN, DEPTH>(A, B, i0, j0, smem, acc);
+                return;
+            }
+        }
         if (lean_ok(A) && lean_ok(B)) {                    // uniform over the workgroup
             const int nfull = A.Rn / BK;
             if constexpr (DEPTH == 2) {
@@ -434,12 +556,12 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bw
     unsigned long long todo;
     uint64_t v_dz, v_w;
     int64_t v_lddz, v_ldw;
-    int v_n;
+    int v_n, v_half;
     {
         const int l = threadIdx.x & 63;
         const bool has = l < a.n_seg;
         const cdc_bwdx_seg& L = a.s[has ? l : 0];
-        v_dz = (uint64_t)L.dz; v_lddz = L.lddz; v_n = L.N;
+        v_dz = (uint64_t)L.dz; v_lddz = L.lddz; v_n = L.N; v_half = L.wt_bf16;
         v_w = WT ? (uint64_t)L.wt : (uint64_t)L.w;
         v_ldw = WT ? L.ldwt : L.ldw;
         todo = __ballot(has && L.out == o);
@@ -457,6 +579,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bw
         Operand A{dz + (int64_t)row_lo * lddz, lddz, 1, M, N};           // (i=row, r=n)  r contiguous
         if (WT) {
             Operand B{wp, ldw, 1, O.K, N};                                // W^T [K,N]: (j=k, r=n)  r contiguous
+            B.half = __builtin_amdgcn_readlane(v_half, s) != 0;          // ... stored as bf16 by cdc_transpose_multi
             gemm_accumulate<BF16, BM, BN, true, true, false, DEPTH>(A, B, i0, j0, smem, acc, nullptr);
         } else {
             Operand B{wp, 1, ldw, O.K, N};                                // W [N,K]:   (j=k, r=n)  j contiguous
@@ -875,7 +998,12 @@ extern "C" int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void*
                       CDC_E_BADARG, "glinear_bwd_x: segment %d malformed", s);
         CDC_CHECK_ARG(!S.wt || S.ldwt >= S.N, CDC_E_BADARG, "glinear_bwd_x: segment %d transposed copy malformed", s);
         all_wt = all_wt && S.wt != nullptr;
+        if (S.wt_bf16)
+            CDC_CHECK_ARG(prec == CDC_PREC_BF16 && S.wt && S.ldwt % 8 == 0 && (((uintptr_t)S.wt | (uintptr_t)S.dz) & 15) == 0 &&
+                              S.lddz % 4 == 0, CDC_E_BADARG, "glinear_bwd_x: segment %d: bf16 transposed copy not eligible", s);
     }
+    for (int s = 0; s < a->n_seg; ++s)
+        CDC_CHECK_ARG(!a->s[s].wt_bf16 || all_wt, CDC_E_BADARG, "glinear_bwd_x: bf16 transposed copies need every segment transposed");
     if (t64 == 0) return 0;
     const bool big = pick_big_tiles(t64);
     const int64_t grid = big ? t128 : t64;
@@ -904,7 +1032,10 @@ __global__ void __launch_bounds__(256) k_transpose_multi(const cdc_transpose_arg
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
         const int c = c0 + k, r = r0 + tx;
-        if (c < cols && r < rows) a.t[ti].dst[(int64_t)c * rows + r] = tile[tx][k];
+        if (c < cols && r < rows) {
+            if (a.dst_bf16) reinterpret_cast<__bf16*>(a.t[ti].dst)[(int64_t)c * rows + r] = (__bf16)tile[tx][k];
+            else a.t[ti].dst[(int64_t)c * rows + r] = tile[tx][k];
+        }
     }
 }
 extern "C" int cdc_transpose_multi(const cdc_transpose_args* a, void* stream) {

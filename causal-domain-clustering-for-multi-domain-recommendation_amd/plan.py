@@ -16,6 +16,7 @@ Gradient conventions
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -236,25 +237,30 @@ class Plan:
     def need_bn_ws(self, rows, total_c):
         self._bn_ws_need = max(self._bn_ws_need, 2 * math.ceil(rows / L.BN_ROWS_PER_BLOCK) * total_c)
 
-    def wt_of(self, w):
+    def wt_of(self, w, half=False):
         """per-step transposed copy [K,N] of a linear weight [N,K]: grad-input then streams both operands with the
-        reduction index contiguous (no transposing LDS stores)"""
+        reduction index contiguous (no transposing LDS stores).  half: the copy is written as bf16 (what the bf16 MFMA
+        path would round the fp32 copy to while staging it) — half the operand bytes, no conversion in the loop."""
         key = (id(w.param), w.index) if isinstance(w, PView) else (id(w.tensor) if isinstance(w, TView) else id(w))
+        key = (key, bool(half))
         hit = self._wt.get(key)
         if hit is None:
             N, K = w.shape
-            hit = (w, torch.empty((K, N), dtype=torch.float32, device=self.device))
+            hit = (w, torch.empty((K, N), dtype=torch.bfloat16 if half else torch.float32, device=self.device), bool(half))
             self._wt[key] = hit
         return hit[1]
 
     def _emit_transposes(self):
-        items = list(self._wt.values())
         steps = []
-        for c0 in range(0, len(items), L.MAX_TENSORS):
+        launches = []
+        for half in (False, True):
+            items = [it for it in self._wt.values() if it[2] == half]
+            launches += [(half, items[c0:c0 + L.MAX_TENSORS]) for c0 in range(0, len(items), L.MAX_TENSORS)]
+        for half, chunk in launches:
             a = L.TransposeArgs()
-            chunk = items[c0:c0 + L.MAX_TENSORS]
             a.n = len(chunk)
-            for i, (w, wt) in enumerate(chunk):
+            a.dst_bf16 = 1 if half else 0
+            for i, (w, wt, _) in enumerate(chunk):
                 a.t[i].src, a.t[i].dst = w.data_ptr(), wt.data_ptr()
                 a.t[i].rows, a.t[i].cols = w.shape[0], w.shape[1]
             self._keep_args = getattr(self, "_keep_args", []) + [a]
@@ -576,8 +582,11 @@ class GLinear:
                     dz = g["y"].grad
                     S.dz, S.lddz = dz.ptr, dz.ld
                     S.w, S.ldw = g["w"].data_ptr(), g["w"].shape[1]
-                    wt = plan.wt_of(g["w"])
+                    half = (plan.prec == L.PREC_BF16 and g["w"].shape[0] % 8 == 0 and dz.ptr % 16 == 0 and dz.ld % 4 == 0 and
+                            os.environ.get("CDC_WT_BF16", "1") != "0")
+                    wt = plan.wt_of(g["w"], half=half)
                     S.wt, S.ldwt = wt.data_ptr(), g["w"].shape[0]
+                    S.wt_bf16 = 1 if half else 0
                     S.N = g["w"].shape[0]
                     S.out = oi
                     si += 1
