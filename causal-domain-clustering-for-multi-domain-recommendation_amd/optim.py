@@ -112,7 +112,6 @@ class FusedAdam:
                   "perm": torch.empty((F, B), dtype=torch.int32, device=dev),
                   "cnt": torch.zeros((F,), dtype=torch.int32, device=dev),
                   "scratch": torch.empty((2 * F * B,), dtype=torch.int64, device=dev) if B > 1024 else None,
-                  "sorted": torch.empty((F * B * D,), dtype=torch.float32, device=dev),
                   "rowgrad": torch.empty((F * B * D,), dtype=torch.float32, device=dev),
                   "side": torch.empty((F * B * 3 * D,), dtype=torch.float32, device=dev) if self.table_mode == "dense" else None}
             self._ws[key] = ws
@@ -223,7 +222,7 @@ class FusedAdam:
                       ws["rowgrad"].data_ptr(), B, F, D), s)
             return
         L.launch("cdc_embed_segment_sum", self.lib.cdc_embed_segment_sum,
-                 (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["sorted"].data_ptr(),
+                 (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), None,
                   ws["rowgrad"].data_ptr(), B, F, D), s)
 
     def flush_table(self):

@@ -85,8 +85,10 @@ int cdc_embed_sort_dedupe_ids(const int32_t* ids, const int32_t* offsets, int64_
                               uint64_t* scratch, int64_t B, int32_t F, void* stream);
 
 /* Per-row gradient of the batch: rowgrad[f, j, :] = sum over unique row j's segment of d_out[b, f*D:(f+1)*D],
- * summed in ascending b (the order aten::embedding_dense_backward uses on the CPU, model/layer.py:140,153).
- * sorted_scratch and rowgrad are [F, B, D] floats. */
+ * summed in ascending b (the order aten::embedding_dense_backward uses on the CPU, model/layer.py:140,153) for segments
+ * shorter than 64 entries; longer ones are cut into 64/D (from 512 entries on: 256/D) contiguous parts that are summed in
+ * ascending b and combined in part order.  rowgrad is [F, B, D] floats.  sorted_scratch is no longer used (the sums read
+ * d_out through perm) and may be NULL; the parameter stays for ABI stability. */
 int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
                           float* sorted_scratch, float* rowgrad, int64_t B, int32_t F, int32_t D, void* stream);
 /* The same sums without the sorted copy, for batches whose segments are short (the owner side of the row-sharded table:
