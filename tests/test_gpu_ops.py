@@ -521,3 +521,51 @@ def test_add_n_matches_sequential_adds(cuda):
             a.src[k], a.ld_src[k] = t.data_ptr() + 8, 5
         L.check(lib.cdc_add_n(C.byref(a), s), "add_n")
         assert torch.equal(dst, ref)
+
+
+@pytest.mark.parametrize("D", [3, 4, 16, 32, 64, 96, 128])
+def test_segment_sum_every_length_class(cuda, D):
+    """cdc_embed_segment_sum over segments of every class the launch distinguishes (thread per chunk below 8 entries, a wave per
+    row from 8 on — split into sub-lane parts from 64 on when D divides 64 — the whole workgroup from 512 on): segments
+    shorter than 64 equal the sequential fp32 sum in ascending batch order to the last bit, longer ones to fp32 rounding."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    lens = [1, 2, 7, 8, 9, 63, 64, 65, 200, 511, 512, 513, 1500]
+    F = 2
+    rows0 = np.repeat(np.arange(len(lens)), lens)                    # field 0: one row per length class
+    B = len(rows0)
+    rng = np.random.default_rng(D)
+    perm0 = rng.permutation(B)
+    idx = np.empty((B, F), dtype=np.int32)
+    idx[:, 0] = rows0[perm0] * 3 + 5
+    idx[:, 1] = rng.integers(0, 50, size=B) + 10_000                 # field 1: many medium segments
+    g = rng.standard_normal((B, F * D)).astype(np.float32)
+    d_idx, d_g = torch.from_numpy(idx).to(cuda), torch.from_numpy(g).to(cuda)
+    uniq = torch.empty((F, B), dtype=torch.int32, device=cuda)
+    seg = torch.empty((F, B + 1), dtype=torch.int32, device=cuda)
+    perm = torch.empty((F, B), dtype=torch.int32, device=cuda)
+    cnt = torch.zeros(F, dtype=torch.int32, device=cuda)
+    scratch = torch.empty(2 * F * B, dtype=torch.int64, device=cuda)
+    rg = torch.full((F, B, D), 7.0, dtype=torch.float32, device=cuda)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.cdc_embed_sort_dedupe(d_idx.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
+                                      scratch.data_ptr(), B, F, s), "sort")
+    L.check(lib.cdc_embed_segment_sum(d_g.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(), None, rg.data_ptr(), B, F, D, s),
+            "segment_sum")
+    c = cnt.cpu().numpy()
+    u, out = uniq.cpu().numpy(), rg.cpu().numpy()
+    for f in range(F):
+        assert c[f] == len(np.unique(idx[:, f]))
+        for j in range(c[f]):
+            rows = np.nonzero(idx[:, f] == u[f, j])[0]               # ascending batch order
+            vals = g[rows, f * D:(f + 1) * D]
+            if len(rows) < 64:
+                acc = np.zeros(D, dtype=np.float32)
+                for v in vals:
+                    acc = (acc + v).astype(np.float32)
+                assert np.array_equal(out[f, j], acc), (f, j, len(rows))
+            else:
+                ref = vals.astype(np.float64).sum(0)
+                assert np.allclose(out[f, j], ref, rtol=2e-5, atol=2e-5 * np.sqrt(len(rows))), (f, j, len(rows))
+        assert (out[f, c[f]:] == 7.0).all()                          # slots past the unique rows stay untouched
