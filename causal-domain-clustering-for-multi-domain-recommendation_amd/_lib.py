@@ -36,7 +36,8 @@ class AdamHP(C.Structure):
 
 class LinGroup(C.Structure):
     _fields_ = [("x", c_p), ("ldx", c_i64), ("w", c_p), ("ldw", c_i64), ("bias", c_p),
-                ("y", c_p), ("ldy", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("act_cols", c_i32)]
+                ("y", c_p), ("ldy", c_i64), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("act_cols", c_i32),
+                ("bn_partial", c_p), ("bn_col0", c_i32), ("bn_total_c", c_i32)]
 
 
 class LinFwdArgs(C.Structure):
@@ -107,7 +108,7 @@ class BnSeg(C.Structure):
 class BnFwdArgs(C.Structure):
     _fields_ = [("n_seg", c_i32), ("training", c_i32), ("relu", c_i32), ("skip_le1", c_i32), ("eps", c_f), ("momentum", c_f),
                 ("drop_p", c_f), ("seed", C.c_uint64), ("seed_offset_dev", c_p), ("M", c_i64),
-                ("row_offsets", c_p), ("workspace", c_p), ("phase", c_i32), ("pad_", c_i32), ("exchange", c_p),
+                ("row_offsets", c_p), ("workspace", c_p), ("phase", c_i32), ("stats_ready", c_i32), ("exchange", c_p),
                 ("s", BnSeg * MAX_BN_SEGS)]
 
 

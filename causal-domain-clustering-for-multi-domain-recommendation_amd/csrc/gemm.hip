@@ -491,6 +491,37 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_
         float* ct = reinterpret_cast<float*>(smem);                      // the operand staging area is free after the last barrier
         OT::put(ct, acc, wm, wn, lane);
         __syncthreads();
+        if (G.bn_partial) {                                               // uniform over the workgroup
+            // the statistics pass of the BatchNorm that normalises y next: per (64-row block, column) sums of y and y^2 in
+            // double, written where k_bn_stats would put them (block index = row / CDC_BN_ROWS_PER_BLOCK).  Wave q takes rows
+            // 16q..16q+15 of a block, lane = column; the four quarter sums are added in order by wave 0.
+            static_assert(CDC_BN_ROWS_PER_BLOCK == 64 && BM % 64 == 0 && BN % 64 == 0, "partial-sum blocks are 64 rows");
+            __shared__ double quarter[4][64][2];
+#pragma unroll
+            for (int cc = 0; cc < BN / 64; ++cc) {
+                const int col = j0 + cc * 64 + lane;
+                const float bv = (col < G.N && G.bias) ? G.bias[col] : 0.f;
+#pragma unroll
+                for (int h = 0; h < BM / 64; ++h) {
+                    const int r_lo = i0 + h * 64;
+                    if (r_lo >= M) break;                                 // uniform
+                    const int rows = min(64, M - r_lo);
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int r = wave * 16; r < min(wave * 16 + 16, rows); ++r) {
+                        const double x = (double)(ct[(h * 64 + r) * OT::CS + cc * 64 + lane] + bv);
+                        s1 += x; s2 += x * x;
+                    }
+                    quarter[wave][lane][0] = s1; quarter[wave][lane][1] = s2;
+                    __syncthreads();
+                    if (wave == 0 && col < G.N) {
+                        double* ws = G.bn_partial + ((int64_t)(r_lo / 64) * G.bn_total_c + G.bn_col0 + col) * 2;
+                        ws[0] = ((quarter[0][lane][0] + quarter[1][lane][0]) + quarter[2][lane][0]) + quarter[3][lane][0];
+                        ws[1] = ((quarter[0][lane][1] + quarter[1][lane][1]) + quarter[2][lane][1]) + quarter[3][lane][1];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
         const bool vec = ((((uintptr_t)y) & 15) == 0) && (G.ldy % 4 == 0);
 #pragma unroll
         for (int p = 0; p < OT::PER; ++p) {
@@ -944,15 +975,21 @@ extern "C" int cdc_glinear_fwd(const cdc_lin_fwd_args* a, int32_t prec, void* st
     CDC_CHECK_ARG(prec == CDC_PREC_BF16 || prec == CDC_PREC_F32, CDC_E_BADARG, "glinear_fwd: bad precision");
     CDC_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f, CDC_E_BADARG, "glinear_fwd: dropout p out of range");
     int64_t t64 = 0, t128 = 0;
+    bool fused_bn = false;
     for (int g = 0; g < a->n_groups; ++g) {
         const cdc_lin_group& G = a->g[g];
         CDC_CHECK_ARG(G.x && G.w && G.y && G.M >= 0 && G.N > 0 && G.K > 0 && G.ldx >= G.K && G.ldw >= G.K && G.ldy >= G.N,
                       CDC_E_BADARG, "glinear_fwd: group %d malformed (M=%d N=%d K=%d)", g, G.M, G.N, G.K);
         t64 += cdc_ceil_div(G.M, 64) * cdc_ceil_div(G.N, 64);
         t128 += cdc_ceil_div(G.M, 128) * cdc_ceil_div(G.N, 128);
+        if (G.bn_partial) {
+            CDC_CHECK_ARG(G.act_cols == 0 && !a->row_offsets && G.bn_col0 >= 0 && G.bn_col0 + G.N <= G.bn_total_c, CDC_E_BADARG,
+                          "glinear_fwd: group %d cannot feed BatchNorm partial sums (activation, ragged rows or bad columns)", g);
+            fused_bn = true;
+        }
     }
     if (t64 == 0) return 0;
-    const bool big = pick_big_tiles(t64);
+    const bool big = !fused_bn && pick_big_tiles(t64);       // the partial sums are written by the LDS-staged 64x64 epilogue
     const int64_t grid = big ? t128 : t64;
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "glinear_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;

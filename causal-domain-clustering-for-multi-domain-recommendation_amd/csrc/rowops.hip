@@ -416,7 +416,7 @@ extern "C" int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream) {
     const int n_chunks = (int)cdc_ceil_div(a->M, CDC_BN_ROWS_PER_BLOCK);
     const int64_t grid = (int64_t)col_tiles * n_chunks;
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "bn_fwd: grid too large");
-    if (a->training && a->phase != 2) {
+    if (a->training && a->phase != 2 && !a->stats_ready) {
         hipLaunchKernelGGL(k_bn_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
         CDC_LAUNCH_CHECK("bn_stats");
     }

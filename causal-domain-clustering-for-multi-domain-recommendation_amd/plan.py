@@ -178,6 +178,8 @@ class Plan:
         self._rowdot_ws_need = 0
         self._gemm_ws = None
         self._gemm_ws_need = 0
+        self._lin_producer = {}           # linear output (root, col0, cols) -> its launch group (BatchNorm statistics fusion)
+        self._last_bn_step = 0
         self._wt = {}                     # weight key -> (weight object, transposed copy [K,N]) refreshed at the start of backward
         self._deferred_dw = []            # grad-weight groups of every layer, launched together at the end of backward
         self.finalized = False
@@ -464,6 +466,10 @@ class GLinear:
                 G.y, G.ldy = g["y"].ptr, g["y"].ld
                 G.M, G.N, G.K = self.M, N, K
                 G.act_cols = g["act_cols"]
+                G.bn_partial = None
+                # a BatchNorm that normalises this output next may ask the epilogue for its partial sums (BatchNorm.build_fwd)
+                y = g["y"]
+                plan._lin_producer[(id(y.root), y.col0, y.cols)] = {"op": self, "G": G, "step": len(plan.fwd_steps), "taken": False}
             self._keep = getattr(self, "_keep", []) + [a]
             fl = sum(2.0 * self.M * g["w"].shape[0] * g["w"].shape[1] for g in chunk)
             plan.fwd_steps.append(plan.call("cdc_glinear_fwd", C.byref(a), plan.prec, flops=fl))
@@ -718,6 +724,7 @@ class BatchNorm:
                 S.num_batches_tracked = None if nbt is None else nbt.data_ptr()
                 S.C = s["x"].cols
                 S.row_group = s.get("row_group", 0)
+            self._fuse_stats(plan, a, chunk)
             self._keep.append(a)
             if plan.dist is not None and plan.training:
                 # global-batch statistics: partial sums -> all-reduce -> normalise
@@ -732,6 +739,30 @@ class BatchNorm:
                 plan.fwd_steps.append(plan.call("cdc_bn_fwd", C.byref(a2), what="cdc_bn_fwd(apply)"))
             else:
                 plan.fwd_steps.append(plan.call("cdc_bn_fwd", C.byref(a)))
+            plan._last_bn_step = len(plan.fwd_steps)
+
+    def _fuse_stats(self, plan, a, chunk):
+        """If every segment of this launch normalises the output of a plain linear launch (no activation, same rows, no
+        BatchNorm launch in between — the partial-sum workspace is shared), those launches' epilogues write the partial
+        sums and this launch skips its statistics pass (one read of the activations less per BatchNorm)."""
+        a.stats_ready = 0
+        if not plan.training or self.row_offsets is not None or os.environ.get("CDC_BN_FUSE", "1") == "0":
+            return
+        prods = []
+        for s in chunk:
+            x = s["x"]
+            p = plan._lin_producer.get((id(x.root), x.col0, x.cols))
+            if (p is None or p["taken"] or p["op"].row_offsets is not None or p["op"].M != self.M or p["G"].act_cols != 0 or
+                    p["step"] < plan._last_bn_step):
+                return
+            prods.append(p)
+        total_c = sum(s["x"].cols for s in chunk)
+        col0 = 0
+        for s, p in zip(chunk, prods):
+            p["taken"] = True
+            p["G"].bn_partial, p["G"].bn_col0, p["G"].bn_total_c = plan._bn_ws.data_ptr(), col0, total_c
+            col0 += s["x"].cols
+        a.stats_ready = 1
 
     def build_bwd(self, plan, gs):
         # segments that normalise the SAME input over the same rows (STAR all-towers: every domain_norm reads the

@@ -190,6 +190,11 @@ typedef struct {
     float* y;        int64_t ldy;    /* [M,N] */
     int32_t M, N, K;
     int32_t act_cols;                /* columns [0,act_cols) get relu (+dropout) in the epilogue */
+    double* bn_partial;              /* NULL, or the workspace of the cdc_bn_fwd launch that normalises y next: the epilogue
+                                        also writes that launch's per-(64-row block, column) partial sums of y and y^2
+                                        (its statistics pass, saved: cdc_bn_fwd_args.stats_ready).  Needs act_cols == 0,
+                                        no row_offsets, CDC_PREC_BF16 or F32 with 64x64 tiles (forced when set). */
+    int32_t bn_col0, bn_total_c;     /* y's first column among that launch's columns; its column total */
 } cdc_lin_group;
 
 typedef struct {
@@ -337,7 +342,8 @@ typedef struct {
     int32_t phase;                    /* 0: statistics + normalisation in one call.  Data parallel (global-batch statistics, as
                                          the reference's single process sees them): 1 = statistics only -> `exchange`;
                                          the caller all-reduces (SUM) `exchange` across ranks; 2 = normalise from `exchange` */
-    int32_t pad_;
+    int32_t stats_ready;              /* 1: the partial sums are already in `workspace` (written by the cdc_glinear_fwd epilogues
+                                         that produced every segment's x, see cdc_lin_group.bn_partial): no statistics pass */
     double* exchange;                 /* phases 1/2: [2*sum(C) column sums (x, x^2) | n_seg row counts] doubles */
     cdc_bn_seg s[CDC_MAX_BN_SEGS];
 } cdc_bn_fwd_args;
