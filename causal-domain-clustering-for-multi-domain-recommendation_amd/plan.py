@@ -287,7 +287,7 @@ class Plan:
             a.n_groups = len(chunk)
             tiles = sum(math.ceil(g["N"] / 64) * math.ceil(g["K"] / 64) for g in chunk)
             Mmax = max(g["M"] for g in chunk)
-            S = max(1, min(1536 // max(tiles, 1), max(Mmax // 128, 1), 64))
+            S = max(1, min(1024 // max(tiles, 1), max(Mmax // 128, 1), 64))       # 1024: measured best of 384…2560 at C2
             a.split_k = S
             if S > 1:
                 self.need_gemm_ws(S * sum(g["N"] * g["K"] + g["N"] for g in chunk))
