@@ -65,7 +65,7 @@ class TransposeItem(C.Structure):
 
 
 class TransposeArgs(C.Structure):
-    _fields_ = [("n", c_i32), ("dst_bf16", c_i32), ("t", TransposeItem * MAX_TENSORS)]
+    _fields_ = [("n", c_i32), ("pad_", c_i32), ("bf16_mask", C.c_uint64), ("t", TransposeItem * MAX_TENSORS)]
 
 
 class BwdwGroup(C.Structure):

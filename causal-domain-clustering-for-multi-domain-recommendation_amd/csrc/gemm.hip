@@ -1070,7 +1070,7 @@ __global__ void __launch_bounds__(256) k_transpose_multi(const cdc_transpose_arg
     for (int k = ty; k < 32; k += 8) {
         const int c = c0 + k, r = r0 + tx;
         if (c < cols && r < rows) {
-            if (a.dst_bf16) reinterpret_cast<__bf16*>(a.t[ti].dst)[(int64_t)c * rows + r] = (__bf16)tile[tx][k];
+            if ((a.bf16_mask >> ti) & 1ull) reinterpret_cast<__bf16*>(a.t[ti].dst)[(int64_t)c * rows + r] = (__bf16)tile[tx][k];
             else a.t[ti].dst[(int64_t)c * rows + r] = tile[tx][k];
         }
     }

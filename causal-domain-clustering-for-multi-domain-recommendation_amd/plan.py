@@ -254,17 +254,18 @@ class Plan:
 
     def _emit_transposes(self):
         steps = []
-        launches = []
-        for half in (False, True):
-            items = [it for it in self._wt.values() if it[2] == half]
-            launches += [(half, items[c0:c0 + L.MAX_TENSORS]) for c0 in range(0, len(items), L.MAX_TENSORS)]
-        for half, chunk in launches:
+        items = list(self._wt.values())
+        for c0 in range(0, len(items), L.MAX_TENSORS):
+            chunk = items[c0:c0 + L.MAX_TENSORS]
             a = L.TransposeArgs()
             a.n = len(chunk)
-            a.dst_bf16 = 1 if half else 0
-            for i, (w, wt, _) in enumerate(chunk):
+            mask = 0
+            for i, (w, wt, half) in enumerate(chunk):
                 a.t[i].src, a.t[i].dst = w.data_ptr(), wt.data_ptr()
                 a.t[i].rows, a.t[i].cols = w.shape[0], w.shape[1]
+                if half:
+                    mask |= 1 << i
+            a.bf16_mask = mask
             self._keep_args = getattr(self, "_keep_args", []) + [a]
             steps.append(self.call("cdc_transpose_multi", C.byref(a)))
         return steps

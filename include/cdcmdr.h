@@ -221,7 +221,7 @@ typedef struct {
                                         launch has one, both operands stream with the reduction index contiguous */
     int32_t N;
     int32_t out;                     /* index of the output this segment reduces into */
-    int32_t wt_bf16;                 /* 1: wt points at bf16 elements (cdc_transpose_multi with dst_bf16; ldwt in elements,
+    int32_t wt_bf16;                 /* 1: wt points at bf16 elements (cdc_transpose_multi with its bf16_mask bit; ldwt in elements,
                                         a multiple of 8, wt and dz 16-byte aligned, lddz a multiple of 4; CDC_PREC_BF16 only):
                                         half the operand bytes, no conversion in the loop, the same bits in the MFMA */
 } cdc_bwdx_seg;
@@ -242,10 +242,11 @@ typedef struct {
 int cdc_glinear_bwd_x(const cdc_lin_bwdx_args* a, int32_t prec, void* stream);
 
 /* dst_i[c,r] = src_i[r,c] for up to CDC_MAX_TENSORS row-major matrices in one launch (per-step W^T copies for grad-input).
- * dst_bf16 = 1: every dst of the launch is written as bf16 (round to nearest even, what the MFMA path would round to). */
+ * bf16_mask bit i set: dst_i is written as bf16 (round to nearest even, what the MFMA path would round to). */
 typedef struct {
     int32_t n;
-    int32_t dst_bf16;
+    int32_t pad_;
+    uint64_t bf16_mask;
     struct { const float* src; float* dst; int32_t rows, cols; } t[CDC_MAX_TENSORS];
 } cdc_transpose_args;
 int cdc_transpose_multi(const cdc_transpose_args* a, void* stream);
