@@ -172,7 +172,7 @@ _SIGNATURES = {
     "cdc_embed_gather_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
     "cdc_embed_index": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i64, c_p]),
     "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
-    "cdc_embed_sort_dedupe_ids": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "cdc_embed_sort_dedupe_ids": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_segment_sum": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_segment_sum_direct": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),

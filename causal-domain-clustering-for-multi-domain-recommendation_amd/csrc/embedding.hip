@@ -171,12 +171,18 @@ struct SortSrc {
     int32_t* step;
     double* acc;
     int32_t n_acc;
+    int32_t* err_flag;      // offsets != NULL: 1 + flat position of an out-of-range id (atomicMax), as cdc_embed_index reports it
 };
 __device__ __forceinline__ uint32_t sort_row(const SortSrc& s, int64_t i, int f, int F) {
     const int32_t v = s.idx[i * F + f];
     if (!s.offsets) return (uint32_t)v;
     const int32_t row = (int32_t)((uint32_t)v + (uint32_t)s.offsets[f]);
-    return (row >= 0 && (int64_t)row < s.R) ? (uint32_t)row : 0xffffffffu;
+    if (row >= 0 && (int64_t)row < s.R) return (uint32_t)row;
+    if (s.err_flag) {
+        const int64_t pos = i * F + f;
+        atomicMax(s.err_flag, (int32_t)(pos < 0x7ffffffe ? pos + 1 : 0x7fffffff));
+    }
+    return 0xffffffffu;
 }
 __device__ __forceinline__ void sort_begin_step(const SortSrc& s, int tid) {
     if (s.step && blockIdx.x == 0 && blockIdx.y == 0) {
@@ -361,15 +367,15 @@ static int sort_dedupe_launch(const SortSrc& src, int32_t* uniq_row, int32_t* se
 
 extern "C" int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
                                      int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream) {
-    const SortSrc src = {idx, nullptr, 0, nullptr, nullptr, 0};
+    const SortSrc src = {idx, nullptr, 0, nullptr, nullptr, 0, nullptr};
     return sort_dedupe_launch(src, uniq_row, seg_start, perm, uniq_cnt, scratch, B, F, stream);
 }
 extern "C" int cdc_embed_sort_dedupe_ids(const int32_t* ids, const int32_t* offsets, int64_t R, int32_t* step_dev, double* accumulators,
-                                         int32_t n_acc, int32_t* uniq_row, int32_t* seg_start, int32_t* perm, int32_t* uniq_cnt,
-                                         uint64_t* scratch, int64_t B, int32_t F, void* stream) {
+                                         int32_t n_acc, int32_t* err_flag, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
+                                         int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream) {
     CDC_CHECK_ARG(offsets && R > 0 && n_acc >= 0 && n_acc <= 64 && (n_acc == 0 || accumulators) && (step_dev || n_acc == 0), CDC_E_BADARG,
                   "embed_sort_dedupe_ids: bad argument");
-    const SortSrc src = {ids, offsets, R, step_dev, accumulators, n_acc};
+    const SortSrc src = {ids, offsets, R, step_dev, accumulators, n_acc, err_flag};
     return sort_dedupe_launch(src, uniq_row, seg_start, perm, uniq_cnt, scratch, B, F, stream);
 }
 

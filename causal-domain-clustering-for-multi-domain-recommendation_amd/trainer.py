@@ -220,9 +220,7 @@ class TrainStep:
             return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
         def stage0():
-            opt.begin_step()
-            opt.table_index(emb.ids, emb.offsets, emb.idx, B, F, err=emb.err)
-            ws = opt.sort_rows(emb.idx, B, F, D, "local")
+            ws = opt.begin_step_sort(emb.ids, emb.offsets, B, F, D, "local", err=emb.err)   # ++step, index, sort: one launch chain
             L.launch("cdc_shard_bucket", lib.cdc_shard_bucket,
                      (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.send_ids.data_ptr(), self.slot_of.data_ptr(),
                       self.overflow.data_ptr(), B, F, N, cap), st())

@@ -79,10 +79,11 @@ int cdc_embed_sort_dedupe(const int32_t* idx, int32_t* uniq_row, int32_t* seg_st
                           int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream);
 /* The same from the raw ids of a batch: row = ids[b,f] + offsets[f] (model/layer.py:139), ids outside [0,R) sort as -1 —
  * cdc_embed_index fused into the sort's first launch.  step_dev != NULL: that launch also does cdc_begin_step's work
- * (++*step_dev, accumulators[0..n_acc) = 0) — for a training step whose first launch this is. */
+ * (++*step_dev, accumulators[0..n_acc) = 0) — for a training step whose first launch this is.  err_flag (may be NULL):
+ * device int32, raised to 1 + the flat position of an out-of-range id, like cdc_embed_index. */
 int cdc_embed_sort_dedupe_ids(const int32_t* ids, const int32_t* offsets, int64_t R, int32_t* step_dev, double* accumulators,
-                              int32_t n_acc, int32_t* uniq_row, int32_t* seg_start, int32_t* perm, int32_t* uniq_cnt,
-                              uint64_t* scratch, int64_t B, int32_t F, void* stream);
+                              int32_t n_acc, int32_t* err_flag, int32_t* uniq_row, int32_t* seg_start, int32_t* perm,
+                              int32_t* uniq_cnt, uint64_t* scratch, int64_t B, int32_t F, void* stream);
 
 /* Per-row gradient of the batch: rowgrad[f, j, :] = sum over unique row j's segment of d_out[b, f*D:(f+1)*D],
  * summed in ascending b (the order aten::embedding_dense_backward uses on the CPU, model/layer.py:140,153) for segments

@@ -478,9 +478,11 @@ def test_sort_dedupe_from_raw_ids_with_begin_step(cuda, B):
         cnt = torch.zeros(F, dtype=torch.int32, device=cuda)
         scratch = torch.empty(2 * F * B, dtype=torch.int64, device=cuda)
         if fused:
+            err = torch.zeros(1, dtype=torch.int32, device=cuda)
             L.check(lib.cdc_embed_sort_dedupe_ids(d_ids.data_ptr(), d_off.data_ptr(), R, step.data_ptr(), acc.data_ptr(), 2,
-                                                  uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
+                                                  err.data_ptr(), uniq.data_ptr(), seg.data_ptr(), perm.data_ptr(), cnt.data_ptr(),
                                                   scratch.data_ptr(), B, F, s), "sort ids")
+            assert int(err.item()) == 5 * F + 0 + 1                # the later of the two bad positions (atomicMax), 1-based
         else:
             idx = torch.empty((B, F), dtype=torch.int32, device=cuda)
             L.check(lib.cdc_embed_index(d_ids.data_ptr(), d_off.data_ptr(), idx.data_ptr(), None, B, F, R, s), "index")
