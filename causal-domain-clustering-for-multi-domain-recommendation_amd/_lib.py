@@ -142,7 +142,8 @@ class RowdotBGroup(C.Structure):
 
 class RowdotBwdArgs(C.Structure):
     _fields_ = [("n_groups", c_i32), ("sigmoid", c_i32), ("M", c_i64), ("row_offsets", c_p), ("workspace", c_p),
-                ("g", RowdotBGroup * MAX_GROUPS)]
+                ("bce_group", c_p), ("bce_y_i16", c_p), ("bce_y_f32", c_p), ("bce_loss", c_p), ("bce_partial", c_p),
+                ("bce_inv_count", c_f), ("pad_", c_i32), ("g", RowdotBGroup * MAX_GROUPS)]
 
 
 class StarFuseArgs(C.Structure):

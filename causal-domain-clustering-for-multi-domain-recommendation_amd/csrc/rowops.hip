@@ -593,24 +593,49 @@ __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd(const cdc_rowdot_bwd
     float* mine = sh + wave * (kmax + 1);
     for (int k = lane; k <= kmax; k += 64) mine[k] = 0.f;
     float db = 0.f;
+    double loss_part = 0.0;
+    const bool bce = a.bce_y_i16 != nullptr || a.bce_y_f32 != nullptr;
     // four rows per round: their d (and sigmoid outputs) are fetched together, then their x rows — the launch is a few
     // dependent round trips long, so what counts is how many loads each of them carries
     constexpr int RB = 4;
     for (int r0 = r_begin + wave; r0 < r_end; r0 += RB * WAVES_PER_BLOCK) {
         float d[RB];
         int64_t gr[RB];
+        if (bce) {
+            // the loss and its gradient formed here instead of by a cdc_bce_fwd_bwd launch in between (same float operations)
+            float o[RB], t[RB];
+            int64_t col[RB];
 #pragma unroll
-        for (int q = 0; q < RB; ++q) {
-            const int r = r0 + q * WAVES_PER_BLOCK;
-            gr[q] = row_lo + min(r, r_end - 1);
-            d[q] = G.dout[gr[q] * G.ld_dout];
-        }
-        if (a.sigmoid) {
-            float o[RB];
+            for (int q = 0; q < RB; ++q) {
+                const int r = r0 + q * WAVES_PER_BLOCK;
+                gr[q] = row_lo + min(r, r_end - 1);
+                o[q] = G.out[gr[q] * G.ld_out];
+                t[q] = a.bce_y_i16 ? (float)a.bce_y_i16[gr[q]] : a.bce_y_f32[gr[q]];
+                col[q] = a.bce_group ? a.bce_group[gr[q]] : 0;
+            }
 #pragma unroll
-            for (int q = 0; q < RB; ++q) o[q] = G.out[gr[q] * G.ld_out];
+            for (int q = 0; q < RB; ++q) {
+                if (col[q] < 0 || col[q] >= a.n_groups) col[q] = 0;
+                const bool own = col[q] == g && r0 + q * WAVES_PER_BLOCK < r_end;
+                const float x = o[q];
+                if (own) loss_part += (double)((t[q] - 1.f) * fmaxf(log1pf(-x), -100.f) - t[q] * fmaxf(logf(x), -100.f));
+                const float dout = own ? a.bce_inv_count * (x - t[q]) / fmaxf((1.f - x) * x, 1e-12f) : 0.f;
+                d[q] = dout * x * (1.f - x);
+            }
+        } else {
 #pragma unroll
-            for (int q = 0; q < RB; ++q) d[q] = d[q] * o[q] * (1.f - o[q]);
+            for (int q = 0; q < RB; ++q) {
+                const int r = r0 + q * WAVES_PER_BLOCK;
+                gr[q] = row_lo + min(r, r_end - 1);
+                d[q] = G.dout[gr[q] * G.ld_dout];
+            }
+            if (a.sigmoid) {
+                float o[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) o[q] = G.out[gr[q] * G.ld_out];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) d[q] = d[q] * o[q] * (1.f - o[q]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < RB; ++q) {
@@ -643,7 +668,11 @@ __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd(const cdc_rowdot_bwd
         }
     }
     if (lane == 0) mine[kmax] = db;
+    __shared__ double loss_w[WAVES_PER_BLOCK];
+    if (bce && lane == 0) loss_w[wave] = loss_part;                      // every lane of a wave holds the same sum
     __syncthreads();
+    if (bce && threadIdx.x == 0)
+        a.bce_partial[(int64_t)g * CDC_ROWDOT_PARTS + part] = ((loss_w[0] + loss_w[1]) + loss_w[2]) + loss_w[3];
     float* ws = a.workspace + ((int64_t)g * CDC_ROWDOT_PARTS + part) * (kmax + 1);
     for (int k = threadIdx.x; k <= kmax; k += ROW_THREADS) {
         float s = 0.f;
@@ -657,6 +686,16 @@ __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd_final(const cdc_rowd
     const int g = blockIdx.y;
     const cdc_rowdot_bgroup& G = a.g[g];
     const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x == (kmax + WAVES_PER_BLOCK) / WAVES_PER_BLOCK) {
+        // the extra block of a launch with the fused BCE: group 0's first wave adds the per-block loss partials in index order
+        if (g != 0 || threadIdx.x >= 64 || !a.bce_loss) return;
+        const int n = a.n_groups * CDC_ROWDOT_PARTS;
+        double s = 0.0;
+        for (int i = lane; i < n; i += 64) s += a.bce_partial[i];
+        s = wave_sum_d(s);
+        if (lane == 0) *a.bce_loss = (float)(s * (double)a.bce_inv_count);
+        return;
+    }
     const int k = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (k > kmax) return;
     const float* ws = a.workspace + (int64_t)g * CDC_ROWDOT_PARTS * (kmax + 1) + k;
@@ -676,15 +715,19 @@ extern "C" int cdc_rowdot_bwd(const cdc_rowdot_bwd_args* a, void* stream) {
     CDC_CHECK_ARG(a && a->n_groups > 0 && a->n_groups <= CDC_MAX_GROUPS && a->M >= 0 && a->workspace, CDC_E_BADARG, "rowdot_bwd: bad argument");
     int kmax = 0;
     for (int g = 0; g < a->n_groups; ++g) {
-        CDC_CHECK_ARG(a->g[g].dout && a->g[g].x && a->g[g].w && a->g[g].K > 0 && (!a->sigmoid || a->g[g].out), CDC_E_BADARG,
-                      "rowdot_bwd: group %d malformed", g);
+        CDC_CHECK_ARG((a->g[g].dout || a->bce_y_i16 || a->bce_y_f32) && a->g[g].x && a->g[g].w && a->g[g].K > 0 &&
+                          (!a->sigmoid || a->g[g].out), CDC_E_BADARG, "rowdot_bwd: group %d malformed", g);
         kmax = std::max(kmax, a->g[g].K);
     }
     CDC_CHECK_ARG((size_t)WAVES_PER_BLOCK * (kmax + 1) * 4 <= 64 * 1024, CDC_E_TOOBIG, "rowdot_bwd: K too large");
+    if (a->bce_y_i16 || a->bce_y_f32)
+        CDC_CHECK_ARG(a->sigmoid && !a->row_offsets && a->bce_loss && a->bce_partial && a->bce_inv_count > 0.f, CDC_E_BADARG,
+                      "rowdot_bwd: the fused BCE needs sigmoid outputs, dense rows, a loss pointer and the partial-sum buffer");
     hipLaunchKernelGGL(k_rowdot_bwd, dim3(CDC_ROWDOT_PARTS, a->n_groups), dim3(ROW_THREADS), WAVES_PER_BLOCK * (kmax + 1) * sizeof(float),
                        (hipStream_t)stream, *a, kmax);
     CDC_LAUNCH_CHECK("rowdot_bwd");
-    hipLaunchKernelGGL(k_rowdot_bwd_final, dim3(cdc_ceil_div(kmax + 1, WAVES_PER_BLOCK), a->n_groups), dim3(ROW_THREADS), 0,
+    const bool bce = a->bce_y_i16 || a->bce_y_f32;
+    hipLaunchKernelGGL(k_rowdot_bwd_final, dim3(cdc_ceil_div(kmax + 1, WAVES_PER_BLOCK) + (bce ? 1 : 0), a->n_groups), dim3(ROW_THREADS), 0,
                        (hipStream_t)stream, *a, kmax);
     CDC_LAUNCH_CHECK("rowdot_bwd_final");
     return 0;

@@ -989,6 +989,7 @@ class RowDot:
                 self._keep.append(n)
                 post.append(plan.call("cdc_add_n", C.byref(n)))
         self._keep.append(a)
+        self.bwd_args = getattr(self, "bwd_args", []) + [a]       # (trainer: the fused BCE is switched on in the head's launch)
         plan.bwd_steps.append(plan.call("cdc_rowdot_bwd", C.byref(a)))
         plan.bwd_steps.extend(post)
 

@@ -124,8 +124,39 @@ class TrainStep:
             model.train(was)
 
     # ------------------------------------------------------------------------------------------
+    def _find_head(self):
+        """The launch that turns the tower logits into the predictions the loss reads: a single sigmoid row-dot launch whose
+        groups are the columns of `self.out`, in order.  Its backward can form the BCE gradient itself (cdc_rowdot_bwd's fused
+        BCE): one launch and a round trip through d_out less per step.  Returns that launch's argument block or None."""
+        from . import plan as P
+        out = self.out
+        for op in self.plan.ops:
+            if not isinstance(op, P.RowDot) or not op.sigmoid or op.row_offsets is not None or len(op.groups) != out.cols:
+                continue
+            if all(g["out"].root is out.root and g["out"].col0 == out.col0 + i and g["out"].cols == 1 for i, g in enumerate(op.groups)):
+                args = getattr(op, "bwd_args", [])
+                return args[0] if len(args) == 1 and op.M == self.B else None
+        return None
+
     def _bce(self):
         og = self.out.grad
+        head = self.__dict__.get("_head", False)
+        if head is False:
+            import os
+            head = self._head = self._find_head()
+            self._fuse_bce = (head is not None and self.mode in ("multi", "single", "single_group") and
+                              os.environ.get("CDC_FUSE_BCE", "1") != "0")
+            if self._fuse_bce:
+                self._bce_partial = torch.zeros(L.MAX_GROUPS * L.ROWDOT_PARTS, dtype=torch.float64, device=self.device)
+        if head is not None:
+            # the argument block belongs to the (cached, possibly shared) plan: set for this trainer before every backward
+            if self._fuse_bce:
+                head.bce_group = None if self.group is None else self.group.data_ptr()
+                head.bce_y_i16, head.bce_y_f32 = self.y.data_ptr(), None
+                head.bce_loss, head.bce_partial = self.loss.data_ptr(), self._bce_partial.data_ptr()
+                head.bce_inv_count = 1.0 / self.global_B
+                return
+            head.bce_y_i16 = head.bce_y_f32 = None
         if self.mode == "mean":
             L.launch("cdc_bce_mean_fwd_bwd", self.lib.cdc_bce_mean_fwd_bwd,
                      (self.out.ptr, self.out.ld, self.y.data_ptr(), None, self.loss.data_ptr(), og.ptr, og.ld, self.B, self.out.cols,

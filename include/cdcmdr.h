@@ -422,6 +422,18 @@ typedef struct {
     int64_t M;
     const int32_t* row_offsets;
     float* workspace;                     /* >= n_groups * CDC_ROWDOT_PARTS * (Kmax+1) floats */
+    /* Fused BCELoss(mean) (run.py:484,723; cdc_bce_fwd_bwd's arithmetic): when bce_y_i16 or bce_y_f32 is set, the launch's
+     * groups are the columns of one prediction matrix (sigmoid must be 1, no row_offsets), g[].dout is NOT read: for row b
+     * and group c, dout = (c == col(b)) ? bce_inv_count * (o - t) / max((1 - o) o, 1e-12) : 0 with col(b) = bce_group[b]
+     * (clamped into the launch's columns; column 0 when bce_group is NULL), and *bce_loss = mean BCE of the own columns
+     * (ordered sum of per-block partials in bce_partial, >= n_groups * CDC_ROWDOT_PARTS doubles). */
+    const int64_t* bce_group;
+    const int16_t* bce_y_i16;
+    const float* bce_y_f32;
+    float* bce_loss;
+    double* bce_partial;
+    float bce_inv_count;
+    int32_t pad_;
     cdc_rowdot_bgroup g[CDC_MAX_GROUPS];
 } cdc_rowdot_bwd_args;
 #define CDC_ROWDOT_PARTS 256
