@@ -176,6 +176,7 @@ _SIGNATURES = {
     "cdc_embed_sort_dedupe_ids": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_segment_sum": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_segment_sum_direct": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
+    "cdc_embed_segsum_lazy_update": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_embed_grad_dense": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
     "cdc_embed_adam_touched": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_adam_dense_pass": (c_i32, [c_p, c_p, c_p, c_i64, AdamHP, c_p, c_p, c_p]),

@@ -451,13 +451,62 @@ extern "C" int cdc_embed_merge_dedupe(const int32_t* idx, int32_t* uniq_row, int
 #define SEG_LONG_BLOCKS 64
 #define SEG_LIST_CAP (CDC_SORT_MAX_ROWS / SEG_LONG_BLOCKS)
 
+// What happens to a finished per-row gradient: stored to rowgrad, or (w != NULL) consumed on the spot by the lazy table's
+// Adam step t for that row — cdc_embed_lazy_update's arithmetic without the round trip through rowgrad and its launch.
+struct SegSink {
+    float* rowgrad;
+    float* w; float* m; float* v;
+    int32_t* last;
+    const int32_t* uniq_row;
+    AdamConsts c;
+    float step_size, bc2s;
+    int32_t t;
+};
+template <int VEC>
+__device__ __forceinline__ void seg_finish(const SegSink& k, int64_t slot, int D, int d0, const float (&acc)[VEC]) {
+    if (!k.w) {
+        float* dst = k.rowgrad + slot * D + d0;
+        if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+        else dst[0] = acc[0];
+        return;
+    }
+    const int64_t row = k.uniq_row[slot];
+    if (row < 0) return;
+    const int64_t e0 = row * D + d0;
+    float wv[VEC], mv[VEC], vv[VEC];
+    if (VEC == 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(k.w + e0), b4 = *reinterpret_cast<const float4*>(k.m + e0),
+                     c4 = *reinterpret_cast<const float4*>(k.v + e0);
+        wv[0] = a4.x; wv[1 % VEC] = a4.y; wv[2 % VEC] = a4.z; wv[3 % VEC] = a4.w;
+        mv[0] = b4.x; mv[1 % VEC] = b4.y; mv[2 % VEC] = b4.z; mv[3 % VEC] = b4.w;
+        vv[0] = c4.x; vv[1 % VEC] = c4.y; vv[2 % VEC] = c4.z; vv[3 % VEC] = c4.w;
+    } else {
+        wv[0] = k.w[e0]; mv[0] = k.m[e0]; vv[0] = k.v[e0];
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) adam_elem(wv[q], mv[q], vv[q], acc[q], k.c, k.step_size, k.bc2s);
+    if (VEC == 4) {
+        *reinterpret_cast<float4*>(k.w + e0) = make_float4(wv[0], wv[1 % VEC], wv[2 % VEC], wv[3 % VEC]);
+        *reinterpret_cast<float4*>(k.m + e0) = make_float4(mv[0], mv[1 % VEC], mv[2 % VEC], mv[3 % VEC]);
+        *reinterpret_cast<float4*>(k.v + e0) = make_float4(vv[0], vv[1 % VEC], vv[2 % VEC], vv[3 % VEC]);
+    } else {
+        k.w[e0] = wv[0]; k.m[e0] = mv[0]; k.v[e0] = vv[0];
+    }
+    if (d0 == 0) k.last[row] = k.t;
+}
+__device__ __forceinline__ SegSink seg_sink_store(float* rowgrad) {
+    SegSink k = {};
+    k.rowgrad = rowgrad;
+    return k;
+}
+
 // One thread per (unique row, 16-byte chunk): the segment's gradient rows are added straight from d_out through perm in
 // segment order, eight entries' loads in flight per round.  max_len > 0: rows whose segment holds max_len entries or more
 // are left to k_segment_sum_long.  uniq_row != NULL: rows < 0 (the -1 padding of an owner's received lists) are skipped.
 template <int VEC>
 __device__ __forceinline__ void seg_direct_body(int bid, int nblocks, const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
                                                 const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
-                                                const int32_t* __restrict__ uniq_row, float* __restrict__ rowgrad,
+                                                const int32_t* __restrict__ uniq_row, const SegSink& sink,
                                                 int32_t B, int32_t F, int32_t D, int32_t max_len) {
     const int chunks = D / VEC;
     const int64_t total = (int64_t)F * B * chunks;
@@ -499,9 +548,7 @@ __device__ __forceinline__ void seg_direct_body(int bid, int nblocks, const floa
                     for (int e = 0; e < VEC; ++e) acc[e] = __fadd_rn(acc[e], v[q][e]);
                 }
         }
-        float* dst = rowgrad + slot * D + c * VEC;
-        if (VEC == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        else dst[0] = acc[0];
+        seg_finish<VEC>(sink, slot, D, c * VEC, acc);
     }
 }
 template <int VEC>
@@ -509,7 +556,7 @@ __global__ void __launch_bounds__(256) k_segment_sum_direct(const float* __restr
                                                             const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
                                                             const int32_t* __restrict__ uniq_row, float* __restrict__ rowgrad,
                                                             int32_t B, int32_t F, int32_t D, int32_t max_len) {
-    seg_direct_body<VEC>(blockIdx.x, gridDim.x, d_out, seg_start, perm, uniq_cnt, uniq_row, rowgrad, B, F, D, max_len);
+    seg_direct_body<VEC>(blockIdx.x, gridDim.x, d_out, seg_start, perm, uniq_cnt, uniq_row, seg_sink_store(rowgrad), B, F, D, max_len);
 }
 extern "C" int cdc_embed_segment_sum_direct(const float* d_out, const int32_t* seg_start, const int32_t* perm,
                                             const int32_t* uniq_cnt, const int32_t* uniq_row, float* rowgrad, int64_t B, int32_t F,
@@ -548,7 +595,7 @@ __device__ __forceinline__ float seg_serial_sum(const float* __restrict__ d_out,
 }
 __device__ __forceinline__ void seg_long_body(int f, int by, const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
                                               const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
-                                              float* __restrict__ rowgrad, int32_t B, int32_t F, int32_t D, int32_t subs,
+                                              const SegSink& sink, int32_t B, int32_t F, int32_t D, int32_t subs,
                                               int32_t min_len) {
     __shared__ int32_t list[SEG_LIST_CAP];
     __shared__ int32_t n_list;
@@ -570,9 +617,12 @@ __device__ __forceinline__ void seg_long_body(int f, int by, const float* __rest
         const int j = list[i];
         const int k0 = sst[j], len = sst[j + 1] - k0;
         if (block_rows && len >= SEG_BLOCK) continue;
-        float* dst = rowgrad + ((int64_t)f * B + j) * D;
+        const int64_t slot = (int64_t)f * B + j;
         if (subs <= 1) {                                               // general D: lanes stride over d, serial ascending sum
-            for (int d = lane; d < D; d += 64) dst[d] = seg_serial_sum(d_out, prm + k0, 0, len, F, D, f, d);
+            for (int d = lane; d < D; d += 64) {
+                const float one[1] = {seg_serial_sum(d_out, prm + k0, 0, len, F, D, f, d)};
+                seg_finish<1>(sink, slot, D, d, one);
+            }
             continue;
         }
         const int sub = lane / D, d = lane - sub * D;
@@ -589,7 +639,10 @@ __device__ __forceinline__ void seg_long_body(int f, int by, const float* __rest
             for (int s2 = 1; s2 < subs; ++s2) total = __fadd_rn(total, __shfl(acc, s2 * D + d, 64));
             acc = total;
         }
-        if (sub == 0) dst[d] = acc;
+        if (sub == 0) {
+            const float one[1] = {acc};
+            seg_finish<1>(sink, slot, D, d, one);
+        }
     }
     if (!block_rows) return;
     // ---- the workgroup per very long row: 256 / D parts ------------------------------------------
@@ -606,7 +659,8 @@ __device__ __forceinline__ void seg_long_body(int f, int by, const float* __rest
         if (tid < D) {
             float total = parts[tid];
             for (int p2 = 1; p2 < P; ++p2) total = __fadd_rn(total, parts[p2 * D + tid]);
-            rowgrad[((int64_t)f * B + j) * D + tid] = total;
+            const float one[1] = {total};
+            seg_finish<1>(sink, (int64_t)f * B + j, D, tid, one);
         }
         __syncthreads();
     }
@@ -617,13 +671,30 @@ __device__ __forceinline__ void seg_long_body(int f, int by, const float* __rest
 template <int VEC>
 __global__ void __launch_bounds__(256) k_segment_sum(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
                                                      const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
-                                                     float* __restrict__ rowgrad, int32_t B, int32_t F, int32_t D, int32_t subs) {
+                                                     SegSink sink, cdc_adam_hp hp, const int32_t* __restrict__ step_dev, int32_t B,
+                                                     int32_t F, int32_t D, int32_t subs) {
+    if (sink.w) {                                                      // the rows' Adam step t happens right here
+        sink.c = make_consts(hp);
+        sink.t = *step_dev;
+        step_scalars_at(hp.step_scalars, hp.n_scalars, sink.t, sink.step_size, sink.bc2s);
+    }
     const int n_long = F * SEG_LONG_BLOCKS;
     if ((int)blockIdx.x < n_long)
-        seg_long_body(blockIdx.x / SEG_LONG_BLOCKS, blockIdx.x % SEG_LONG_BLOCKS, d_out, seg_start, perm, uniq_cnt, rowgrad, B, F, D, subs,
+        seg_long_body(blockIdx.x / SEG_LONG_BLOCKS, blockIdx.x % SEG_LONG_BLOCKS, d_out, seg_start, perm, uniq_cnt, sink, B, F, D, subs,
                       SEG_DIRECT);
     else
-        seg_direct_body<VEC>(blockIdx.x - n_long, gridDim.x - n_long, d_out, seg_start, perm, uniq_cnt, nullptr, rowgrad, B, F, D, SEG_DIRECT);
+        seg_direct_body<VEC>(blockIdx.x - n_long, gridDim.x - n_long, d_out, seg_start, perm, uniq_cnt, nullptr, sink, B, F, D, SEG_DIRECT);
+}
+// short segments only (an owner's merged row lists), same sink
+template <int VEC>
+__global__ void __launch_bounds__(256) k_segment_sum_short_sink(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                                                SegSink sink, cdc_adam_hp hp, const int32_t* __restrict__ step_dev,
+                                                                int32_t B, int32_t F, int32_t D) {
+    sink.c = make_consts(hp);
+    sink.t = *step_dev;
+    step_scalars_at(hp.step_scalars, hp.n_scalars, sink.t, sink.step_size, sink.bc2s);
+    seg_direct_body<VEC>(blockIdx.x, gridDim.x, d_out, seg_start, perm, uniq_cnt, sink.uniq_row, sink, B, F, D, 0);
 }
 
 extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_start, const int32_t* perm,
@@ -636,9 +707,38 @@ extern "C" int cdc_embed_segment_sum(const float* d_out, const int32_t* seg_star
     const bool vec = (D % 4 == 0) && (((uintptr_t)d_out | (uintptr_t)rowgrad) % 16 == 0);
     const int blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192) + F * SEG_LONG_BLOCKS;
     const int subs = (D <= 64 && 64 % D == 0) ? 64 / D : 1;
-    if (vec) hipLaunchKernelGGL(k_segment_sum<4>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, rowgrad, (int32_t)B, F, D, subs);
-    else     hipLaunchKernelGGL(k_segment_sum<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, rowgrad, (int32_t)B, F, D, subs);
+    SegSink sink = {};
+    sink.rowgrad = rowgrad;
+    const cdc_adam_hp no_hp = {};
+    if (vec) hipLaunchKernelGGL(k_segment_sum<4>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, no_hp, nullptr, (int32_t)B, F, D, subs);
+    else     hipLaunchKernelGGL(k_segment_sum<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, no_hp, nullptr, (int32_t)B, F, D, subs);
     CDC_LAUNCH_CHECK("embed_segment_sum");
+    return 0;
+}
+
+// cdc_embed_segment_sum + cdc_embed_lazy_update in one launch: a row's summed gradient is used for its Adam step t where it is
+// formed.  short_only: every segment is short (an owner's merged lists; rows < 0 skipped) — the direct kernel alone.
+extern "C" int cdc_embed_segsum_lazy_update(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
+                                            const int32_t* uniq_row, float* w, float* m, float* v, int32_t* last, cdc_adam_hp hp,
+                                            const int32_t* step_dev, int64_t B, int32_t F, int32_t D, int32_t short_only, void* stream) {
+    CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && uniq_row && w && m && v && last && step_dev && hp.step_scalars &&
+                      hp.n_scalars > 0, CDC_E_BADARG, "embed_segsum_lazy_update: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_segsum_lazy_update: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (D % 4 == 0) && ((((uintptr_t)d_out | (uintptr_t)w | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    SegSink sink = {};
+    sink.w = w; sink.m = m; sink.v = v; sink.last = last; sink.uniq_row = uniq_row;
+    const int direct_blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
+    if (short_only) {
+        if (vec) hipLaunchKernelGGL(k_segment_sum_short_sink<4>, dim3(direct_blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D);
+        else     hipLaunchKernelGGL(k_segment_sum_short_sink<1>, dim3(direct_blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D);
+    } else {
+        const int blocks = direct_blocks + F * SEG_LONG_BLOCKS;
+        const int subs = (D <= 64 && 64 % D == 0) ? 64 / D : 1;
+        if (vec) hipLaunchKernelGGL(k_segment_sum<4>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D, subs);
+        else     hipLaunchKernelGGL(k_segment_sum<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D, subs);
+    }
+    CDC_LAUNCH_CHECK("embed_segsum_lazy_update");
     return 0;
 }
 

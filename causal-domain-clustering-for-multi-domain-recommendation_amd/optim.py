@@ -17,6 +17,8 @@ Dense parameters go through one multi-tensor kernel with the L2 gradient 2*l2*w 
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -215,6 +217,12 @@ class FusedAdam:
                      (ws["side"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), w, m, v, B, F, D), s)
         else:
             ws = self._workspace(B, F, D, tag)   # rows were sorted by table_catchup of this step
+            if os.environ.get("CDC_FUSE_ROW_UPDATE", "1") != "0":
+                # per-row gradient sums and the rows' Adam step in one launch
+                L.launch("cdc_embed_segsum_lazy_update", self.lib.cdc_embed_segsum_lazy_update,
+                         (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["uniq"].data_ptr(),
+                          w, m, v, self.table_last.data_ptr(), hp, self.step_dev.data_ptr(), B, F, D, 1 if short_segments else 0), s)
+                return
             self._segment_sum(ws, d_out, B, F, D, s, short=short_segments)
             L.launch("cdc_embed_lazy_update", self.lib.cdc_embed_lazy_update,
                      (ws["rowgrad"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(),

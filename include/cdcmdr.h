@@ -149,6 +149,12 @@ int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_row, const i
                           float* w, float* m, float* v, int32_t* last,
                           cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring, int32_t ring_len,
                           int64_t B, int32_t F, int32_t D, void* stream);
+/* cdc_embed_segment_sum + cdc_embed_lazy_update in ONE launch: every row's summed gradient is used for its Adam step t by the
+ * thread(s) that formed it (no rowgrad round trip).  Same sums, same arithmetic, identical bits.  short_only = 1: the batch
+ * is an owner's merged row lists (segments of at most one entry per sender; rows < 0 are padding and skipped). */
+int cdc_embed_segsum_lazy_update(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
+                                 const int32_t* uniq_row, float* w, float* m, float* v, int32_t* last, cdc_adam_hp hp,
+                                 const int32_t* step_dev, int64_t B, int32_t F, int32_t D, int32_t short_only, void* stream);
 /* brings rows to step target = *step_dev + step_bias: rows with last < target are replayed.
  * period <= 1: all R rows.  period > 1: only slice (target mod period) of the table (ceil(R/period) consecutive rows), so
  * that calling it every step brings every row up to date once per `period` steps — this bounds the gaps the per-batch
