@@ -593,13 +593,14 @@ __device__ __forceinline__ float seg_serial_sum(const float* __restrict__ d_out,
     }
     return acc;
 }
+template <int VEC>
 __device__ __forceinline__ void seg_long_body(int f, int by, const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
                                               const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
                                               const SegSink& sink, int32_t B, int32_t F, int32_t D, int32_t subs,
                                               int32_t min_len) {
     __shared__ int32_t list[SEG_LIST_CAP];
     __shared__ int32_t n_list;
-    __shared__ float parts[256];
+    __shared__ __attribute__((aligned(16))) float parts[256 * VEC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = uniq_cnt[f];
     const int32_t* sst = seg_start + (int64_t)f * (B + 1);
@@ -645,22 +646,57 @@ __device__ __forceinline__ void seg_long_body(int f, int by, const float* __rest
         }
     }
     if (!block_rows) return;
-    // ---- the workgroup per very long row: 256 / D parts ------------------------------------------
-    const int P = 256 / D;
-    const int part = tid / D, d = tid - part * D;
+    // ---- the workgroup per very long row: a thread owns VEC consecutive columns, 256 / (D / VEC) parts ----------
+    const int chunks = D / VEC;
+    const int P = 256 / chunks;
+    const int part = tid / chunks, d = (tid - part * chunks) * VEC;
     for (int i = 0; i < count; ++i) {
         const int j = list[i];
         const int k0 = sst[j], len = sst[j + 1] - k0;
         if (len < SEG_BLOCK) continue;                                 // uniform over the workgroup
         const int q = (len + P - 1) / P;
         const int begin = min(part * q, len), end = min(begin + q, len);
-        parts[tid] = seg_serial_sum<32>(d_out, prm + k0, begin, end, F, D, f, d);
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+        if (part < P) {
+            constexpr int NB = VEC == 4 ? 16 : 32;                     // loads in flight per round (register budget)
+            for (int k = begin; k < end; k += NB) {
+                int pr[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) pr[u] = (k + u < end) ? prm[k0 + k + u] : -1;
+                float x[NB][VEC];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (pr[u] >= 0) {
+                        const float* src = d_out + ((int64_t)pr[u] * F + f) * D + d;
+                        if (VEC == 4) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(src);
+                            x[u][0] = t4.x; x[u][1 % VEC] = t4.y; x[u][2 % VEC] = t4.z; x[u][3 % VEC] = t4.w;
+                        } else {
+                            x[u][0] = src[0];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    if (pr[u] >= 0) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[e] = __fadd_rn(acc[e], x[u][e]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) parts[tid * VEC + e] = acc[e];
         __syncthreads();
-        if (tid < D) {
-            float total = parts[tid];
-            for (int p2 = 1; p2 < P; ++p2) total = __fadd_rn(total, parts[p2 * D + tid]);
-            const float one[1] = {total};
-            seg_finish<1>(sink, (int64_t)f * B + j, D, tid, one);
+        if (tid < chunks) {
+            float total[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) total[e] = parts[tid * VEC + e];
+            for (int p2 = 1; p2 < P; ++p2)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) total[e] = __fadd_rn(total[e], parts[(p2 * chunks + tid) * VEC + e]);
+            seg_finish<VEC>(sink, (int64_t)f * B + j, D, tid * VEC, total);
         }
         __syncthreads();
     }
@@ -680,8 +716,8 @@ __global__ void __launch_bounds__(256) k_segment_sum(const float* __restrict__ d
     }
     const int n_long = F * SEG_LONG_BLOCKS;
     if ((int)blockIdx.x < n_long)
-        seg_long_body(blockIdx.x / SEG_LONG_BLOCKS, blockIdx.x % SEG_LONG_BLOCKS, d_out, seg_start, perm, uniq_cnt, sink, B, F, D, subs,
-                      SEG_DIRECT);
+        seg_long_body<VEC>(blockIdx.x / SEG_LONG_BLOCKS, blockIdx.x % SEG_LONG_BLOCKS, d_out, seg_start, perm, uniq_cnt, sink, B, F, D,
+                           subs, SEG_DIRECT);
     else
         seg_direct_body<VEC>(blockIdx.x - n_long, gridDim.x - n_long, d_out, seg_start, perm, uniq_cnt, nullptr, sink, B, F, D, SEG_DIRECT);
 }
