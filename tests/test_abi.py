@@ -45,7 +45,7 @@ STRUCTS = {
     "cdc_bn_seg": "BnSeg", "cdc_bn_fwd_args": "BnFwdArgs", "cdc_bn_bseg": "BnBSeg", "cdc_bn_bwd_args": "BnBwdArgs",
     "cdc_rowdot_group": "RowdotGroup", "cdc_rowdot_fwd_args": "RowdotFwdArgs", "cdc_rowdot_bgroup": "RowdotBGroup",
     "cdc_rowdot_bwd_args": "RowdotBwdArgs", "cdc_adam_tensor": "AdamTensor", "cdc_adam_args": "AdamArgs",
-    "cdc_star_fuse_args": "StarFuseArgs", "cdc_transpose_args": "TransposeArgs",
+    "cdc_star_fuse_args": "StarFuseArgs", "cdc_transpose_args": "TransposeArgs", "cdc_add_n_args": "AddNArgs",
 }
 
 
