@@ -29,8 +29,12 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=2000,
-                    help="default covers the ~1700 steps in which Adam bias corrections still move and lets the lazy table reach its steady state")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps right before the timed region")
+    ap.add_argument("--preroll", type=int, default=-1,
+                    help="untimed steps run BEFORE --warmup, whatever --warmup is, so that the timed region is in steady state: the "
+                         "lazy table needs flush_every steps until every slice owes a whole period of replay, and the Adam bias "
+                         "corrections move for ~1700 steps (their table look-ups stop afterwards).  -1 = flush_every + the length of "
+                         "the step-scalar table + 64")
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (weak scaling)")
     ap.add_argument("--fields", type=int, default=26)
     ap.add_argument("--vocab", type=int, default=1_000_000)
@@ -42,10 +46,10 @@ def parse():
     ap.add_argument("--id-dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=4)
-    ap.add_argument("--sync-bn", type=int, default=0,
-                    help="N>1: 1 = BatchNorm statistics over the global batch (bit-for-bit the single-process semantics of the "
-                         "concatenated batch, ~18 small all-reduces per step); 0 = per-rank statistics over the local 4096 rows "
-                         "(the population the reference's BatchNorm sees at its batch size)")
+    ap.add_argument("--sync-bn", type=int, default=1,
+                    help="N>1: 1 (default, the parity semantic of SURVEY 8e) = BatchNorm statistics over the global batch, bit for bit "
+                         "the single-process step on the concatenated batch; 0 = per-rank statistics over the local rows.  With 1 "
+                         "the per-rank-statistics throughput is measured as well and reported as `value_per_rank_bn`")
     ap.add_argument("--table-dist", default=None, choices=["sharded", "replicated"], help="N>1: default sharded (lazy table)")
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="diagnostic, single process: run ONE rank's launch work of a W-rank step with the collectives replaced "
@@ -156,10 +160,63 @@ class Loopback:
         pass
 
 
+def self_launch(args):
+    """--gpus N > 1 without a launcher around us: start the N ranks ourselves (torch.distributed.run as a CHILD process,
+    before this process has touched a GPU — no re-exec) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("CDC_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()            # counts devices without initialising the runtime
+    if not rehearsal and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["CDC_BENCH_CHILD"] = "1"
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{") and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc else (0 if line is not None else 1)
+
+
+def replay_depth(opt):
+    """Mean number of L2-only steps the NEXT slice flush replays per row (host-synchronising; called outside the timed
+    region).  In steady state this is flush_every for rows not looked up since their slice's last flush and less for the
+    others; right after start-up (last[] = 0 everywhere) it is only the step count — the state BENCH_r01 was timed in."""
+    if opt.table_mode != "lazy" or opt.flush_every <= 1:
+        return None
+    t = int(opt.step_dev.item())                 # the next step is t+1; its slice flush brings slice (t mod P) up to step t
+    R, P = opt.table.shape[0], opt.flush_every
+    rps = -(-R // P)
+    lo = (t % P) * rps
+    hi = min(lo + rps, R)
+    if lo >= hi:
+        return None
+    last = opt.table_last[lo:hi]
+    if opt.own_mod > 1:
+        rows = torch.arange(lo, hi, device=last.device)
+        last = last[rows % opt.own_mod == opt.own_rem]
+    return float((t - last.double()).clamp_(min=0).mean().item())
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world == 1 and args.gpus > 1 and os.environ.get("CDC_BENCH_CHILD") != "1":
+        raise SystemExit(self_launch(args))
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     from cdcmdr_amd.dist import DataParallel
     from cdcmdr_amd.optim import FusedAdam
@@ -180,48 +237,69 @@ def main():
 
     model, field_dims = build_model(args, device)
     table_mode = args.table_mode
-    use_graph = bool(args.graph)        # under DP the three launch stages between the collectives are graphs
+    use_graph = bool(args.graph)        # under DP the launch stages between the collectives are graphs
     opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode,
                     flush_every=args.flush_every)
-    ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dp or sim, sync_bn=bool(args.sync_bn),
+    dist_obj = dp or sim
+    ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dist_obj, sync_bn=bool(args.sync_bn),
                    table_dist=args.table_dist)
+    # N>1: the headline runs with global-batch BatchNorm statistics (the parity semantic); the per-rank-statistics step
+    # (torch DDP without SyncBatchNorm) is timed beside it on the same model and optimiser state
+    ts_local = None
+    if dp is not None and world > 1 and args.sync_bn:
+        ts_local = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dp, sync_bn=False,
+                             table_dist=args.table_dist)
 
     B = args.batch
+    if args.preroll < 0:
+        args.preroll = (args.flush_every + int(opt.scalars.shape[0]) + 64) if table_mode == "lazy" else 8
     if args.pool <= 0:
-        args.pool = max(8, min(args.warmup + args.steps, 1024))
+        args.pool = max(8, min(args.preroll + args.warmup + args.steps, 1024))
     # every rank draws its own shard of the synthetic stream (same generator, rank-offset seed)
     Xr, yr = make_dataset(B * args.pool, field_dims, n_domain=3, domain_idx=10, seed=2000 + rank, dist=args.id_dist)
     gr = Xr[:, 10].astype(np.int64)                            # identity domain -> tower map (3-domain PLE)
     Xd = torch.from_numpy(Xr).to(device).view(args.pool, B, -1)
     yd = torch.from_numpy(yr).to(device).view(args.pool, B)
     gd = torch.from_numpy(gr).to(device).view(args.pool, B)
+    cursor = [0]
 
-    def run(n, first=0):
-        for i in range(n):
-            j = (first + i) % args.pool
-            ts.step(Xd[j], yd[j], gd[j])
+    def run(step_obj, n):
+        for _ in range(n):
+            j = cursor[0] % args.pool
+            cursor[0] += 1
+            step_obj.step(Xd[j], yd[j], gd[j])
 
-    run(args.warmup)
-    if dp:
-        dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    torch.cuda.synchronize()
-    if dp:
-        dp.barrier()
-    elapsed = time.perf_counter() - t0
-    if dp:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dp.all_reduce_max(tmax)
-        elapsed = float(tmax.item())
+    def timed(step_obj, n):
+        if dp:
+            dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(step_obj, n)
+        torch.cuda.synchronize()
+        if dp:
+            dp.barrier()
+        el = time.perf_counter() - t0
+        if dp:
+            tmax = torch.tensor([el], dtype=torch.float64, device=device)
+            dp.all_reduce_max(tmax)
+            el = float(tmax.item())
+        return el
+
+    run(ts, args.preroll)                        # untimed, independent of --warmup: reach the steady state
+    run(ts, args.warmup)
+    depth = replay_depth(opt)
+    elapsed = timed(ts, args.steps)
     loss_val = float(ts.loss.item())
+    elapsed_local = None
+    if ts_local is not None:
+        run(ts_local, max(args.warmup, 4))
+        elapsed_local = timed(ts_local, args.steps)
 
     # ---- roofline of the dominant kernel, HIP events on the launch stream (instrumented eager steps) ----------
     roof = measure_roofline(args, ts, opt, Xd, yd, gd)
 
     cpu = None
-    if args.cpu_baseline and world == 1 and rank == 0:
+    if args.cpu_baseline and world == 1 and rank == 0 and sim is None:
         Xc = [Xr[i * B:(i + 1) * B] for i in range(min(args.pool, 1 + args.cpu_steps))]
         yc = [yr[i * B:(i + 1) * B].astype(np.float32) for i in range(len(Xc))]
         gc = [gr[i * B:(i + 1) * B] for i in range(len(Xc))]
@@ -237,6 +315,7 @@ def main():
     roof.pop("breakdown_all", None)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        steady = table_mode != "lazy" or args.preroll >= args.flush_every + int(opt.scalars.shape[0])
         out = {
             "metric": METRIC, "value": B * world * args.steps / elapsed, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -248,9 +327,14 @@ def main():
                        "hip_graph": use_graph, "id_dist": args.id_dist, "parallelism": f"dp{world}", "attention_branch": bool(args.atten),
                        "table_dist": ts.table_dist if world > 1 else None,
                        "bn_stats": None if world == 1 else ("global batch (sync)" if args.sync_bn else "per rank"),
+                       "steady_state": bool(steady), "preroll_steps": args.preroll,
+                       "mean_replay_depth_of_next_slice_flush": depth, "flush_every": args.flush_every if table_mode == "lazy" else None,
                        "last_bce_loss": loss_val},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if elapsed_local is not None:
+            out["value_per_rank_bn"] = B * world * args.steps / elapsed_local
+            out["ms_per_step_per_rank_bn"] = elapsed_local / args.steps * 1e3
         print(json.dumps(out), flush=True)
     if dp:
         dp.close()
@@ -262,27 +346,32 @@ _KERNEL_OF = {"cdc_embed_lazy_flush(slice)": "k_lazy_flush", "cdc_embed_adam_den
 
 
 def profiled_traffic(call_name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/round1/pmc_default_fetch_write.txt: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, KB per dispatch;
-    gfx950 reports half of a wide coalesced read, hence fetch x 2).  Not collected live: counters need the profiler."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "pmc_default_fetch_write.txt")
+    """HBM bytes per launch of the dominant kernel.  NOT measured in this run (counters need the profiler around the
+    process): read from the newest committed PMC summary of this same command (profiles/roundN/pmc_default_fetch_write.txt:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, KB per dispatch; gfx950 reports half of a wide coalesced read,
+    hence fetch x 2).  The source file is named in the line so that a stale figure can be told from a fresh one."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     kern = _KERNEL_OF.get(call_name)
-    if kern is None or not os.path.exists(path):
+    if kern is None or not os.path.isdir(root):
         return None, None
-    fetch = write = None
-    cur = None
-    for line in open(path):
-        if not line.startswith(" "):
-            cur = line
-        elif cur is not None and kern in cur:
-            parts = line.split()
-            if parts[0] == "FETCH_SIZE":
-                fetch = float(parts[1])
-            elif parts[0] == "WRITE_SIZE":
-                write = float(parts[1])
-    if fetch is None or write is None:
-        return None, None
-    return fetch * 1024 * 2 + write * 1024, "profiles/round1/pmc_default_fetch_write.txt (rocprofv3 --pmc, per dispatch)"
+    for rnd in sorted((d for d in os.listdir(root) if d.startswith("round")), reverse=True):
+        path = os.path.join(root, rnd, "pmc_default_fetch_write.txt")
+        if not os.path.exists(path):
+            continue
+        fetch = write = None
+        cur = None
+        for line in open(path):
+            if not line.startswith(" "):
+                cur = line
+            elif cur is not None and kern in cur:
+                parts = line.split()
+                if parts[0] == "FETCH_SIZE":
+                    fetch = float(parts[1])
+                elif parts[0] == "WRITE_SIZE":
+                    write = float(parts[1])
+        if fetch is not None and write is not None:
+            return fetch * 1024 * 2 + write * 1024, f"profiles/{rnd}/pmc_default_fetch_write.txt (committed rocprofv3 --pmc passes, per dispatch; not live)"
+    return None, None
 
 
 def measure_roofline(args, ts, opt, Xd, yd, gd):

@@ -123,6 +123,10 @@ class CDCTrainer:
         self.model.save_model_state()
 
     def _restore(self):
+        # the reference restores the WEIGHTS only (cdc.py:351-354): the Adam moments of every row keep the k probe steps they
+        # have lived through under its dense optimiser.  Lazy table: replay those steps for the rows that were not looked up
+        # (flush) BEFORE the weights are overwritten, then mark every row current.
+        self.opt.flush_table()
         self.model.load_model_state()
         if self.opt.table_mode == "lazy":                             # the restored rows ARE the current values
             self.opt.table_last.fill_(int(self.opt.step_dev.item()))
@@ -171,6 +175,7 @@ class CDCTrainer:
                 if self.log is not None:
                     self.log(float(acc) / log_interval)
                 acc = 0.0
+                self.check_ids()
 
         if epoch_i == 0:                                              # warm-up on the tower mean
             for _ in range(self.warmup_step):
@@ -183,4 +188,10 @@ class CDCTrainer:
             if (epoch_i == 0 and i == 0) or (self.update_interval > 0 and (i + 1) % self.update_interval == 0):
                 self.update_matrix()
             account(*self._step(X, y, "split", domain_i=int(d)))
+        self.check_ids()
         return len(self.seq)
+
+    def check_ids(self):
+        """host-synchronising: IndexError if any resident step has seen an out-of-range id since the last check"""
+        for ts in list(self._steps.values()):
+            ts.check_ids()

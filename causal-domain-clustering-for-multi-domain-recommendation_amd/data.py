@@ -46,10 +46,11 @@ class DeviceLoader:
         self.tensors, self.batch_size, self.shuffle = tuple(tensors), int(batch_size), bool(shuffle)
         self.rank, self.world, self.generator = int(rank), int(world), generator
         self.n = n
+        self.dropped_rows = 0             # data parallel: rows of the ragged last global batch of the last epoch (not trained on)
 
     def __len__(self):
         g = self.batch_size * self.world
-        return (self.n + g - 1) // g
+        return self.n // g if self.world > 1 else (self.n + g - 1) // g
 
     def _order(self):
         if not self.shuffle:
@@ -75,9 +76,12 @@ class DeviceLoader:
         for lo in range(0, self.n, step):
             hi = min(lo + step, self.n)
             if self.world > 1:
-                # the rank's contiguous share of the global batch; the ragged last batch is split as evenly as it goes
-                per = -(-(hi - lo) // self.world)
-                a, b = min(lo + self.rank * per, hi), min(lo + (self.rank + 1) * per, hi)
+                # the rank's contiguous share of the global batch.  A ragged last global batch is not yielded at all: split
+                # unevenly, some ranks would hold a full local batch and run the step's collectives while others skip it
+                if hi - lo < step:
+                    self.dropped_rows = hi - lo
+                    return
+                a, b = lo + self.rank * self.batch_size, lo + (self.rank + 1) * self.batch_size
             else:
                 a, b = lo, hi
             if perm is None:
@@ -140,7 +144,9 @@ def train_epoch(step, loader, log_interval=None, log=None):
     """`Run.train` (run.py:470-497) on a TrainStep: one pass over the loader; every `log_interval` batches (reference:
     204800 // bs) the mean of loss + regularisation term is reported through `log(mean)` — the only host synchronisation.
     The ragged last batch of an epoch is trained on like any other (a sibling step of that size on the same model and
-    optimiser state); under data parallelism it is skipped and counted.  Returns (batches run, batches skipped)."""
+    optimiser state); under data parallelism the loader does not yield it (every rank skips the same global batch).
+    Out-of-range ids and row-list overflows are surfaced at the logging synchronisations and at the end of the epoch
+    (`step.check_ids()`: IndexError like nn.Embedding's).  Returns (batches run, batches skipped)."""
     if log_interval is None:
         log_interval = max(1, 204800 // step.B)
     acc = torch.zeros((), dtype=torch.float64, device=step.device)
@@ -160,4 +166,10 @@ def train_epoch(step, loader, log_interval=None, log=None):
             if log is not None:
                 log(float(acc.item()) / log_interval)
             acc.zero_()
+            ts.check_ids()                       # the host is synchronised here anyway
+    step.check_ids()
+    for sib in step.__dict__.get("_siblings", {}).values():
+        sib.check_ids()
+    if getattr(loader, "dropped_rows", 0):
+        skipped += 1
     return done, skipped

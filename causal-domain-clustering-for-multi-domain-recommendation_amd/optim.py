@@ -311,7 +311,14 @@ class FusedAdam:
                 self.table_m.copy_(st["exp_avg"])
                 self.table_v.copy_(st["exp_avg_sq"])
             else:
-                self.state[id(p)] = (st["exp_avg"].to(self.device).clone(), st["exp_avg_sq"].to(self.device).clone())
+                # cdc_adam_multi's argument blocks (and any hipGraph captured from them) hold the moment POINTERS: restore into
+                # the tensors that already exist, allocate only what the optimiser has never seen
+                have = self.state.get(id(p))
+                if have is not None and have[0].shape == st["exp_avg"].shape:
+                    have[0].copy_(st["exp_avg"])
+                    have[1].copy_(st["exp_avg_sq"])
+                else:
+                    self.state[id(p)] = (st["exp_avg"].to(self.device).clone(), st["exp_avg_sq"].to(self.device).clone())
+                    self._dense_sig = None
         if self.table_last is not None:
             self.table_last.fill_(int(sd["step"]))
-        self._dense_sig = None

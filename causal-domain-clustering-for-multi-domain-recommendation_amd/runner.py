@@ -26,6 +26,15 @@ class Runner:
         else:
             self.step.opt.flush_table()
 
+    def _rank(self):
+        d = getattr(self.step, "dist", None)
+        return 0 if d is None else int(getattr(d, "rank", 0))
+
+    def _barrier(self):
+        d = getattr(self.step, "dist", None)
+        if d is not None and getattr(self.step, "world", 1) > 1:
+            d.barrier()
+
     def is_continuable(self, result_dict, epoch_i):
         score = result_dict.get("mean_auc")
         best = self.best_mean_auc
@@ -42,7 +51,8 @@ class Runner:
             if hasattr(self.model, "domain2group_list"):
                 save["domain2group_list"] = [int(v) for v in self.model.domain2group_list]
                 save["s_group2domain_list"] = [[int(v) for v in g] for g in self.model.s_group2domain_list]
-            torch.save(save, self.save_model_path)
+            if self._rank() == 0:                # one writer; the other ranks hold the same state after _sync_table()
+                torch.save(save, self.save_model_path)
             self.log(f"current best epoch: {epoch_i + 1}, auc: {self.best_auc:.4f}, loss: {self.best_loss:.4f}")
             return True
         if self.trial_counter + 1 < self.num_trials:
@@ -63,6 +73,7 @@ class Runner:
             self.log(f"validation: auc: {result['total_auc']:.4f}, loss: {result['total_loss']:.4f}")
             if not self.is_continuable(result, epoch_i):
                 break
+        self._barrier()                          # rank 0's last save is complete before anyone reads it
         ck = torch.load(self.save_model_path, map_location=self.step.device, weights_only=False)     # our own file (result dicts inside)
         self.model.load_state_dict(ck["state_dict"])
         self.step.opt.load_state_dict(ck["optimizer"])

@@ -119,7 +119,8 @@ class TrainStep:
         was = model.training
         model.train(self.train_mode)                 # the ops read module.training while describing themselves
         try:
-            return model._cache().get(model, ("train_step", id(opt), self.train_mode, self.mode == "star"), B, build)
+            return model._cache().get(model, ("train_step", id(opt), self.train_mode, self.mode == "star",
+                                               bool(self.sync_bn and self.dp_on)), B, build)
         finally:
             model.train(was)
 

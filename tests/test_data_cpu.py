@@ -51,11 +51,31 @@ def test_rank_shards_partition_every_global_batch():
     for r in range(world):
         torch.manual_seed(7)
         parts.append([b for b in DeviceLoader((X, y), bs, shuffle=True, rank=r, world=world)])
-    assert all(len(p) == len(whole) for p in parts)
-    for i, b in enumerate(whole):
+    # 1003 rows = 5 whole global batches of 200 + 3 ragged rows, which NO rank yields
+    assert all(len(p) == len(whole) - 1 == 5 for p in parts)
+    for i, b in enumerate(whole[:-1]):
         cat = torch.cat([parts[r][i][0] for r in range(world)])
         assert torch.equal(cat, b[0])                            # rank order == batch order (the DP parity definition)
-    assert all(parts[r][0][0].shape[0] == bs for r in range(world))
+    assert all(b[0].shape[0] == bs for p in parts for b in p)
+
+
+@pytest.mark.parametrize("n", [2 * 3 * 64 - 1, 2 * 3 * 64 + 3 * 64 - 1, 7])
+def test_every_rank_runs_the_same_number_of_full_batches(n):
+    """The ragged last GLOBAL batch (here one row short of world*B, the case where ceil-splitting gave every rank but the last a
+    full batch) must be skipped by all ranks alike: a rank that runs the step issues collectives the others never join."""
+    from cdcmdr_amd.data import DeviceLoader
+    X, y = _data(n=n)
+    world, bs = 3, 64
+    counts = []
+    for r in range(world):
+        torch.manual_seed(3)
+        dl = DeviceLoader((X, y), bs, shuffle=True, rank=r, world=world)
+        batches = list(dl)
+        assert all(b[0].shape[0] == bs for b in batches)
+        assert len(batches) == len(dl) == n // (world * bs)
+        assert dl.dropped_rows == n % (world * bs)
+        counts.append(len(batches))
+    assert len(set(counts)) == 1
 
 
 def test_split_files_round_trip_and_make_loader(tmp_path):

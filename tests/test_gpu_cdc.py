@@ -111,3 +111,44 @@ def test_cdc_training_loop_runs_end_to_end(cuda, tmp_path, monkeypatch):
         assert bool(torch.isfinite(p).all())
     tr.train_epoch(1)                                        # no warm-up, no forced update at i == 0
     assert tr.training is False or tr.training is True
+
+
+def test_update_matrix_keeps_dense_and_lazy_table_moments_bit_equal(cuda, tmp_path, monkeypatch):
+    """update_matrix() probes (train k steps, evaluate, restore the WEIGHTS): the reference's dense Adam advances the moments
+    of every table row during the probes and only the weights come back (run.py:528-594, cdc.py:343-354).  The lazy table
+    must land on the same moments: exact replay (fast_replay=False) == the dense table mode, bit for bit."""
+    import types
+    from cdcmdr_amd.cdc_trainer import CDCTrainer
+    from cdcmdr_amd.data import make_domain_loaders
+    from cdcmdr_amd.model.cdc import CDC
+    from cdcmdr_amd.optim import FusedAdam
+    monkeypatch.chdir(tmp_path)
+    n_domain, n_cluster, domain_idx, bs = 6, 2, 4, 64
+    fd = [7, 300, 3, 50, n_domain, 29]
+    res = {}
+    for table_mode in ("dense", "lazy"):
+        rng = np.random.default_rng(0)
+        n = 1500
+        X = torch.from_numpy(make_ids(rng, n, fd))
+        y = torch.from_numpy(rng.integers(0, 2, size=(n, 1)).astype(np.int16))
+        np.random.seed(1)
+        torch.manual_seed(1)
+        loaders, seq, w = make_domain_loaders(X, y, bs, cuda, domain_idx, n_domain)
+        cfg = types.SimpleNamespace(mmoe_n_expert=3, dataset_name="t", p_weight=0.5, p_weight_method="linear_decay", p_weight_exp_decay=0.9,
+                                    old_matrix_weight=0.3, affinity_func="minus", use_atten=False)
+        cdc = CDC(fd, 4, n_cluster, n_domain, "mmoe", (16, 8), (8,), domain_idx, domain_cnt_weight=w, n_causal_mask=2, use_metric="loss",
+                  device=cuda, dropout=0.0, config=cfg).to(cuda).set_precision("f32")
+        opt = FusedAdam(cdc.base_model_instance, table_mode=table_mode, fast_replay=False, flush_every=4)
+        tr = CDCTrainer(cdc, opt, bs, loaders, n_domain, w, seq, warmup_step=1, update_matrix_step=1, update_interval=0)
+        tr.warmup_step, tr.update_matrix_step = 3, 2
+        for _ in range(3):                                        # a few ordinary steps first, so the moments are not all zero
+            Xb, yb = tr.get_domain_data(0)
+            tr._step(Xb, yb, "split", domain_i=0)
+        tr.update_matrix()
+        opt.flush_table()
+        res[table_mode] = (opt.table_m.cpu().clone(), opt.table_v.cpu().clone(),
+                           cdc.base_model_instance.embedding.embedding_dict.weight.detach().cpu().clone(), int(opt.step_dev.item()))
+    assert res["dense"][3] == res["lazy"][3] > 3
+    assert torch.equal(res["dense"][2], res["lazy"][2]), "table weights differ"
+    assert torch.equal(res["dense"][0], res["lazy"][0]), "exp_avg of the table differs after update_matrix()"
+    assert torch.equal(res["dense"][1], res["lazy"][1]), "exp_avg_sq of the table differs after update_matrix()"

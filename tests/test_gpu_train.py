@@ -390,6 +390,58 @@ def test_checkpoint_resume_continues_bit_identically(cuda, tmp_path, table_mode)
     assert torch.equal(opt.table_m.cpu(), want_m)
 
 
+def test_load_state_dict_into_a_graph_captured_step(cuda):
+    """A captured hipGraph holds the moment POINTERS of cdc_adam_multi's argument blocks: load_state_dict must restore into the
+    existing tensors.  Three steps (the third replayed from the graph), a checkpoint, three more steps, then the checkpoint
+    loaded back INTO THE SAME warmed objects and the three steps repeated == a fresh model + optimiser resumed from the same
+    checkpoint, bit for bit (what Runner.fit does when it reloads the best checkpoint into its live TrainStep)."""
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [50, 3000, 7, 900]
+
+    def make():
+        torch.manual_seed(11)
+        model = PLE(fd, 8, 3, 1, 1, ((16,), (8,)), (8,), dropout=0.0).to(cuda).set_precision("f32")
+        return model, FusedAdam(model, table_mode="lazy", fast_replay=False, flush_every=4)
+
+    r = np.random.default_rng(5)
+    batches = [(torch.from_numpy(make_ids(r, 128, fd)).to(cuda), torch.from_numpy(r.integers(0, 2, size=128).astype(np.int16)).to(cuda),
+                torch.from_numpy(r.integers(0, 3, size=128).astype(np.int64)).to(cuda)) for _ in range(6)]
+    model, opt = make()
+    ts = TrainStep(model, opt, 128, use_graph=True)
+    for b in batches[:3]:
+        ts.step(*b)
+    assert ts.graph is not None                                          # step 3 was captured and replayed
+    ck = {"state_dict": {k: v.detach().clone() for k, v in model.state_dict().items()}, "optimizer": opt.state_dict()}
+    ptrs = {k: (m.data_ptr(), v.data_ptr()) for k, (m, v) in opt.state.items()}
+    for b in batches[3:]:
+        ts.step(*b)                                                      # moves weights and moments away from the checkpoint
+    model.load_state_dict(ck["state_dict"])
+    opt.load_state_dict(ck["optimizer"])
+    assert {k: (m.data_ptr(), v.data_ptr()) for k, (m, v) in opt.state.items()} == ptrs, "moment tensors were re-allocated"
+    for b in batches[3:]:
+        ts.step(*b)                                                      # graph replays on the restored state
+    opt.flush_table()
+    got = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    got_m = {k: m.cpu().clone() for k, (m, _) in opt.state.items()}
+    names = {id(p): n for n, p in model.named_parameters()}
+    got_m = {names[k]: v for k, v in got_m.items()}
+
+    model2, opt2 = make()
+    model2.load_state_dict(ck["state_dict"])
+    opt2.load_state_dict(ck["optimizer"])
+    ts2 = TrainStep(model2, opt2, 128)
+    for b in batches[3:]:
+        ts2.step(*b)
+    opt2.flush_table()
+    names2 = {id(p): n for n, p in model2.named_parameters()}
+    for k, v in model2.state_dict().items():
+        assert torch.equal(v.cpu(), got[k]), f"{k} differs between the in-place restore and a fresh resume"
+    for k, (m, _) in opt2.state.items():
+        assert torch.equal(m.cpu(), got_m[names2[k]]), f"exp_avg of {names2[k]} differs"
+
+
 def test_runner_fit_keeps_the_best_checkpoint_and_stops_early(cuda, tmp_path):
     """Run.main / is_continuable (run.py:440-468, 713-770) on the HIP path: epochs of training, validation through the
     device-side evaluator, best checkpoint by mean_auc, early stop, reload of the best model, test-set evaluation."""
