@@ -68,9 +68,45 @@ class TransposeArgs(C.Structure):
     _fields_ = [("n", c_i32), ("pad_", c_i32), ("bf16_mask", C.c_uint64), ("t", TransposeItem * MAX_TENSORS)]
 
 
+G2_MAX_OUT = 24
+G2_MAX_SEG = 32
+
+
+class G2Out(C.Structure):
+    _fields_ = [("y", c_p), ("ldy", c_i64), ("yh", c_p), ("ldyh", c_i64), ("bias", c_p), ("mask", c_p), ("ldmask", c_i64),
+                ("bn_partial", c_p), ("M", c_i32), ("N", c_i32), ("act_cols", c_i32), ("accumulate", c_i32), ("mask_bf16", c_i32),
+                ("bn_col0", c_i32), ("bn_total_c", c_i32), ("stream_id", c_i32)]
+
+
+class G2Seg(C.Structure):
+    _fields_ = [("a", c_p), ("lda", c_i64), ("b", c_p), ("ldb", c_i64), ("Kr", c_i32), ("out", c_i32)]
+
+
+class G2Args(C.Structure):
+    _fields_ = [("n_out", c_i32), ("n_seg", c_i32), ("mode", c_i32), ("relu", c_i32), ("drop_p", c_f), ("mask_scale", c_f),
+                ("tile_cfg", c_i32), ("pad_", c_i32), ("seed", C.c_uint64), ("seed_offset_dev", c_p), ("o", G2Out * G2_MAX_OUT), ("s", G2Seg * G2_MAX_SEG)]
+
+
+class WShadowItem(C.Structure):
+    _fields_ = [("src", c_p), ("dst_h", c_p), ("ld_h", c_i64), ("dst_t", c_p), ("ld_t", c_i64), ("rows", c_i32), ("cols", c_i32)]
+
+
+class WShadowArgs(C.Structure):
+    _fields_ = [("n", c_i32), ("pad_", c_i32), ("t", WShadowItem * MAX_TENSORS)]
+
+
+class ShadowItem(C.Structure):
+    _fields_ = [("src", c_p), ("ld_src", c_i64), ("dst", c_p), ("ld_dst", c_i64), ("rows", c_i64), ("cols", c_i32), ("pad_", c_i32)]
+
+
+class ShadowArgs(C.Structure):
+    _fields_ = [("n", c_i32), ("pad_", c_i32), ("t", ShadowItem * MAX_GROUPS)]
+
+
 class BwdwGroup(C.Structure):
     _fields_ = [("dz", c_p), ("lddz", c_i64), ("x", c_p), ("ldx", c_i64), ("dw", c_p), ("lddw", c_i64),
-                ("db", c_p), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("accumulate", c_i32)]
+                ("db", c_p), ("M", c_i32), ("N", c_i32), ("K", c_i32), ("accumulate", c_i32),
+                ("dzh", c_p), ("lddzh", c_i64), ("xh", c_p), ("ldxh", c_i64)]
 
 
 class LinBwdwArgs(C.Structure):
@@ -193,6 +229,9 @@ _SIGNATURES = {
     "cdc_glinear_fwd": (c_i32, [C.POINTER(LinFwdArgs), c_i32, c_p]),
     "cdc_glinear_bwd_x": (c_i32, [C.POINTER(LinBwdxArgs), c_i32, c_p]),
     "cdc_transpose_multi": (c_i32, [C.POINTER(TransposeArgs), c_p]),
+    "cdc_gemm_bf16_nt": (c_i32, [C.POINTER(G2Args), c_p]),
+    "cdc_weight_shadows": (c_i32, [C.POINTER(WShadowArgs), c_p]),
+    "cdc_shadow_bf16": (c_i32, [C.POINTER(ShadowArgs), c_p]),
     "cdc_glinear_bwd_w": (c_i32, [C.POINTER(LinBwdwArgs), c_i32, c_p]),
     "cdc_gate_pool_fwd": (c_i32, [C.POINTER(PoolFwdArgs), c_p]),
     "cdc_gate_pool_bwd": (c_i32, [C.POINTER(PoolBwdArgs), c_p]),

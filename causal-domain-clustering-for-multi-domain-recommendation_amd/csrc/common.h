@@ -27,6 +27,10 @@ void cdc_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// gemm2.hip: grad-weight from bf16 shadows (called by cdc_glinear_bwd_w)
+int g2_launch_bwd_w(const cdc_lin_bwdw_args* a, int64_t slab_stride, hipStream_t st);
+bool g2_bwd_w_uses_small_tiles(const cdc_lin_bwdw_args* a);
+
 static inline int64_t cdc_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------------

@@ -1104,7 +1104,12 @@ extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void*
     const int64_t grid = t64 * S;
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "glinear_bwd_w: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    if (prec == CDC_PREC_BF16)
+    bool shadows = prec == CDC_PREC_BF16 && !a->row_offsets;
+    for (int g = 0; g < a->n_groups && shadows; ++g) shadows = a->g[g].dzh != nullptr && a->g[g].xh != nullptr;
+    if (shadows) {
+        const int rc = g2_launch_bwd_w(a, slab, st);
+        if (rc) return rc;
+    } else if (prec == CDC_PREC_BF16)
         hipLaunchKernelGGL(k_glinear_bwd_w_tr, dim3(grid), dim3(GEMM_THREADS), 0, st, *a, slab);
     else
         hipLaunchKernelGGL((k_glinear_bwd_w<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a, slab);

@@ -111,14 +111,18 @@ class TView:
 class _GradState:
     """Tracks which column intervals of a root gradient tensor the backward sequence has initialised."""
 
-    def __init__(self):
+    def __init__(self, plan=None):
         self.done = {}      # id(root) -> list of (c0, c1)
+        self.plan = plan
 
     def claim(self, buf):
         """Returns True if `buf`'s gradient region is already initialised (=> accumulate), else marks it."""
         key = id(buf.root)
         iv = self.done.setdefault(key, [])
         c0, c1 = buf.col0, buf.col0 + buf.cols
+        if self.plan is not None:
+            # whoever claims the region is about to write it: a bf16 shadow of the gradient written earlier is stale from here on
+            self.plan.invalidate_shadow(buf.grad)
         for a, b in iv:
             if a <= c0 and c1 <= b:
                 return True
@@ -184,6 +188,12 @@ class Plan:
         self._deferred_dw = []            # grad-weight groups of every layer, launched together at the end of backward
         self.finalized = False
         self.loss_inputs = None
+        # bf16 contraction path with operands that are bf16 in memory (csrc/gemm2.hip): shadows of activations, gradients, weights
+        self.use_g2 = self.prec == L.PREC_BF16 and os.environ.get("CDC_GEMM2", "1") != "0"
+        self._shadows = {}                # id(fp32 root) -> (root, bf16 tensor [rows64, cols64 + 64], zero padded)
+        self._sh_have = {}                # id(root) -> [(c0, c1)] columns whose shadow is current at this point of the sequence
+        self._sh_wanted = {}              # id(root) -> [(c0, c1)] columns some contraction reads through the shadow
+        self._wsh = {}                    # weight key -> (weight, straight copy [N, K64], transposed copy [K, N64])
 
     # ---------------------------------------------------------------- buffers
     def new(self, cols, rows=None, dtype=torch.float32):
@@ -286,9 +296,16 @@ class Plan:
         for chunk in launches:
             a = L.LinBwdwArgs()
             a.n_groups = len(chunk)
-            tiles = sum(math.ceil(g["N"] / 64) * math.ceil(g["K"] / 64) for g in chunk)
             Mmax = max(g["M"] for g in chunk)
-            S = max(1, min(1024 // max(tiles, 1), max(Mmax // 128, 1), 64))       # 1024: measured best of 384…2560 at C2
+            if all(g.get("dzh") is not None for g in chunk):
+                # shadows (csrc/gemm2.hip k_g2_tn): 128x128 output tiles unless every group is at most 64x64; a row slice of at least
+                # four 64-row slabs per workgroup
+                T = 64 if all(g["N"] <= 64 and g["K"] <= 64 for g in chunk) else 128
+                tiles = sum(math.ceil(g["N"] / T) * math.ceil(g["K"] / T) for g in chunk)
+                S = max(1, min(int(os.environ.get("CDC_DW_BLOCKS", "768")) // max(tiles, 1), max(Mmax // 256, 1), 32))
+            else:
+                tiles = sum(math.ceil(g["N"] / 64) * math.ceil(g["K"] / 64) for g in chunk)
+                S = max(1, min(1024 // max(tiles, 1), max(Mmax // 128, 1), 64))       # 1024: measured best of 384…2560 at C2
             a.split_k = S
             if S > 1:
                 self.need_gemm_ws(S * sum(g["N"] * g["K"] + g["N"] for g in chunk))
@@ -298,6 +315,10 @@ class Plan:
                 G.dz, G.lddz, G.x, G.ldx = g["dz"], g["lddz"], g["x"], g["ldx"]
                 G.dw, G.lddw, G.db = g["dw"], g["lddw"], g["db"]
                 G.M, G.N, G.K, G.accumulate = g["M"], g["N"], g["K"], g["accumulate"]
+                if g.get("dzh") is not None:
+                    (G.dzh, G.lddzh), (G.xh, G.ldxh) = g["dzh"], g["xh"]
+                else:
+                    G.dzh = G.xh = None
             self._keep_args = getattr(self, "_keep_args", []) + [a]
             fl = sum(2.0 * g["M"] * g["N"] * g["K"] for g in chunk)
             steps.append((a, fl))
@@ -309,6 +330,107 @@ class Plan:
     def need_rowdot_ws(self, n):
         self._rowdot_ws_need = max(self._rowdot_ws_need, n)
 
+    # ---------------------------------------------------------------- bf16 shadows (gemm2)
+    def _shadow_root(self, root):
+        hit = self._shadows.get(id(root))
+        if hit is None:
+            rows, cols = root.shape
+            t = torch.zeros(((rows + 63) // 64 * 64, (cols + 63) // 64 * 64 + 128), dtype=torch.bfloat16, device=self.device)
+            hit = (root, t)
+            self._shadows[id(root)] = hit
+        return hit[1]
+
+    def shadow_view(self, buf):
+        """(address, row stride in elements) of buf's columns inside the bf16 shadow of its root"""
+        t = self._shadow_root(buf.root)
+        return t.data_ptr() + 2 * buf.col0, t.stride(0)
+
+    @staticmethod
+    def _iv_covered(table, buf):
+        c0, c1 = buf.col0, buf.col0 + buf.cols
+        return any(a <= c0 and c1 <= b for a, b in table.get(id(buf.root), []))
+
+    @staticmethod
+    def _iv_add(table, buf):
+        iv = table.setdefault(id(buf.root), [])
+        iv.append((buf.col0, buf.col0 + buf.cols))
+        iv.sort()
+        merged = [iv[0]]
+        for a, b in iv[1:]:
+            if a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        iv[:] = merged
+
+    def want_shadow(self, buf):
+        self._iv_add(self._sh_wanted, buf)
+
+    def shadow_wanted(self, buf):
+        c0, c1 = buf.col0, buf.col0 + buf.cols
+        return any(a < c1 and c0 < b for a, b in self._sh_wanted.get(id(buf.root), []))
+
+    def mark_shadow(self, buf):
+        self._iv_add(self._sh_have, buf)
+
+    def has_shadow(self, buf):
+        return self._iv_covered(self._sh_have, buf)
+
+    def invalidate_shadow(self, buf):
+        iv = self._sh_have.get(id(buf.root))
+        if iv:
+            c0, c1 = buf.col0, buf.col0 + buf.cols
+            iv[:] = [(a, b) for a, b in iv if not (a < c1 and c0 < b)]
+
+    def ensure_shadows(self, bufs, steps):
+        """one conversion launch (appended to `steps`) for those of `bufs` whose shadow no producer has written"""
+        todo = []
+        for b in bufs:
+            if not self.has_shadow(b) and not any(t.root is b.root and t.col0 == b.col0 and t.cols == b.cols for t in todo):
+                todo.append(b)
+        for c0 in range(0, len(todo), L.MAX_GROUPS):
+            chunk = todo[c0:c0 + L.MAX_GROUPS]
+            a = L.ShadowArgs()
+            a.n = len(chunk)
+            for i, b in enumerate(chunk):
+                T = a.t[i]
+                T.src, T.ld_src = b.ptr, b.ld
+                T.dst, T.ld_dst = self.shadow_view(b)
+                T.rows, T.cols = b.rows, b.cols
+                self.mark_shadow(b)
+            self._keep_args = getattr(self, "_keep_args", []) + [a]
+            steps.append(self.call("cdc_shadow_bf16", C.byref(a)))
+
+    def wshadow(self, w):
+        """bf16 copies of a linear weight [N,K], refreshed once per step ahead of the forward: the straight copy [N, K64]
+        (forward's B operand) and the transposed copy [K, N64] (grad-input's B operand), zero padded to whole K-slabs"""
+        key = (id(w.param), w.index) if isinstance(w, PView) else id(w)
+        hit = self._wsh.get(key)
+        if hit is None:
+            N, K = w.shape
+            h = torch.zeros((N, (K + 63) // 64 * 64), dtype=torch.bfloat16, device=self.device)
+            t = torch.zeros((K, (N + 63) // 64 * 64), dtype=torch.bfloat16, device=self.device)
+            hit = (w, h, t)
+            self._wsh[key] = hit
+        return hit[1], hit[2]
+
+    def _emit_wshadows(self):
+        steps = []
+        items = list(self._wsh.values())
+        for c0 in range(0, len(items), L.MAX_TENSORS):
+            chunk = items[c0:c0 + L.MAX_TENSORS]
+            a = L.WShadowArgs()
+            a.n = len(chunk)
+            for i, (w, h, t) in enumerate(chunk):
+                T = a.t[i]
+                T.src = w.data_ptr()
+                T.dst_h, T.ld_h = h.data_ptr(), h.stride(0)
+                T.dst_t, T.ld_t = t.data_ptr(), t.stride(0)
+                T.rows, T.cols = w.shape[0], w.shape[1]
+            self._keep_args = getattr(self, "_keep_args", []) + [a]
+            steps.append(self.call("cdc_weight_shadows", C.byref(a)))
+        return steps
+
     # ---------------------------------------------------------------- ops
     def add(self, op):
         self.ops.append(op)
@@ -319,7 +441,7 @@ class Plan:
         self._bn_ws = torch.empty(max(self._bn_ws_need, 1), dtype=torch.float64, device=self.device)
         self._rowdot_ws = torch.empty(max(self._rowdot_ws_need, 1), dtype=torch.float32, device=self.device)
         self._gemm_ws = torch.empty(max(self._gemm_ws_need, 1), dtype=torch.float32, device=self.device)
-        gs = _GradState()
+        gs = _GradState(self)
         for o in outputs:
             gs.claim(o)
             _ = o.grad
@@ -338,6 +460,7 @@ class Plan:
             self.bwd_steps.append(step)
             self.deferred_dw_steps.append(step)
         self.bwd_steps[0:0] = self._emit_transposes()
+        self.fwd_steps[0:0] = self._emit_wshadows()
         self.finalized = True
 
     def comm(self, fn):
@@ -372,6 +495,9 @@ class Plan:
     def call(self, fn_name, *args, what=None, flops=0.0, nbytes=0.0):
         fn = getattr(self.lib, fn_name)
         what = what or fn_name
+        if os.environ.get("CDC_PROFILE_DETAIL") == "1":          # one timing bucket per launch of the sequence, not per entry point
+            self._call_seq = getattr(self, "_call_seq", 0) + 1
+            what = f"{what}#{self._call_seq:03d}"
 
         def run(stream):
             L.launch(what, fn, args, stream, flops, nbytes)
@@ -437,6 +563,14 @@ class GLinear:
                 y.mask = (plan.keep_scale if self.drop_p > 0 else 1.0, g["act_cols"])
             g["y"] = y
             self.outs.append(y)
+        # bf16 operands from memory (csrc/gemm2.hip): plain weights, whole row range, 16-byte aligned column slices
+        self.g2 = (plan.use_g2 and row_offsets is None and self.M > 0 and
+                   all(isinstance(g["w"], (torch.Tensor, PView)) and not isinstance(g.get("b"), TView) for g in groups) and
+                   all(g["x"].col0 % 8 == 0 and g["y"].col0 % 8 == 0 for g in groups))
+        if self.g2:
+            for g in groups:
+                plan.want_shadow(g["x"])                  # forward and grad-weight read x through its shadow
+                plan.want_shadow(g["y"].grad)             # grad-input and grad-weight read dZ through its shadow
         # grad-weight split-K: enough (tile, row-slice) workgroups to fill 256 CUs several times over
         self.split_k = []
         for c0 in range(0, len(groups), L.MAX_GROUPS):
@@ -448,7 +582,40 @@ class GLinear:
                 plan.need_gemm_ws(S * sum(g["w"].numel() + g["w"].shape[0] for g in chunk))
         plan.add(self)
 
+    def _build_fwd_g2(self, plan):
+        plan.ensure_shadows([g["x"] for g in self.groups], plan.fwd_steps)
+        for c0 in range(0, len(self.groups), L.G2_MAX_OUT):
+            chunk = self.groups[c0:c0 + L.G2_MAX_OUT]
+            a = L.G2Args()
+            a.n_out = a.n_seg = len(chunk)
+            a.mode, a.relu, a.drop_p, a.mask_scale = 0, 1 if self.relu else 0, self.drop_p, 1.0
+            a.seed = (self.seed + c0) & 0xFFFFFFFFFFFFFFFF
+            a.seed_offset_dev = plan.step_dev.data_ptr()
+            for i, g in enumerate(chunk):
+                O, S = a.o[i], a.s[i]
+                N, K = g["w"].shape
+                y = g["y"]
+                O.y, O.ldy = y.ptr, y.ld
+                if plan.shadow_wanted(y):                  # a later contraction reads y: its shadow comes out of this epilogue
+                    O.yh, O.ldyh = plan.shadow_view(y)
+                    plan.mark_shadow(y)
+                else:
+                    O.yh = None
+                O.bias = None if g.get("b") is None else g["b"].data_ptr()
+                O.mask, O.bn_partial = None, None
+                O.M, O.N, O.act_cols, O.accumulate, O.mask_bf16, O.stream_id = self.M, N, g["act_cols"], 0, 0, i
+                S.a, S.lda = plan.shadow_view(g["x"])
+                wh, _ = plan.wshadow(g["w"])
+                S.b, S.ldb = wh.data_ptr(), wh.stride(0)
+                S.Kr, S.out = (K + 63) // 64 * 64, i
+                plan._lin_producer[(id(y.root), y.col0, y.cols)] = {"op": self, "G": O, "step": len(plan.fwd_steps), "taken": False}
+            self._keep = getattr(self, "_keep", []) + [a]
+            fl = sum(2.0 * self.M * g["w"].shape[0] * g["w"].shape[1] for g in chunk)
+            plan.fwd_steps.append(plan.call("cdc_gemm_bf16_nt", C.byref(a), what="cdc_glinear_fwd", flops=fl))
+
     def build_fwd(self, plan):
+        if self.g2:
+            return self._build_fwd_g2(plan)
         for c0 in range(0, len(self.groups), L.MAX_GROUPS):
             chunk = self.groups[c0:c0 + L.MAX_GROUPS]
             a = L.LinFwdArgs()
@@ -479,6 +646,8 @@ class GLinear:
         # dZ of every group lives in y.grad (pre-activation gradient, see module docstring)
         for g in self.groups:
             plan.ensure_grad(g["y"], gs)
+        if self.g2:                                  # grad-input and grad-weight read dZ through its bf16 shadow
+            plan.ensure_shadows([g["y"].grad for g in self.groups], plan.bwd_steps)
         # ---- grad-weight / grad-bias
         # leaf weights (parameters): deferred to one launch with every other layer's at the end of backward.
         # fused weights (STAR's W_d*W_s: their gradient feeds a further backward op) and ragged groups: right here.
@@ -496,7 +665,9 @@ class GLinear:
                     assert acc_b == acc_w
                     db = gb.data_ptr()
                 plan._deferred_dw.append({"dz": dz.ptr, "lddz": dz.ld, "x": g["x"].ptr, "ldx": g["x"].ld, "dw": gw.data_ptr(), "lddw": K,
-                                          "db": db, "M": self.M, "N": N, "K": K, "accumulate": 1 if acc_w else 0})
+                                          "db": db, "M": self.M, "N": N, "K": K, "accumulate": 1 if acc_w else 0,
+                                          "dzh": plan.shadow_view(dz) if self.g2 else None,
+                                          "xh": plan.shadow_view(g["x"]) if self.g2 else None})
         for c0 in (range(0, len(self.groups), L.MAX_GROUPS) if not defer else []):
             chunk = self.groups[c0:c0 + L.MAX_GROUPS]
             a = L.LinBwdwArgs()
@@ -555,6 +726,8 @@ class GLinear:
             outs = [(g["x"], [gi]) for gi, g in enumerate(self.groups) if not g.get("no_dx")]
             assert len(outs) == len(self.groups) and len(outs) <= L.MAX_GROUPS, "ragged launch limited to one chunk"
             launches = [outs]
+        if self.g2:
+            return self._build_bwd_x_g2(plan, gs, outs)
         ragged_acc = {}
         for la in launches:
             # all outputs of one launch share the mask scale (one plan-wide dropout rate)
@@ -601,6 +774,57 @@ class GLinear:
             self._keep.append(a)
             fl = sum(2.0 * self.M * self.groups[gi]["w"].shape[0] * self.groups[gi]["w"].shape[1] for _, gis in la for gi in gis)
             plan.bwd_steps.append(plan.call("cdc_glinear_bwd_x", C.byref(a), plan.prec, flops=fl))
+
+
+    def _build_bwd_x_g2(self, plan, gs, outs):
+        """grad-input from the bf16 shadows of dZ and the per-step W^T copies; outputs: x.grad in fp32, plus its bf16 shadow
+        when the layer that produced x reads its dZ through one"""
+        launches, cur_o, cur_s = [], [], 0
+        for o in outs:
+            if len(o[1]) > L.G2_MAX_SEG:
+                raise RuntimeError("more than %d linear groups share one input" % L.G2_MAX_SEG)
+            if cur_o and (len(cur_o) + 1 > L.G2_MAX_OUT or cur_s + len(o[1]) > L.G2_MAX_SEG):
+                launches.append(cur_o)
+                cur_o, cur_s = [], 0
+            cur_o.append(o)
+            cur_s += len(o[1])
+        if cur_o:
+            launches.append(cur_o)
+        for la in launches:
+            a = L.G2Args()
+            a.n_out = len(la)
+            a.mode, a.relu, a.drop_p, a.mask_scale, a.seed, a.seed_offset_dev = 1, 0, 0.0, 1.0, 0, None
+            si = 0
+            for oi, (x, gis) in enumerate(la):
+                O = a.o[oi]
+                xg = x.grad
+                acc = gs.claim(x)                          # (invalidates an older shadow of x.grad)
+                O.y, O.ldy = xg.ptr, xg.ld
+                if plan.shadow_wanted(xg):
+                    O.yh, O.ldyh = plan.shadow_view(xg)
+                    plan.mark_shadow(xg)
+                else:
+                    O.yh = None
+                O.bias, O.bn_partial = None, None
+                if x.mask is not None:
+                    O.mask, O.ldmask, O.mask_bf16 = x.ptr, x.ld, 0
+                    O.act_cols = min(x.mask[1], x.cols)
+                    a.mask_scale = x.mask[0]
+                else:
+                    O.mask, O.act_cols, O.mask_bf16 = None, 0, 0
+                O.M, O.N, O.accumulate, O.stream_id = self.M, x.cols, 1 if acc else 0, oi
+                for gi in gis:
+                    g = self.groups[gi]
+                    S = a.s[si]
+                    S.a, S.lda = plan.shadow_view(g["y"].grad)
+                    _, wt = plan.wshadow(g["w"])
+                    S.b, S.ldb = wt.data_ptr(), wt.stride(0)
+                    S.Kr, S.out = (g["w"].shape[0] + 63) // 64 * 64, oi
+                    si += 1
+            a.n_seg = si
+            self._keep.append(a)
+            fl = sum(2.0 * self.M * self.groups[gi]["w"].shape[0] * self.groups[gi]["w"].shape[1] for _, gis in la for gi in gis)
+            plan.bwd_steps.append(plan.call("cdc_gemm_bf16_nt", C.byref(a), what="cdc_glinear_bwd_x", flops=fl))
 
 
 class GatePool:

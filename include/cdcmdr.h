@@ -258,6 +258,76 @@ typedef struct {
 } cdc_transpose_args;
 int cdc_transpose_multi(const cdc_transpose_args* a, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The same contractions with operands that ARE bf16 in memory ("shadows": the bf16 rounding of an fp32 tensor, written once
+ * by its producer instead of every time a tile of it is staged).  Arithmetic identical to CDC_PREC_BF16 above: bf16 operands
+ * (round to nearest even), fp32 accumulate, fp32 epilogue.  Replaces the same reference lines as cdc_glinear_fwd /
+ * cdc_glinear_bwd_x (nn.Linear at model/layer.py:185,193,275; model/ple.py:83-94; model/mmoe.py:35-40 and the two addmm calls
+ * autograd issues for forward and grad-input).
+ *   out_o[M,N] = epilogue( sum over the output's segments s of A_s[M,Kr] . B_s[N,Kr]^T )
+ *   mode 0 (forward):    A = shadow of x, B = shadow of W [N,K];  epilogue: + bias, relu / dropout on columns [0,act_cols),
+ *                        optional BatchNorm partial sums (as cdc_lin_group.bn_partial)
+ *   mode 1 (grad-input): A = shadow of dZ [M,N_s], B = shadow of W^T [K,N_s] (cdc_weight_shadows);  epilogue: activation mask
+ *                        of the layer that produced x on columns [0,act_cols): d = (mask > 0) ? d * mask_scale : 0, then
+ *                        optional += into the fp32 destination
+ * Kr: the reduction length rounded UP to a multiple of 64; both operands' rows must be readable that far and the padding of
+ * at least one of them must be zero (shadows are allocated zero-padded).  Operand pointers 16-byte aligned, row strides
+ * multiples of 8 elements.  Every output may be written as fp32 (y), as its bf16 shadow (yh), or both. */
+#define CDC_G2_MAX_OUT 24
+#define CDC_G2_MAX_SEG 32
+typedef struct {
+    float* y; int64_t ldy;           /* fp32 destination [M,N] or NULL */
+    void*  yh; int64_t ldyh;         /* bf16 destination [M,N] or NULL (row stride in elements) */
+    const float* bias;               /* mode 0: [N] or NULL */
+    const void* mask; int64_t ldmask;/* mode 1: post-activation output of the layer that produced x (fp32, or bf16 when mask_bf16) or NULL */
+    double* bn_partial;              /* mode 0: as cdc_lin_group.bn_partial */
+    int32_t M, N;
+    int32_t act_cols;                /* mode 0: activation columns; mode 1: masked columns */
+    int32_t accumulate;              /* mode 1: y += result (needs y) */
+    int32_t mask_bf16;
+    int32_t bn_col0, bn_total_c;
+    int32_t stream_id;               /* mode 0: distinguishes the dropout streams of the outputs of one launch */
+} cdc_g2_out;
+typedef struct {
+    const void* a; int64_t lda;      /* bf16 [M, >=Kr] */
+    const void* b; int64_t ldb;      /* bf16 [N, >=Kr] */
+    int32_t Kr;                      /* reduction length, multiple of 64 */
+    int32_t out;                     /* output this segment accumulates into */
+} cdc_g2_seg;
+typedef struct {
+    int32_t n_out, n_seg;
+    int32_t mode;                    /* 0 forward, 1 grad-input */
+    int32_t relu;
+    float   drop_p;
+    float   mask_scale;
+    int32_t tile_cfg;                /* 0 = chosen by the library; 1..10 force a tile shape / ring depth (tuning, tools/gemm2_probe.hip) */
+    int32_t pad_;
+    uint64_t seed;
+    const int32_t* seed_offset_dev;
+    cdc_g2_out o[CDC_G2_MAX_OUT];
+    cdc_g2_seg s[CDC_G2_MAX_SEG];
+} cdc_g2_args;
+int cdc_gemm_bf16_nt(const cdc_g2_args* a, void* stream);
+
+/* Weight shadows, once per step before the forward: for every W_i [rows = N, cols = K] (contiguous fp32) the straight bf16
+ * copy dst_h [N, ld_h] and/or the transposed bf16 copy dst_t [K, ld_t].  Only the tensor's own elements are written: the
+ * destinations' padding (ld_h > K, ld_t > N, several tensors concatenated into one destination) is the caller's, zeroed once. */
+typedef struct {
+    int32_t n;
+    int32_t pad_;
+    struct { const float* src; void* dst_h; int64_t ld_h; void* dst_t; int64_t ld_t; int32_t rows, cols; } t[CDC_MAX_TENSORS];
+} cdc_wshadow_args;
+int cdc_weight_shadows(const cdc_wshadow_args* a, void* stream);
+
+/* dst_i = bf16(src_i) for up to CDC_MAX_GROUPS [rows, cols] views (row strides in elements): the shadow of an activation or
+ * gradient whose producer does not write it itself. */
+typedef struct {
+    int32_t n;
+    int32_t pad_;
+    struct { const float* src; int64_t ld_src; void* dst; int64_t ld_dst; int64_t rows; int32_t cols; int32_t pad_; } t[CDC_MAX_GROUPS];
+} cdc_shadow_args;
+int cdc_shadow_bf16(const cdc_shadow_args* a, void* stream);
+
 /* dW_g[N,K] = dZ_gᵀ · X_g ; db_g[N] = column sums of dZ_g (fp32, exact order-fixed reduction). */
 typedef struct {
     const float* dz; int64_t lddz;   /* [M,N] */
@@ -266,6 +336,10 @@ typedef struct {
     float* db;                       /* [N] or NULL */
     int32_t M, N, K;
     int32_t accumulate;              /* 1: dw += , db += */
+    const void* dzh; int64_t lddzh;  /* optional bf16 shadows of dz and x (row strides in elements; rows zero-padded to a multiple */
+    const void* xh;  int64_t ldxh;   /* of 64, 128 readable columns past col 0 of a tile).  When every group of a CDC_PREC_BF16 launch
+                                        without row_offsets has both, the contraction reads them (direct-to-LDS staging, transposing
+                                        LDS reads) and db is summed from the bf16 dz */
 } cdc_bwdw_group;
 typedef struct {
     int32_t n_groups;

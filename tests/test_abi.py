@@ -46,6 +46,8 @@ STRUCTS = {
     "cdc_rowdot_group": "RowdotGroup", "cdc_rowdot_fwd_args": "RowdotFwdArgs", "cdc_rowdot_bgroup": "RowdotBGroup",
     "cdc_rowdot_bwd_args": "RowdotBwdArgs", "cdc_adam_tensor": "AdamTensor", "cdc_adam_args": "AdamArgs",
     "cdc_star_fuse_args": "StarFuseArgs", "cdc_transpose_args": "TransposeArgs", "cdc_add_n_args": "AddNArgs",
+    "cdc_g2_out": "G2Out", "cdc_g2_seg": "G2Seg", "cdc_g2_args": "G2Args", "cdc_wshadow_args": "WShadowArgs",
+    "cdc_shadow_args": "ShadowArgs",
 }
 
 
