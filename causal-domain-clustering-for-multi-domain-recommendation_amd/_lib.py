@@ -116,7 +116,7 @@ class LinBwdwArgs(C.Structure):
 
 class PoolFwdGate(C.Structure):
     _fields_ = [("logits", c_p), ("ld_logits", c_i64), ("out", c_p), ("ld_out", c_i64), ("probs", c_p),
-                ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL)]
+                ("out_h", c_p), ("ld_out_h", c_i64), ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL)]
 
 
 class PoolFwdArgs(C.Structure):
@@ -126,19 +126,19 @@ class PoolFwdArgs(C.Structure):
 
 class PoolBwdGate(C.Structure):
     _fields_ = [("d_out", c_p), ("ld_dout", c_i64), ("probs", c_p), ("d_logits", c_p), ("ld_dlogits", c_i64),
-                ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL)]
+                ("d_logits_h", c_p), ("ld_dlogits_h", c_i64), ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL)]
 
 
 class PoolBwdArgs(C.Structure):
     _fields_ = [("n_gates", c_i32), ("n_expert", c_i32), ("H", c_i32), ("B", c_i64), ("experts", c_p),
                 ("ld_exp", c_i64), ("d_experts", c_p), ("ld_dexp", c_i64), ("mask_relu", c_i32),
-                ("mask_scale", c_f), ("accumulate", c_i32), ("gate", PoolBwdGate * MAX_GATES)]
+                ("mask_scale", c_f), ("accumulate", c_i32), ("d_experts_h", c_p), ("ld_dexp_h", c_i64), ("gate", PoolBwdGate * MAX_GATES)]
 
 
 class BnSeg(C.Structure):
     _fields_ = [("x", c_p), ("ldx", c_i64), ("y", c_p), ("ldy", c_i64), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("save_mean", c_p), ("save_invstd", c_p),
-                ("num_batches_tracked", c_p), ("C", c_i32), ("row_group", c_i32)]
+                ("num_batches_tracked", c_p), ("yh", c_p), ("ldyh", c_i64), ("C", c_i32), ("row_group", c_i32)]
 
 
 class BnFwdArgs(C.Structure):
@@ -151,7 +151,8 @@ class BnFwdArgs(C.Structure):
 class BnBSeg(C.Structure):
     _fields_ = [("dy", c_p), ("lddy", c_i64), ("y", c_p), ("ldy", c_i64), ("x", c_p), ("ldx", c_i64),
                 ("dx", c_p), ("lddx", c_i64), ("gamma", c_p), ("save_mean", c_p), ("save_invstd", c_p),
-                ("dgamma", c_p), ("dbeta", c_p), ("C", c_i32), ("row_group", c_i32), ("accumulate_dx", c_i32), ("pad_", c_i32)]
+                ("dgamma", c_p), ("dbeta", c_p), ("dxh", c_p), ("lddxh", c_i64), ("C", c_i32), ("row_group", c_i32), ("accumulate_dx", c_i32),
+                ("pad_", c_i32)]
 
 
 class BnBwdArgs(C.Structure):
@@ -207,6 +208,7 @@ _SIGNATURES = {
     "cdc_abi_version": (c_i32, []),
     "cdc_last_error": (C.c_char_p, []),
     "cdc_embed_gather_fwd": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
+    "cdc_embed_gather_fwd_h": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_i32, c_i32, c_i64, c_p]),
     "cdc_embed_index": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, c_i64, c_p]),
     "cdc_embed_sort_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "cdc_embed_sort_dedupe_ids": (c_i32, [c_p, c_p, c_i64, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),

@@ -13,6 +13,7 @@
 template <int VEC>
 __global__ void __launch_bounds__(256) k_gather_fwd(const int32_t* __restrict__ ids, const int32_t* __restrict__ offsets,
                                                     const float* __restrict__ table, float* __restrict__ out,
+                                                    __bf16* __restrict__ out_h, int64_t ld_out_h,
                                                     int32_t* __restrict__ idx_out, int32_t* __restrict__ err_flag,
                                                     int64_t n_pos, int32_t F, int32_t D, int64_t R) {
     const int chunks = D / VEC;                       // chunks of VEC floats per row
@@ -30,8 +31,15 @@ __global__ void __launch_bounds__(256) k_gather_fwd(const int32_t* __restrict__ 
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ok) val = *reinterpret_cast<const float4*>(table + (int64_t)row * D + c * 4);
             *reinterpret_cast<float4*>(out + pos * D + c * 4) = val;
+            if (out_h) {                                      // bf16 shadow [B, ld_out_h]: position (b, f) at column f*D
+                typedef __bf16 h4_t __attribute__((ext_vector_type(4)));
+                h4_t h = {(__bf16)val.x, (__bf16)val.y, (__bf16)val.z, (__bf16)val.w};
+                *reinterpret_cast<h4_t*>(out_h + (pos / F) * ld_out_h + (int64_t)f * D + c * 4) = h;
+            }
         } else {
-            out[pos * D + c] = ok ? table[(int64_t)row * D + c] : 0.f;
+            const float v = ok ? table[(int64_t)row * D + c] : 0.f;
+            out[pos * D + c] = v;
+            if (out_h) out_h[(pos / F) * ld_out_h + (int64_t)f * D + c] = (__bf16)v;
         }
     }
 }
@@ -39,7 +47,15 @@ __global__ void __launch_bounds__(256) k_gather_fwd(const int32_t* __restrict__ 
 extern "C" int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, const float* table, float* out,
                                     int32_t* idx_out, int32_t* err_flag, int64_t B, int32_t F, int32_t D, int64_t R,
                                     void* stream) {
+    return cdc_embed_gather_fwd_h(ids, offsets, table, out, nullptr, 0, idx_out, err_flag, B, F, D, R, stream);
+}
+extern "C" int cdc_embed_gather_fwd_h(const int32_t* ids, const int32_t* offsets, const float* table, float* out, void* out_h_,
+                                      int64_t ld_out_h, int32_t* idx_out, int32_t* err_flag, int64_t B, int32_t F, int32_t D, int64_t R,
+                                      void* stream) {
+    __bf16* out_h = reinterpret_cast<__bf16*>(out_h_);
     CDC_CHECK_ARG(ids && offsets && table && out, CDC_E_BADARG, "embed_gather_fwd: null pointer");
+    CDC_CHECK_ARG(!out_h || (ld_out_h >= (int64_t)F * D && (((uintptr_t)out_h) & 7) == 0 && ld_out_h % 4 == 0), CDC_E_BADARG,
+                  "embed_gather_fwd: malformed bf16 shadow");
     CDC_CHECK_ARG(B >= 0 && F > 0 && D > 0 && R > 0, CDC_E_BADARG, "embed_gather_fwd: bad sizes B=%ld F=%d D=%d R=%ld",
                   (long)B, F, D, (long)R);
     if (B == 0) return 0;
@@ -48,10 +64,10 @@ extern "C" int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, 
     const int64_t total = n_pos * (vec ? D / 4 : D);
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
     if (vec)
-        hipLaunchKernelGGL(k_gather_fwd<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, table, out,
+        hipLaunchKernelGGL(k_gather_fwd<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, table, out, out_h, ld_out_h,
                            idx_out, err_flag, n_pos, F, D, R);
     else
-        hipLaunchKernelGGL(k_gather_fwd<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, table, out,
+        hipLaunchKernelGGL(k_gather_fwd<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, offsets, table, out, out_h, ld_out_h,
                            idx_out, err_flag, n_pos, F, D, R);
     CDC_LAUNCH_CHECK("embed_gather_fwd");
     return 0;

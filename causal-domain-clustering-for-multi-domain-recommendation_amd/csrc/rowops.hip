@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_fwd(const cdc_pool_fw
             for (int j = 0; j < CDC_MAX_SEL; ++j)
                 if (j < G.n_sel) acc += p[j] * ex[(int64_t)G.sel[j] * a.H + h];   // same order as torch.sum(dim=1)
             G.out[row * G.ld_out + h] = acc;
+            if (G.out_h) reinterpret_cast<__bf16*>(G.out_h)[row * G.ld_out_h + h] = (__bf16)acc;
         }
     }
 }
@@ -55,6 +56,13 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_fwd(const cdc_pool_fw
 // rows and every global access is a float4.  Per element the sum over the selected experts keeps its order, so the
 // results equal the scalar kernel's bit for bit.
 typedef float pool_f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pool_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pool_store_h4(void* base, int64_t off, const pool_f4& v) {       // 4 x bf16 = one 8-byte store
+    pool_h4 h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = (__bf16)v[q];
+    *reinterpret_cast<pool_h4*>(reinterpret_cast<__bf16*>(base) + off) = h;
+}
 static bool pool_vec_ok(int H, const void* experts, int64_t ld_exp) {
     const int gl = H / 4;
     return H % 4 == 0 && gl >= 1 && gl <= 64 && (gl & (gl - 1)) == 0 && (((uintptr_t)experts & 15) == 0) && ld_exp % 4 == 0;
@@ -97,6 +105,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_fwd_v4(const cdc_pool
         for (int j = 0; j < CDC_MAX_SEL; ++j)
             if (j < G.n_sel) acc += p[j] * ex[(int64_t)G.sel[j] * gl + l];
         reinterpret_cast<pool_f4*>(G.out + row * G.ld_out)[l] = acc;
+        if (G.out_h) pool_store_h4(G.out_h, row * G.ld_out_h + 4 * l, acc);
     }
 }
 
@@ -113,7 +122,8 @@ extern "C" int cdc_gate_pool_fwd(const cdc_pool_fwd_args* a, void* stream) {
     if (pool_vec_ok(a->H, a->experts, a->ld_exp)) {
         bool ok = true;
         for (int g = 0; g < a->n_gates; ++g)
-            ok = ok && (((uintptr_t)a->gate[g].out & 15) == 0) && (a->gate[g].ld_out % 4 == 0);
+            ok = ok && (((uintptr_t)a->gate[g].out & 15) == 0) && (a->gate[g].ld_out % 4 == 0) &&
+                 (!a->gate[g].out_h || ((((uintptr_t)a->gate[g].out_h & 7) == 0) && a->gate[g].ld_out_h % 4 == 0));
         if (ok) {
             const int rows_per_block = WAVES_PER_BLOCK * (64 / (a->H / 4));
             hipLaunchKernelGGL(k_gate_pool_fwd_v4, dim3(cdc_ceil_div(a->B, rows_per_block)), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
@@ -156,7 +166,11 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd(const cdc_pool_bw
                 if (j == lane) { pj_lane = pj; dpj_lane = dp[j]; }
             }
         }
-        if (lane < G.n_sel) G.d_logits[row * G.ld_dlogits + lane] = pj_lane * (dpj_lane - dot);
+        if (lane < G.n_sel) {
+            const float dl = pj_lane * (dpj_lane - dot);
+            G.d_logits[row * G.ld_dlogits + lane] = dl;
+            if (G.d_logits_h) reinterpret_cast<__bf16*>(G.d_logits_h)[row * G.ld_dlogits_h + lane] = (__bf16)dl;
+        }
     }
     // (2) expert gradients: d_expert_e = sum over (gate, j) with sel == e of p * d_out, then the expert's relu/dropout mask.
     // Accumulators live in LDS ([expert][lane] per wave) so that the data-dependent expert index costs one ds op, not a
@@ -174,7 +188,9 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd(const cdc_pool_bw
             float v = acc[e][lane];
             if (a.mask_relu) v = ex[(int64_t)e * a.H + h] > 0.f ? v * a.mask_scale : 0.f;
             float* dst = dex + (int64_t)e * a.H + h;
-            *dst = a.accumulate ? *dst + v : v;
+            v = a.accumulate ? *dst + v : v;
+            *dst = v;
+            if (a.d_experts_h) reinterpret_cast<__bf16*>(a.d_experts_h)[row * a.ld_dexp_h + (int64_t)e * a.H + h] = (__bf16)v;
         }
     }
 }
@@ -215,7 +231,9 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd_v4(const cdc_pool
                 float dpj = 0.f;
 #pragma unroll
                 for (int j = 0; j < CDC_MAX_SEL; ++j) if (j == j0) dpj = dp[j];
-                G.d_logits[r * G.ld_dlogits + j0] = G.probs[r * G.n_sel + j0] * (dpj - dot);
+                const float dl = G.probs[r * G.n_sel + j0] * (dpj - dot);
+                G.d_logits[r * G.ld_dlogits + j0] = dl;
+                if (G.d_logits_h) reinterpret_cast<__bf16*>(G.d_logits_h)[r * G.ld_dlogits_h + j0] = (__bf16)dl;
             }
         }
         // (2) every selected expert receives p_j * d_out
@@ -231,7 +249,9 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd_v4(const cdc_pool
             for (int q = 0; q < 4; ++q) v[q] = x[q] > 0.f ? v[q] * a.mask_scale : 0.f;
         }
         pool_f4* dst = dex + (int64_t)e * gl + l;
-        *dst = a.accumulate ? *dst + v : v;
+        if (a.accumulate) v = *dst + v;
+        *dst = v;
+        if (a.d_experts_h) pool_store_h4(a.d_experts_h, r * a.ld_dexp_h + ((int64_t)e * gl + l) * 4, v);
     }
 }
 
@@ -242,7 +262,8 @@ extern "C" int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream) {
         CDC_CHECK_ARG(a->gate[g].d_out && a->gate[g].probs && a->gate[g].d_logits && a->gate[g].n_sel > 0 &&
                           a->gate[g].n_sel <= CDC_MAX_SEL, CDC_E_BADARG, "gate_pool_bwd: gate %d malformed", g);
     if (a->B == 0) return 0;
-    if (pool_vec_ok(a->H, a->experts, a->ld_exp) && (((uintptr_t)a->d_experts & 15) == 0) && a->ld_dexp % 4 == 0 && a->n_expert <= 16) {
+    if (pool_vec_ok(a->H, a->experts, a->ld_exp) && (((uintptr_t)a->d_experts & 15) == 0) && a->ld_dexp % 4 == 0 && a->n_expert <= 16 &&
+        (!a->d_experts_h || ((((uintptr_t)a->d_experts_h & 7) == 0) && a->ld_dexp_h % 4 == 0))) {
         bool ok = true;
         for (int g = 0; g < a->n_gates; ++g)
             ok = ok && (((uintptr_t)a->gate[g].d_out & 15) == 0) && (a->gate[g].ld_dout % 4 == 0);
@@ -371,6 +392,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
             v = cdc_uniform(seed, e) < a.drop_p ? 0.f : v * keep_scale;
         }
         S.y[gr * S.ldy + c] = v;
+        if (S.yh) reinterpret_cast<__bf16*>(S.yh)[gr * S.ldyh + c] = (__bf16)v;
     }
 }
 
@@ -508,7 +530,9 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
             dx = gam * invstd * (dz - invM * (db + xhat * dg));
         } else dx = gam * invstd * dz;
         float* dst = S.dx + gr * S.lddx + c;
-        *dst = S.accumulate_dx ? *dst + dx : dx;
+        if (S.accumulate_dx) dx = *dst + dx;
+        *dst = dx;
+        if (S.dxh) reinterpret_cast<__bf16*>(S.dxh)[gr * S.lddxh + c] = (__bf16)dx;
     }
 }
 

@@ -210,6 +210,11 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
             P.BatchNorm(plan, segs, relu=True, dropout=True)
             cur = dst
         else:
+            # hidden activations of a BatchNorm-free stack are read by the next layer's contractions only (forward, grad-weight,
+            # and as the activation mask of its grad-input): with the bf16-shadow path they never exist in fp32
+            if j < depth - 1 and width % 8 == 0 and dst is None:
+                for g in groups[:n]:
+                    g["half_only"] = True
             op = P.GLinear(plan, groups, relu=True, dropout=True)
             cur = [op.outs[i] for i in range(n)]
         if n_extra:

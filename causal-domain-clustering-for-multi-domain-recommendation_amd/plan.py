@@ -194,6 +194,7 @@ class Plan:
         self._sh_have = {}                # id(root) -> [(c0, c1)] columns whose shadow is current at this point of the sequence
         self._sh_wanted = {}              # id(root) -> [(c0, c1)] columns some contraction reads through the shadow
         self._wsh = {}                    # weight key -> (weight, straight copy [N, K64], transposed copy [K, N64])
+        self._half_only = set()           # id(root): activations (and their gradients) that exist ONLY as bf16 shadows
 
     # ---------------------------------------------------------------- buffers
     def new(self, cols, rows=None, dtype=torch.float32):
@@ -297,6 +298,8 @@ class Plan:
             a = L.LinBwdwArgs()
             a.n_groups = len(chunk)
             Mmax = max(g["M"] for g in chunk)
+            if any(g.get("needs_shadows") for g in chunk) and not all(g.get("dzh") is not None for g in chunk):
+                raise RuntimeError("a grad-weight launch mixes shadow-only activations with groups that have no shadows")
             if all(g.get("dzh") is not None for g in chunk):
                 # shadows (csrc/gemm2.hip k_g2_tn): 128x128 output tiles unless every group is at most 64x64; a row slice of at least
                 # four 64-row slabs per workgroup
@@ -400,6 +403,30 @@ class Plan:
                 self.mark_shadow(b)
             self._keep_args = getattr(self, "_keep_args", []) + [a]
             steps.append(self.call("cdc_shadow_bf16", C.byref(a)))
+
+    def make_half_only(self, buf):
+        """The buffer's values are only ever read by bf16 contractions (hidden activations of a BatchNorm-free MLP stack): keep
+        them — and their gradient — as bf16 shadows alone.  The fp32 tensors stay allocated (addresses are part of many
+        argument blocks) but are never written; they are poisoned so that a consumer this rule did not foresee fails loudly."""
+        self._half_only.add(id(buf.root))
+        self._half_only.add(id(self._root_grad(buf.root)))
+        buf.root.fill_(float("nan"))
+        self._root_grad(buf.root).fill_(float("nan"))
+
+    def is_half_only(self, buf):
+        return id(buf.root) in self._half_only
+
+    def shadow_convert_step(self, buf):
+        """a launch step that rewrites buf's shadow from its fp32 values (for a caller that fills buf behind the plan's back:
+        the row-sharded trainer replaces the gather launch by its row exchange)"""
+        a = L.ShadowArgs()
+        a.n = 1
+        T = a.t[0]
+        T.src, T.ld_src = buf.ptr, buf.ld
+        T.dst, T.ld_dst = self.shadow_view(buf)
+        T.rows, T.cols = buf.rows, buf.cols
+        self._keep_args = getattr(self, "_keep_args", []) + [a]
+        return self.call("cdc_shadow_bf16", C.byref(a))
 
     def wshadow(self, w):
         """bf16 copies of a linear weight [N,K], refreshed once per step ahead of the forward: the straight copy [N, K64]
@@ -522,8 +549,14 @@ class EmbedGather:
 
     def build_fwd(self, plan):
         R = self.table.shape[0]
-        self.fwd_step = plan.call("cdc_embed_gather_fwd", _p(self.ids), _p(self.offsets), _p(self.table.data),
-                                  self.out.cptr(), _p(self.idx), _p(self.err), C.c_int64(plan.B), self.F, self.D, C.c_int64(R))
+        oh, ldh = None, 0
+        if plan.use_g2 and plan.shadow_wanted(self.out):      # the contractions read the embeddings through their bf16 shadow
+            ptr, ldh = plan.shadow_view(self.out)
+            oh = C.c_void_p(ptr)
+            plan.mark_shadow(self.out)
+        self.fwd_step = plan.call("cdc_embed_gather_fwd_h", _p(self.ids), _p(self.offsets), _p(self.table.data),
+                                  self.out.cptr(), oh, C.c_int64(ldh), _p(self.idx), _p(self.err), C.c_int64(plan.B), self.F, self.D,
+                                  C.c_int64(R), what="cdc_embed_gather_fwd")
         plan.fwd_steps.append(self.fwd_step)     # (a row-sharded trainer replaces this launch by its exchange)
 
     def build_bwd(self, plan, gs):
@@ -542,6 +575,8 @@ class GLinear:
     """
 
     def __init__(self, plan, groups, relu=False, dropout=False, row_offsets=None, M=None):
+        """a group with "half_only": True: its output feeds nothing but further bf16 contractions (the caller guarantees it); with
+        the gemm2 path it and its gradient are kept as bf16 shadows only (no fp32 round trip through HBM)."""
         self.groups = groups
         self.relu = relu
         self.drop_p = plan.dropout if dropout else 0.0
@@ -567,10 +602,16 @@ class GLinear:
         self.g2 = (plan.use_g2 and row_offsets is None and self.M > 0 and
                    all(isinstance(g["w"], (torch.Tensor, PView)) and not isinstance(g.get("b"), TView) for g in groups) and
                    all(g["x"].col0 % 8 == 0 and g["y"].col0 % 8 == 0 for g in groups))
+        for g in groups:
+            if plan.is_half_only(g["x"]) and not self.g2:
+                raise RuntimeError("a linear layer outside the bf16-shadow path reads an activation that exists only as a shadow")
         if self.g2:
             for g in groups:
                 plan.want_shadow(g["x"])                  # forward and grad-weight read x through its shadow
                 plan.want_shadow(g["y"].grad)             # grad-input and grad-weight read dZ through its shadow
+                if g.get("half_only") and os.environ.get("CDC_HALF_ONLY", "1") != "0":
+                    plan.want_shadow(g["y"])
+                    plan.make_half_only(g["y"])
         # grad-weight split-K: enough (tile, row-slice) workgroups to fill 256 CUs several times over
         self.split_k = []
         for c0 in range(0, len(groups), L.MAX_GROUPS):
@@ -595,7 +636,10 @@ class GLinear:
                 O, S = a.o[i], a.s[i]
                 N, K = g["w"].shape
                 y = g["y"]
-                O.y, O.ldy = y.ptr, y.ld
+                if plan.is_half_only(y):
+                    O.y = None
+                else:
+                    O.y, O.ldy = y.ptr, y.ld
                 if plan.shadow_wanted(y):                  # a later contraction reads y: its shadow comes out of this epilogue
                     O.yh, O.ldyh = plan.shadow_view(y)
                     plan.mark_shadow(y)
@@ -645,6 +689,10 @@ class GLinear:
     def build_bwd(self, plan, gs):
         # dZ of every group lives in y.grad (pre-activation gradient, see module docstring)
         for g in self.groups:
+            if plan.is_half_only(g["y"]):
+                if not plan.has_shadow(g["y"].grad):
+                    raise RuntimeError("the gradient of a shadow-only activation was not written by a bf16 grad-input launch")
+                continue
             plan.ensure_grad(g["y"], gs)
         if self.g2:                                  # grad-input and grad-weight read dZ through its bf16 shadow
             plan.ensure_shadows([g["y"].grad for g in self.groups], plan.bwd_steps)
@@ -667,7 +715,8 @@ class GLinear:
                 plan._deferred_dw.append({"dz": dz.ptr, "lddz": dz.ld, "x": g["x"].ptr, "ldx": g["x"].ld, "dw": gw.data_ptr(), "lddw": K,
                                           "db": db, "M": self.M, "N": N, "K": K, "accumulate": 1 if acc_w else 0,
                                           "dzh": plan.shadow_view(dz) if self.g2 else None,
-                                          "xh": plan.shadow_view(g["x"]) if self.g2 else None})
+                                          "xh": plan.shadow_view(g["x"]) if self.g2 else None,
+                                          "needs_shadows": plan.is_half_only(g["x"]) or plan.is_half_only(g["y"])})
         for c0 in (range(0, len(self.groups), L.MAX_GROUPS) if not defer else []):
             chunk = self.groups[c0:c0 + L.MAX_GROUPS]
             a = L.LinBwdwArgs()
@@ -799,15 +848,24 @@ class GLinear:
                 O = a.o[oi]
                 xg = x.grad
                 acc = gs.claim(x)                          # (invalidates an older shadow of x.grad)
-                O.y, O.ldy = xg.ptr, xg.ld
-                if plan.shadow_wanted(xg):
+                half = plan.is_half_only(x)
+                if half:
+                    if acc:
+                        raise RuntimeError("an activation kept as a bf16 shadow only feeds more than one grad-input launch")
+                    O.y = None
+                else:
+                    O.y, O.ldy = xg.ptr, xg.ld
+                if half or plan.shadow_wanted(xg):
                     O.yh, O.ldyh = plan.shadow_view(xg)
                     plan.mark_shadow(xg)
                 else:
                     O.yh = None
                 O.bias, O.bn_partial = None, None
                 if x.mask is not None:
-                    O.mask, O.ldmask, O.mask_bf16 = x.ptr, x.ld, 0
+                    if plan.has_shadow(x):                 # the sign of the activation is the same in its bf16 shadow: half the bytes
+                        (O.mask, O.ldmask), O.mask_bf16 = plan.shadow_view(x), 1
+                    else:
+                        O.mask, O.ldmask, O.mask_bf16 = x.ptr, x.ld, 0
                     O.act_cols = min(x.mask[1], x.cols)
                     a.mask_scale = x.mask[0]
                 else:
@@ -855,6 +913,11 @@ class GatePool:
                 G = a.gate[i]
                 G.logits, G.ld_logits = lg.ptr, lg.ld
                 G.out, G.ld_out = self.outs[c0 + i].ptr, self.outs[c0 + i].ld
+                if plan.use_g2 and plan.shadow_wanted(self.outs[c0 + i]):
+                    G.out_h, G.ld_out_h = plan.shadow_view(self.outs[c0 + i])
+                    plan.mark_shadow(self.outs[c0 + i])
+                else:
+                    G.out_h = None
                 G.probs = self.probs[c0 + i].data_ptr()
                 G.n_sel = len(sel)
                 for j, e in enumerate(sel):
@@ -877,6 +940,11 @@ class GatePool:
             else:
                 a.mask_relu, a.mask_scale = 0, 1.0
             a.accumulate = 1 if (acc or c0 > 0) else 0
+            if plan.use_g2 and plan.shadow_wanted(eg):       # the experts' grad-input / grad-weight read dZ through its shadow
+                a.d_experts_h, a.ld_dexp_h = plan.shadow_view(eg)
+                plan.mark_shadow(eg)
+            else:
+                a.d_experts_h = None
             for i, (lg, sel) in enumerate(chunk):
                 G = a.gate[i]
                 plan.ensure_grad(self.outs[c0 + i], gs)
@@ -887,6 +955,11 @@ class GatePool:
                 if gs.claim(lg):
                     raise RuntimeError("gate logits feed more than one consumer")
                 G.d_logits, G.ld_dlogits = lgg.ptr, lgg.ld
+                if plan.use_g2 and plan.shadow_wanted(lgg):
+                    G.d_logits_h, G.ld_dlogits_h = plan.shadow_view(lgg)
+                    plan.mark_shadow(lgg)
+                else:
+                    G.d_logits_h = None
                 G.n_sel = len(sel)
                 for j, e in enumerate(sel):
                     G.sel[j] = e
@@ -949,6 +1022,11 @@ class BatchNorm:
                 S.num_batches_tracked = None if nbt is None else nbt.data_ptr()
                 S.C = s["x"].cols
                 S.row_group = s.get("row_group", 0)
+                if plan.use_g2 and plan.shadow_wanted(s["y"]):
+                    S.yh, S.ldyh = plan.shadow_view(s["y"])
+                    plan.mark_shadow(s["y"])
+                else:
+                    S.yh = None
             self._fuse_stats(plan, a, chunk)
             self._keep.append(a)
             if plan.dist is not None and plan.training:
@@ -1018,6 +1096,7 @@ class BatchNorm:
                 S.y, S.ldy = s["y"].ptr, s["y"].ld
                 S.x, S.ldx = s["x"].ptr, s["x"].ld
                 S.accumulate_dx = 0
+                S.dxh = None
                 if fan_in is not None:
                     sl = fan_in.slice((c0 + i) * s["x"].cols, (c0 + i + 1) * s["x"].cols)
                     S.dx, S.lddx = sl.ptr, sl.ld
@@ -1031,6 +1110,9 @@ class BatchNorm:
                     elif gs.claim(s["x"]):
                         S.accumulate_dx = 1
                     S.dx, S.lddx = xg.ptr, xg.ld
+                    if plan.use_g2 and plan.shadow_wanted(xg):
+                        S.dxh, S.lddxh = plan.shadow_view(xg)
+                        plan.mark_shadow(xg)
                 S.gamma = s["gamma"].data_ptr()
                 if plan.training:
                     S.save_mean, S.save_invstd = s["save_mean"].data_ptr(), s["save_invstd"].data_ptr()

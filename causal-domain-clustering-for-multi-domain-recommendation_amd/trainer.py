@@ -263,11 +263,15 @@ class TrainStep:
                      (self.recv_ids.data_ptr(), self.zero_offsets.data_ptr(), opt.table.data_ptr(), self.rows_send.data_ptr(),
                       None, None, Bv, F, D, opt.table.shape[0]), st())
 
+        emb_shadow = plan.shadow_convert_step(emb.out) if (plan.use_g2 and plan.has_shadow(emb.out)) else None
+
         def expand():
             ws = opt._workspace(B, F, D, "local")
             L.launch("cdc_shard_expand", lib.cdc_shard_expand,
                      (self.rows_recv.data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), ws["seg"].data_ptr(),
                       ws["perm"].data_ptr(), self.slot_of.data_ptr(), emb.out.ptr, B, F, D, N, cap), st())
+            if emb_shadow is not None:                    # the gather launch this replaces also wrote the embeddings' bf16 shadow
+                emb_shadow(st())
 
         def pack():
             ws = opt._workspace(B, F, D, "local")

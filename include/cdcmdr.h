@@ -58,6 +58,12 @@ int cdc_embed_gather_fwd(const int32_t* ids, const int32_t* offsets, const float
                          float* out, int32_t* idx_out, int32_t* err_flag,
                          int64_t B, int32_t F, int32_t D, int64_t R, void* stream);
 
+/* The same gather that also writes the bf16 shadow of `out` (row stride ld_out_h elements; NULL = none) for the contractions
+ * that read the embeddings through cdc_gemm_bf16_nt. */
+int cdc_embed_gather_fwd_h(const int32_t* ids, const int32_t* offsets, const float* table,
+                           float* out, void* out_h, int64_t ld_out_h, int32_t* idx_out, int32_t* err_flag,
+                           int64_t B, int32_t F, int32_t D, int64_t R, void* stream);
+
 /* model/layer.py:152 alone: idx_out[b,f] = ids[b,f] + offsets[f] (int32, wrapping). */
 int cdc_embed_index(const int32_t* ids, const int32_t* offsets, int32_t* idx_out, int32_t* err_flag, int64_t B, int32_t F,
                     int64_t R, void* stream);   /* out-of-range ids: idx_out = -1 (+ err_flag), skipped downstream */
@@ -367,6 +373,7 @@ typedef struct {
         const float* logits; int64_t ld_logits;   /* [B, n_sel] */
         float* out; int64_t ld_out;               /* [B, H] */
         float* probs;                             /* [B, n_sel] contiguous (saved for backward) */
+        void* out_h; int64_t ld_out_h;            /* optional bf16 shadow of out (cdc_gemm_bf16_nt reads it), or NULL */
         int32_t n_sel;
         int32_t sel[CDC_MAX_SEL];
     } gate[CDC_MAX_GATES];
@@ -381,10 +388,12 @@ typedef struct {
     int32_t mask_relu;                        /* 1: d_experts = (experts > 0) ? d * mask_scale : 0 */
     float mask_scale;
     int32_t accumulate;                       /* 1: d_experts += (a second launch for more than CDC_MAX_GATES gates) */
+    void* d_experts_h; int64_t ld_dexp_h;     /* optional bf16 shadow of d_experts (the value after the +=), or NULL */
     struct {
         const float* d_out; int64_t ld_dout;  /* [B,H] */
         const float* probs;                   /* [B,n_sel] */
         float* d_logits; int64_t ld_dlogits;  /* [B,n_sel] */
+        void* d_logits_h; int64_t ld_dlogits_h;   /* optional bf16 shadow of d_logits, or NULL */
         int32_t n_sel;
         int32_t sel[CDC_MAX_SEL];
     } gate[CDC_MAX_GATES];
@@ -407,6 +416,7 @@ typedef struct {
     float* running_mean; float* running_var;  /* updated in training */
     float* save_mean; float* save_invstd;     /* [C] saved for backward (training) */
     int64_t* num_batches_tracked;     /* incremented in training when the segment is normalised (may be NULL) */
+    void* yh; int64_t ldyh;           /* optional bf16 shadow of y, or NULL */
     int32_t C;
     int32_t row_group;                /* index into row_offsets (ragged rows) */
 } cdc_bn_seg;
@@ -440,6 +450,7 @@ typedef struct {
     const float* save_mean; const float* save_invstd;      /* training: batch stats; eval: the running
                                                               mean and 1/sqrt(running_var+eps) */
     float* dgamma; float* dbeta;
+    void* dxh; int64_t lddxh;         /* optional bf16 shadow of dx (the value after the +=), or NULL */
     int32_t C;
     int32_t row_group;
     int32_t accumulate_dx;            /* 1: dx += (several segments normalise the same input: STAR's domain_norm) */

@@ -74,7 +74,10 @@ def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=No
         scale = max(float(g.abs().max()), 1e-6)
         if bn_active and is_pre_bn_bias(k, names):
             wscale = float(want[k[:-5] + ".weight"].abs().max())
-            assert float(got.abs().max()) <= 1e-3 * max(wscale, 1e-3) + 1e-4, f"pre-BN bias grad {k} not ~0"
+            # fp32: summation noise of a mathematically zero sum.  bf16: the bias gradient is the column sum of the bf16-rounded
+            # dZ the weight gradient contracts (csrc/gemm2.hip), so the zero sum carries the roundings' noise (~2^-9 per element)
+            bound = (1e-1 if bf16 else 1e-3) * max(wscale, 1e-3) + 1e-4
+            assert float(got.abs().max()) <= bound, f"pre-BN bias grad {k} not ~0: {float(got.abs().max()):.3e} > {bound:.3e}"
             continue
         if bf16:
             # against the oracle's bf16 restatement; a relu unit whose pre-activation sits within fp32 accumulation noise of
