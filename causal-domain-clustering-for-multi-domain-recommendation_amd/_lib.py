@@ -31,7 +31,7 @@ c_p = C.c_void_p
 class AdamHP(C.Structure):
     _fields_ = [("lerp_w", c_f), ("beta2", c_f), ("one_minus_beta2", c_f), ("eps", c_f),
                 ("weight_decay", c_f), ("l2_twice", c_f), ("step_scalars", c_p), ("n_scalars", c_i32), ("fast_replay", c_i32),
-                ("inv_bc2", c_p)]
+                ("inv_bc2", c_p), ("replay_tab", c_p), ("k1", c_f), ("k2", c_f)]
 
 
 class LinGroup(C.Structure):
@@ -183,6 +183,25 @@ class RowdotBwdArgs(C.Structure):
                 ("bce_inv_count", c_f), ("pad_", c_i32), ("g", RowdotBGroup * MAX_GROUPS)]
 
 
+HEAD_MAX_TOWERS = 8
+
+
+class HeadTower(C.Structure):
+    _fields_ = [("x", c_p), ("ldx", c_i64), ("w", c_p), ("bias", c_p), ("dx", c_p), ("lddx", c_i64), ("dw", c_p), ("dbias", c_p),
+                ("K", c_i32), ("accumulate_dx", c_i32)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("n_tower", c_i32), ("sigmoid", c_i32), ("n_addend", c_i32), ("pad_", c_i32), ("M", c_i64),
+                ("out", c_p), ("ld_out", c_i64), ("d_out", c_p), ("ld_dout", c_i64),
+                ("wide_x", c_p), ("ld_wide", c_i64), ("wide_w", c_p), ("wide_bias", c_p), ("wide_out", c_p), ("ld_wide_out", c_i64),
+                ("wide_dx", c_p), ("ld_wide_dx", c_i64), ("wide_dw", c_p), ("wide_dbias", c_p), ("wide_K", c_i32), ("accumulate_wide_dx", c_i32),
+                ("addend", c_p * 2), ("ld_addend", c_i64 * 2), ("d_addend", c_p * 2), ("ld_d_addend", c_i64 * 2),
+                ("accumulate_d_addend", c_i32 * 2), ("workspace", c_p),
+                ("bce_group", c_p), ("bce_y_i16", c_p), ("bce_y_f32", c_p), ("bce_loss", c_p), ("bce_partial", c_p),
+                ("bce_inv_count", c_f), ("pad2_", c_i32), ("t", HeadTower * HEAD_MAX_TOWERS)]
+
+
 class StarFuseArgs(C.Structure):
     _fields_ = [("n", c_i32), ("op", c_i32), ("size", c_i64), ("s", c_p), ("ds", c_p), ("accumulate_ds", c_i32), ("pad_", c_i32),
                 ("a", c_p * MAX_GROUPS), ("out", c_p * MAX_GROUPS), ("da", c_p * MAX_GROUPS)]
@@ -241,6 +260,9 @@ _SIGNATURES = {
     "cdc_bn_bwd": (c_i32, [C.POINTER(BnBwdArgs), c_p]),
     "cdc_rowdot_fwd": (c_i32, [C.POINTER(RowdotFwdArgs), c_p]),
     "cdc_rowdot_bwd": (c_i32, [C.POINTER(RowdotBwdArgs), c_p]),
+    "cdc_head_fwd": (c_i32, [C.POINTER(HeadArgs), c_p]),
+    "cdc_head_bwd": (c_i32, [C.POINTER(HeadArgs), c_p]),
+    "cdc_head_workspace_floats": (c_i64, [C.POINTER(HeadArgs)]),
     "cdc_bce_fwd_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f, c_p]),
     "cdc_attn_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),
     "cdc_attn_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),

@@ -155,9 +155,74 @@ __device__ __forceinline__ void adam_replay(float (&w)[N], float (&m)[N], float 
 // minimum is taken with shuffles.  Against adam_replay's per-lane loop this saves two vector loads and their address
 // arithmetic per replayed step whenever a wave is not uniform — which is nearly always (a quarter of the rows of a flush
 // slice were looked up since its last flush).
+// The fast replay in SCALED state: with c = 2*l2 + wd the L2-only step is g = c*w, so M = m / ((1-beta1) c) and
+// V = v / ((1-beta2) c^2) obey  M <- beta1*M + w,  V <- beta2*V + w^2,  w <- w - A_t * M / (sqrt(V) + E_t)  with the per-step
+// scalars A_t = step_size_t * (1-beta1) c * bc2_t / sqrt((1-beta2) c^2),  E_t = eps * bc2_t / sqrt((1-beta2) c^2)  (host table,
+// formed in double).  Six packed fp32 operations + sqrt + rcp per element pair and step instead of nine: the replay is
+// VALU-issue bound (profiles/round2), so the slice launch shrinks with the instruction count.  Same mathematics as
+// adam_elem_fast_pk; roundings differ in the last bit per step (the fast replay is 1-ulp arithmetic already).
+__device__ __forceinline__ void adam_scaled_step_pk(cdc_f2& w, cdc_f2& M, cdc_f2& V, float beta1, float beta2, float A, float E) {
+    M = __builtin_elementwise_fma((cdc_f2){beta1, beta1}, M, w);
+    V = __builtin_elementwise_fma((cdc_f2){beta2, beta2}, V, w * w);
+    cdc_f2 sq;
+    sq.x = __builtin_amdgcn_sqrtf(V.x);
+    sq.y = __builtin_amdgcn_sqrtf(V.y);
+    const cdc_f2 d = sq + (cdc_f2){E, E};
+    cdc_f2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    w = __builtin_elementwise_fma(M * (-A), r, w);
+}
+template <int N>
+__device__ __forceinline__ void adam_replay_wave_scaled(float (&w)[N], float (&m)[N], float (&v)[N], int from, int to, const cdc_adam_hp& hp) {
+    static_assert(N % 2 == 0, "pairs of elements");
+    const int last_i = hp.n_scalars - 1;
+    const float A_conv = hp.replay_tab[2 * last_i], E_conv = hp.replay_tab[2 * last_i + 1];
+    const float beta1 = 1.f - hp.lerp_w;
+    int fmin = from < to ? from : to;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(fmin, o, 64);
+        fmin = other < fmin ? other : fmin;
+    }
+    fmin = __builtin_amdgcn_readfirstlane(fmin);
+    if (fmin >= to) return;                                           // wave-uniform: nothing to replay
+    const float ik1 = 1.f / hp.k1, ik2 = 1.f / hp.k2;
+    cdc_f2 W[N / 2], M[N / 2], V[N / 2];
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+        W[k] = (cdc_f2){w[2 * k], w[2 * k + 1]};
+        M[k] = (cdc_f2){m[2 * k], m[2 * k + 1]} * ik1;
+        V[k] = (cdc_f2){v[2 * k], v[2 * k + 1]} * ik2;
+    }
+    for (int s = fmin + 1; s <= to; ++s) {                            // s, A, E in SGPRs (scalar loads of the host table)
+        float A = A_conv, E = E_conv;
+        if (s < last_i) { A = hp.replay_tab[2 * s]; E = hp.replay_tab[2 * s + 1]; }
+        if (s > from) {
+#pragma unroll
+            for (int k = 0; k < N / 2; ++k) adam_scaled_step_pk(W[k], M[k], V[k], beta1, hp.beta2, A, E);
+        }
+    }
+    if (from < to) {
+#pragma unroll
+        for (int k = 0; k < N / 2; ++k) {
+            const cdc_f2 mo = M[k] * hp.k1, vo = V[k] * hp.k2;
+            w[2 * k] = W[k].x; w[2 * k + 1] = W[k].y;
+            m[2 * k] = mo.x; m[2 * k + 1] = mo.y;
+            v[2 * k] = vo.x; v[2 * k + 1] = vo.y;
+        }
+    }
+}
+
 template <bool FAST, int N>
 __device__ __forceinline__ void adam_replay_wave(float (&w)[N], float (&m)[N], float (&v)[N], int from, int to, const AdamConsts& c,
                                                  const cdc_adam_hp& hp) {
+    if constexpr (FAST && N % 2 == 0) {
+        if (hp.replay_tab && hp.k1 > 0.f && hp.k2 > 0.f) {            // uniform: the scaled form needs a decay term (c > 0)
+            adam_replay_wave_scaled<N>(w, m, v, from, to, hp);
+            return;
+        }
+    }
     const int last_i = hp.n_scalars - 1;
     const float ss_conv = hp.step_scalars[2 * last_i];
     const float bc_conv = FAST ? hp.inv_bc2[last_i] : hp.step_scalars[2 * last_i + 1];

@@ -777,6 +777,54 @@ __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a,
         if (lane == 0) first[0] = 0;
     }
     __syncthreads();
+    // 16-byte lanes when every group's flat start, its dW size and the slab stride are multiples of 4 floats and the
+    // destinations are dense: the same sums in the same order, a quarter of the load instructions
+    bool vec4 = (slab_stride % 4 == 0) && ((((uintptr_t)a.workspace) & 15) == 0);
+    for (int g = 0; g < a.n_groups && vec4; ++g) {
+        const cdc_bwdw_group& G = a.g[g];
+        vec4 = first[g] % 4 == 0 && ((int64_t)G.N * G.K) % 4 == 0 && G.lddw == G.K && ((((uintptr_t)G.dw) & 15) == 0) &&
+               (!G.db || ((((uintptr_t)G.db) & 15) == 0));
+    }
+    if (vec4) {
+        const int64_t total4 = (total + 3) / 4;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t e = q * 4;
+            int g = 0;
+            while (g + 1 < a.n_groups && e >= first[g + 1]) ++g;
+            const cdc_bwdw_group& G = a.g[g];
+            const int64_t local = e - first[g];
+            const int64_t nk = (int64_t)G.N * G.K;
+            const int64_t gsz = nk + G.N;
+            const int n_valid = (int)min((int64_t)4, gsz - local);       // a group whose N is not a multiple of 4 ends mid-piece
+            if (n_valid == 4) {
+                f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+                int s = 0;
+                for (; s + 4 <= a.split_k; s += 4) {
+                    const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(a.workspace + (int64_t)s * slab_stride + e);
+                    const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(a.workspace + (int64_t)(s + 1) * slab_stride + e);
+                    const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(a.workspace + (int64_t)(s + 2) * slab_stride + e);
+                    const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(a.workspace + (int64_t)(s + 3) * slab_stride + e);
+                    sum += v0; sum += v1; sum += v2; sum += v3;
+                }
+                for (; s < a.split_k; ++s) sum += *reinterpret_cast<const f32x4_t*>(a.workspace + (int64_t)s * slab_stride + e);
+                float* dst = local < nk ? G.dw + local : (G.db ? G.db + (local - nk) : nullptr);
+                if (dst) {
+                    if (G.accumulate) sum += *reinterpret_cast<const f32x4_t*>(dst);
+                    *reinterpret_cast<f32x4_t*>(dst) = sum;
+                }
+            } else {
+                for (int k = 0; k < n_valid; ++k) {
+                    float sum = 0.f;
+                    for (int s = 0; s < a.split_k; ++s) sum += a.workspace[(int64_t)s * slab_stride + e + k];
+                    const int64_t lk = local + k;
+                    float* dst = lk < nk ? G.dw + lk : (G.db ? G.db + (lk - nk) : nullptr);
+                    if (dst) *dst = G.accumulate ? *dst + sum : sum;
+                }
+                // the remaining lanes of this piece belong to the next group: its flat start is a multiple of 4, so none do
+            }
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         // slabs are added in slice order (deterministic); four loads are in flight per round
         float sum = 0.f;
@@ -1117,7 +1165,7 @@ extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void*
     if (S > 1) {
         int64_t total = 0;
         for (int g = 0; g < a->n_groups; ++g) total += (int64_t)a->g[g].N * a->g[g].K + a->g[g].N;
-        int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 4096);
+        int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 1024), 4096);       // four floats per thread (one 16-byte piece when aligned)
         hipLaunchKernelGGL(k_bwd_w_reduce, dim3(blocks), dim3(256), 0, st, *a, slab, total);
         CDC_LAUNCH_CHECK("bwd_w_reduce");
     }

@@ -430,7 +430,12 @@ extern "C" int cdc_gemm_bf16_nt(const cdc_g2_args* a, void* stream) {
                       CDC_E_BADARG, "gemm_bf16_nt: segment %d malformed (Kr=%d must be a positive multiple of 64 covered by both rows)", s, S.Kr);
         CDC_CHECK_ARG(((((uintptr_t)S.a) | ((uintptr_t)S.b)) & 15) == 0 && S.lda % 8 == 0 && S.ldb % 8 == 0, CDC_E_ALIGN,
                       "gemm_bf16_nt: segment %d operands must be 16-byte aligned with row strides that are multiples of 8 elements", s);
-        if (S.Kr > max_kr) max_kr = S.Kr;
+    }
+    {   // the longest reduction of any output (all its segments together): what the ring depth / tile choice looks at
+        int64_t per_out[CDC_G2_MAX_OUT] = {0};
+        for (int s = 0; s < a->n_seg; ++s) per_out[a->s[s].out] += a->s[s].Kr;
+        for (int o = 0; o < a->n_out; ++o)
+            if (per_out[o] > max_kr) max_kr = (int)std::min<int64_t>(per_out[o], 1 << 30);
     }
     if (max_m == 0) return 0;
     auto tiles = [&](int bm, int bn) {
@@ -445,8 +450,11 @@ extern "C" int cdc_gemm_bf16_nt(const cdc_g2_args* a, void* stream) {
         const bool narrow = max_n <= 64;
         const int64_t t128 = tiles(128, narrow ? 64 : 128);
         const bool short_rows = t128 < 256;
+        // measured on the C2 launches (tools/gemm2_probe.hip, profiles/round2): 128x128 with two workgroups per CU wins whenever
+        // it fills the chip; under-filled launches take 64-row tiles, and 64x64 when the reduction is long (grad-input of the
+        // first layer: 4096 x 416 outputs over K = 2068 — more, smaller tiles beat deeper rings)
         if (narrow) cfg = short_rows ? 9 : 7;
-        else if (short_rows) cfg = max_kr >= 512 ? 5 : 4;
+        else if (short_rows) cfg = max_kr >= 1024 ? 9 : 10;
         else cfg = 1;
     }
     hipStream_t st = (hipStream_t)stream;

@@ -311,11 +311,20 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_stats(const cdc_bn_fwd_args 
     double s1 = 0.0, s2 = 0.0;
     const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
     const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
-    if (c < S.C)
-        for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
-            const double x = (double)S.x[(int64_t)(t.row_lo + r) * S.ldx + c];
+    if (c < S.C) {
+        constexpr int RPW = CDC_BN_ROWS_PER_BLOCK / WAVES_PER_BLOCK;      // a wave's rows of the chunk: all loads issued before the sums
+        float xv[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int r = r_begin + wave + k * WAVES_PER_BLOCK;
+            xv[k] = r < r_end ? S.x[(int64_t)(t.row_lo + r) * S.ldx + c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {                                  // rows past r_end contribute exact zeros
+            const double x = (double)xv[k];
             s1 += x; s2 += x * x;
         }
+    }
     __shared__ double sh[2][WAVES_PER_BLOCK][64];
     sh[0][wave][lane] = s1; sh[1][wave][lane] = s2;
     __syncthreads();
@@ -325,6 +334,24 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_stats(const cdc_bn_fwd_args 
         double* ws = a.workspace + ((int64_t)t.chunk * total_c + t.col_base + c) * 2;
         ws[0] = s1; ws[1] = s2;
     }
+}
+
+// Sum of a column's per-chunk partials (s1, s2): the block's four waves take chunks w, w+4, ... (loads of a wave in flight
+// together) and the four wave sums are added in wave order — every block of a column forms the same bits.  ALL threads of the
+// block must call this (barrier inside); lanes past the segment's columns read column 0 and ignore the result.
+__device__ __forceinline__ void bn_sum_partials(const double* __restrict__ ws, int used, int total_c, int col, double& s1, double& s2) {
+    __shared__ double bn_part[2][WAVES_PER_BLOCK][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll 4
+    for (int k = wave; k < used; k += WAVES_PER_BLOCK) {
+        const double* p = ws + ((int64_t)k * total_c + col) * 2;
+        a1 += p[0]; a2 += p[1];
+    }
+    bn_part[0][wave][lane] = a1; bn_part[1][wave][lane] = a2;
+    __syncthreads();
+    s1 = ((bn_part[0][0][lane] + bn_part[0][1][lane]) + bn_part[0][2][lane]) + bn_part[0][3][lane];
+    s2 = ((bn_part[1][0][lane] + bn_part[1][1][lane]) + bn_part[1][2][lane]) + bn_part[1][3][lane];
 }
 
 // pass 2: finalise stats for the tile's columns (every block redundantly, fixed order), normalise its rows
@@ -340,19 +367,15 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
     // the reference skips BN when the (group's) batch has one row (MLP / MDR_BatchNorm) or at most one row (DNN)
     const bool skip_norm = (Ms == 1) || (a.skip_le1 && Ms <= 1);
     float mean = 0.f, invstd = 1.f;
+    double p1 = 0.0, p2 = 0.0;
+    if (a.training && !skip_norm && !global_stats)                       // block-uniform
+        bn_sum_partials(a.workspace, (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK, total_c, t.col_base + (c < S.C ? c : 0), p1, p2);
     if (c < S.C && !skip_norm) {
         if (a.training) {
-            double s1 = 0.0, s2 = 0.0;
+            double s1 = p1, s2 = p2;
             if (global_stats) {
                 s1 = a.exchange[2 * (int64_t)(t.col_base + c)];
                 s2 = a.exchange[2 * (int64_t)(t.col_base + c) + 1];
-            } else {
-                const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
-#pragma unroll 8
-                for (int k = 0; k < used; ++k) {
-                    const double* ws = a.workspace + ((int64_t)k * total_c + t.col_base + c) * 2;
-                    s1 += ws[0]; s2 += ws[1];
-                }
             }
             const double mu = Ms > 0 ? s1 / Ms : 0.0;
             double var = Ms > 0 ? s2 / Ms - mu * mu : 0.0;
@@ -382,9 +405,19 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
     if (a.drop_p > 0.f && a.seed_offset_dev) seed += (uint64_t)(uint32_t)(*a.seed_offset_dev) * 0xD1342543DE82EF95ull;
     const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
     const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
-    for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
+    constexpr int RPW = CDC_BN_ROWS_PER_BLOCK / WAVES_PER_BLOCK;
+    float xv[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {                                      // the wave's 16 loads are in flight together
+        const int r = r_begin + wave + k * WAVES_PER_BLOCK;
+        xv[k] = r < r_end ? S.x[(int64_t)(t.row_lo + r) * S.ldx + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int r = r_begin + wave + k * WAVES_PER_BLOCK;
+        if (r >= r_end) break;
         const int64_t gr = t.row_lo + r;
-        float v = S.x[gr * S.ldx + c];
+        float v = xv[k];
         if (!skip_norm) v = (v - mean) * invstd * gam + bet;
         if (a.relu) v = fmaxf(v, 0.f);
         if (a.drop_p > 0.f) {
@@ -465,11 +498,23 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_stats(const cdc_bn_bwd_a
     const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
     if (c < S.C && t.M != 1) {
         const float mean = S.save_mean[c], invstd = S.save_invstd[c];
-        for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
-            const int64_t gr = t.row_lo + r;
-            float dz = S.dy[gr * S.lddy + c];
-            if (a.relu || a.mask_scale != 1.f) dz = S.y[gr * S.ldy + c] > 0.f ? dz * a.mask_scale : 0.f;
-            const float xhat = (S.x[gr * S.ldx + c] - mean) * invstd;
+        constexpr int RPW = CDC_BN_ROWS_PER_BLOCK / WAVES_PER_BLOCK;
+        const bool masked = a.relu || a.mask_scale != 1.f;
+        float dv[RPW], yv[RPW], xv[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {                                  // 48 loads in flight per lane instead of 3
+            const int r = r_begin + wave + k * WAVES_PER_BLOCK;
+            const bool ok = r < r_end;
+            const int64_t gr = t.row_lo + (ok ? r : r_begin);
+            dv[k] = ok ? S.dy[gr * S.lddy + c] : 0.f;
+            yv[k] = (ok && masked) ? S.y[gr * S.ldy + c] : 1.f;
+            xv[k] = S.x[gr * S.ldx + c];
+        }
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {                                  // rows past r_end carry dz = 0: exact zeros in both sums
+            float dz = dv[k];
+            if (masked) dz = yv[k] > 0.f ? dz * a.mask_scale : 0.f;
+            const float xhat = (xv[k] - mean) * invstd;
             s1 += (double)dz; s2 += (double)dz * (double)xhat;
         }
     }
@@ -490,19 +535,13 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
     const cdc_bn_bseg& S = a.s[t.seg];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = t.c0 + lane;
-    if (c >= S.C) return;
     const bool global_stats = a.training && a.phase == 2 && a.exchange;
     const int Ms = global_stats ? (int)(a.exchange[2 * (int64_t)total_c + t.seg] + 0.5) : t.M;
     const bool skip_norm = (Ms == 1);
     double s1 = 0.0, s2 = 0.0;
-    if (!skip_norm) {
-        const int used = (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK;
-#pragma unroll 8
-        for (int k = 0; k < used; ++k) {
-            const double* ws = a.workspace + ((int64_t)k * total_c + t.col_base + c) * 2;
-            s1 += ws[0]; s2 += ws[1];
-        }
-    }
+    if (!skip_norm)                                                      // block-uniform; every thread takes part (barrier inside)
+        bn_sum_partials(a.workspace, (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK, total_c, t.col_base + (c < S.C ? c : 0), s1, s2);
+    if (c >= S.C) return;
     if (t.chunk == 0 && wave == 0) {
         // parameter gradients stay LOCAL sums: the data-parallel all-reduce of the gradient arena adds the ranks up
         if (S.dbeta) S.dbeta[c] = (float)s1;
@@ -519,14 +558,30 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
     const float db = (float)s1, dg = (float)s2;
     const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
     const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
-    for (int r = r_begin + wave; r < r_end; r += WAVES_PER_BLOCK) {
+    constexpr int RPW = CDC_BN_ROWS_PER_BLOCK / WAVES_PER_BLOCK;
+    const bool masked = a.relu || a.mask_scale != 1.f;
+    const bool need_x = !skip_norm && a.training;
+    float dv[RPW], yv[RPW], xv[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int r = r_begin + wave + k * WAVES_PER_BLOCK;
+        const bool ok = r < r_end;
+        const int64_t gr = t.row_lo + (ok ? r : r_begin);
+        dv[k] = ok ? S.dy[gr * S.lddy + c] : 0.f;
+        yv[k] = (ok && masked) ? S.y[gr * S.ldy + c] : 1.f;
+        xv[k] = need_x ? S.x[gr * S.ldx + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int r = r_begin + wave + k * WAVES_PER_BLOCK;
+        if (r >= r_end) break;
         const int64_t gr = t.row_lo + r;
-        float dz = S.dy[gr * S.lddy + c];
-        if (a.relu || a.mask_scale != 1.f) dz = S.y[gr * S.ldy + c] > 0.f ? dz * a.mask_scale : 0.f;
+        float dz = dv[k];
+        if (masked) dz = yv[k] > 0.f ? dz * a.mask_scale : 0.f;
         float dx;
         if (skip_norm) dx = dz;
         else if (a.training) {
-            const float xhat = (S.x[gr * S.ldx + c] - mean) * invstd;
+            const float xhat = (xv[k] - mean) * invstd;
             dx = gam * invstd * (dz - invM * (db + xhat * dg));
         } else dx = gam * invstd * dz;
         float* dst = S.dx + gr * S.lddx + c;

@@ -168,7 +168,8 @@ def _bn_seg(x, norm, out=None, row_group=0):
             "num_batches_tracked": norm.num_batches_tracked, "row_group": row_group}
 
 
-def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmoid=False, final_outs=None, last_outs=None):
+def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmoid=False, final_outs=None, last_outs=None,
+              head_out=None, head_wide=None):
     """Runs structurally identical MultiLayerPerceptrons side by side: one grouped-linear launch (and one
     BatchNorm launch) per layer depth for all of them.
 
@@ -219,6 +220,11 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
             cur = [op.outs[i] for i in range(n)]
         if n_extra:
             extra_outs = op.outs[n:]
+    if mlps[0].out_linear is not None and head_out is not None:
+        # the output layers of all towers, the wide term and the sigmoid in one launch per direction (csrc/head.hip)
+        towers = [{"x": cur[i], "w": m.out_linear.weight, "b": m.out_linear.bias} for i, m in enumerate(mlps)]
+        P.TowerHead(plan, towers, head_out, wide=head_wide, addends=final_addends, sigmoid=final_sigmoid)
+        return [head_out.slice(i, i + 1) for i in range(n)], extra_outs
     if mlps[0].out_linear is not None:
         groups = []
         for i, m in enumerate(mlps):
@@ -431,9 +437,21 @@ class BaseModel(HipModule):
         output_layers = nn.ModuleList([nn.Sigmoid() for _ in range(n_tower)])
         return towers, None, output_layers
 
-    def describe_towers(self, plan, tower_inputs, other_outs, out):
-        """tower MLP -> `+= other` for every other logit -> sigmoid -> column i of `out` [B, n_tower]."""
-        finals = [out.slice(i, i + 1) for i in range(len(self.towers))]
+    def describe_towers(self, plan, tower_inputs, other_outs, out, wide_in=None):
+        """tower MLP -> `+= other` for every other logit -> sigmoid -> column i of `out` [B, n_tower].
+        wide_in: the embeddings buffer when the caller has NOT described the wide term itself: it is then formed inside the
+        fused head launch (csrc/head.hip) together with the towers' output layers; other_outs are the further logits."""
+        import os
+        n = len(self.towers)
+        fused = (wide_in is not None and n <= P.L.HEAD_MAX_TOWERS and len(other_outs) <= 2 and
+                 all(t.out_linear is not None for t in self.towers) and os.environ.get("CDC_FUSED_HEAD", "1") != "0")
+        if wide_in is not None and not fused:
+            other_outs = [self.linear.describe(plan, wide_in)] + list(other_outs)
+        if fused:
+            wide = {"x": wide_in, "w": self.linear.fc.weight, "b": self.linear.fc.bias}
+            mlp_stack(plan, list(self.towers), tower_inputs, final_addends=other_outs, final_sigmoid=True, head_out=out, head_wide=wide)
+            return out
+        finals = [out.slice(i, i + 1) for i in range(n)]
         mlp_stack(plan, list(self.towers), tower_inputs, final_addends=other_outs, final_sigmoid=True, final_outs=finals)
         return out
 

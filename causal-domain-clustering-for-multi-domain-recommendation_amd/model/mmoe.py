@@ -47,11 +47,11 @@ class MMoE(BaseModel):
         first = outs[0]
         experts = P.Buf(first.root, first.rows, self.n_expert * self.expert_out, first.ld, 0, plan)
         pool = P.GatePool(plan, experts, self.n_expert, self.expert_out, [(lg, list(range(self.n_expert))) for lg in gate_logits])
-        others = [self.linear.describe(plan, E)]
+        others = []                                                      # the wide term (mmoe.py:62) is formed inside the head launch
         if self.use_atten:
             others.append(self.describe_atten(plan, E))                  # mmoe.py:68-70
         out = plan.new(self.n_tower)
-        self.describe_towers(plan, pool.outs, others, out)
+        self.describe_towers(plan, pool.outs, others, out, wide_in=E)
         return [out], [], []
 
     def forward(self, x):

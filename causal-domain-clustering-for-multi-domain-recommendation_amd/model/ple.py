@@ -100,11 +100,11 @@ class PLE(BaseModel):
         inputs = [E] * (self.n_tower + 1)
         for cgc in self.cgc_layers:
             inputs = cgc.describe(plan, inputs)
-        others = [self.linear.describe(plan, E)]
+        others = []                                                      # the wide term (ple.py:61) is formed inside the head launch
         if self.use_atten:
             others.append(self.describe_atten(plan, E))                  # ple.py:65-67
         out = plan.new(self.n_tower)
-        self.describe_towers(plan, inputs[:self.n_tower], others, out)
+        self.describe_towers(plan, inputs[:self.n_tower], others, out, wide_in=E)
         return [out], [], []
 
     def forward(self, x):

@@ -77,6 +77,16 @@ class FusedAdam:
             l2_of[id(p)] = l2_of.get(id(p), 0.0) + l2
         self._l2_of = l2_of
         self.l2_table = l2_of.get(id(self.table), 0.0)
+        # fast replay in scaled state (csrc/common.h adam_replay_wave_scaled): constants and the per-step table, in double
+        self._k1 = self._k2 = 0.0
+        self.replay_tab = None
+        c = float(torch.tensor(2.0 * f32(self.l2_table) + self._wd, dtype=torch.float64).to(torch.float32))
+        if self.fast_replay and c > 0.0 and os.environ.get("CDC_SCALED_REPLAY", "1") != "0":
+            self._k1, self._k2 = f32(self._lerp_w * c), f32(self._omb2 * c * c)
+            if self._k1 > 0.0 and self._k2 > 0.0:
+                t64 = tab.double()
+                rt = torch.stack([t64[:, 0] * self._k1 * t64[:, 1] / math.sqrt(self._k2), self._eps * t64[:, 1] / math.sqrt(self._k2)], dim=1)
+                self.replay_tab = rt.to(torch.float32).to(dev).contiguous()
         self.state = {}                                                       # id(param) -> (m, v)
         self.table_m = torch.zeros_like(self.table.data)
         self.table_v = torch.zeros_like(self.table.data)
@@ -99,6 +109,8 @@ class FusedAdam:
         hp.n_scalars = self.scalars.shape[0]
         hp.fast_replay = 1 if self.fast_replay else 0
         hp.inv_bc2 = self.inv_bc2.data_ptr()
+        hp.replay_tab = None if self.replay_tab is None else self.replay_tab.data_ptr()
+        hp.k1, hp.k2 = self._k1, self._k2
         return hp
 
     def _stream(self):

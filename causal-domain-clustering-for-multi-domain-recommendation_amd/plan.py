@@ -1300,6 +1300,89 @@ class RowDot:
         plan.bwd_steps.extend(post)
 
 
+class TowerHead:
+    """The tower head in one launch per direction (csrc/head.hip; model/layer.py:48-56): per tower the output Linear(->1), plus the
+    wide term formed once per row, plus further [B,1] logits, sigmoid, column t of `out`.  The backward also forms the wide
+    term's gradient (the sum of the towers' logit gradients) and, with the trainer's fused loss, BCELoss and its gradient.
+
+    towers: list of dicts {x: Buf [B,K], w: Parameter [1,K] or [K], b: Parameter [1] or None};  out: Buf [B, n_tower];
+    wide: dict {x: Buf [B,Kw], w, b} or None;  addends: Bufs [B,1]."""
+
+    def __init__(self, plan, towers, out, wide=None, addends=(), sigmoid=True):
+        assert 0 < len(towers) <= L.HEAD_MAX_TOWERS and len(addends) <= 2 and out.cols == len(towers)
+        self.towers, self.out, self.wide, self.addends, self.sigmoid = towers, out, wide, list(addends), sigmoid
+        self.M = plan.B
+        for t in towers:
+            assert t["x"].cols == t["w"].numel()
+            if t["x"].mask is not None:
+                raise RuntimeError("the tower head cannot consume an activation-fused linear output")
+        if wide is not None:
+            assert wide["x"].cols == wide["w"].numel()
+        width = sum(t["w"].numel() + 1 for t in towers) + (wide["w"].numel() + 1 if wide is not None else 0)
+        self.ws = torch.empty(L.ROWDOT_PARTS * width, dtype=torch.float32, device=plan.device)
+        self._keep = []
+        plan.add(self)
+
+    def _fill(self, a, plan):
+        a.n_tower, a.sigmoid, a.n_addend, a.M = len(self.towers), 1 if self.sigmoid else 0, len(self.addends), self.M
+        a.out, a.ld_out = self.out.ptr, self.out.ld
+        for i, t in enumerate(self.towers):
+            T = a.t[i]
+            T.x, T.ldx = t["x"].ptr, t["x"].ld
+            T.w = t["w"].data_ptr()
+            T.bias = None if t.get("b") is None else t["b"].data_ptr()
+            T.K = t["w"].numel()
+        if self.wide is not None:
+            w = self.wide
+            a.wide_x, a.ld_wide = w["x"].ptr, w["x"].ld
+            a.wide_w = w["w"].data_ptr()
+            a.wide_bias = None if w.get("b") is None else w["b"].data_ptr()
+            a.wide_K = w["w"].numel()
+        for i, ad in enumerate(self.addends):
+            a.addend[i], a.ld_addend[i] = ad.ptr, ad.ld
+
+    def build_fwd(self, plan):
+        a = L.HeadArgs()
+        self._fill(a, plan)
+        self._keep.append(a)
+        plan.fwd_steps.append(plan.call("cdc_head_fwd", C.byref(a)))
+
+    def build_bwd(self, plan, gs):
+        a = L.HeadArgs()
+        self._fill(a, plan)
+        plan.ensure_grad(self.out, gs)
+        og = self.out.grad
+        a.d_out, a.ld_dout = og.ptr, og.ld
+        for i, t in enumerate(self.towers):
+            T = a.t[i]
+            xg = t["x"].grad
+            T.accumulate_dx = 1 if gs.claim(t["x"]) else 0
+            T.dx, T.lddx = xg.ptr, xg.ld
+            if plan._claim_param(t["w"]) or (t.get("b") is not None and plan._claim_param(t["b"])):
+                raise RuntimeError("a tower's output layer is used twice in one plan")
+            T.dw = plan.param_grad(t["w"]).data_ptr()
+            T.dbias = None if t.get("b") is None else plan.param_grad(t["b"]).data_ptr()
+        if self.wide is not None:
+            w = self.wide
+            if w["x"].mask is not None:
+                raise RuntimeError("the wide term cannot consume an activation-fused linear output")
+            xg = w["x"].grad
+            a.accumulate_wide_dx = 1 if gs.claim(w["x"]) else 0
+            a.wide_dx, a.ld_wide_dx = xg.ptr, xg.ld
+            if plan._claim_param(w["w"]) or (w.get("b") is not None and plan._claim_param(w["b"])):
+                raise RuntimeError("the wide term's parameters are used twice in one plan")
+            a.wide_dw = plan.param_grad(w["w"]).data_ptr()
+            a.wide_dbias = None if w.get("b") is None else plan.param_grad(w["b"]).data_ptr()
+        for i, ad in enumerate(self.addends):
+            adg = ad.grad
+            a.accumulate_d_addend[i] = 1 if gs.claim(ad) else 0
+            a.d_addend[i], a.ld_d_addend[i] = adg.ptr, adg.ld
+        a.workspace = self.ws.data_ptr()
+        self._keep.append(a)
+        self.bwd_args = [a]                      # (trainer: the fused BCE is switched on in this launch)
+        plan.bwd_steps.append(plan.call("cdc_head_bwd", C.byref(a)))
+
+
 class CrossLayer:
     """DCN-v1 cross layer (model/layer.py:321-329): out = x0 * (xl·w) + b + xl."""
 

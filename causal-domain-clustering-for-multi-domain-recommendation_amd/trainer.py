@@ -132,6 +132,10 @@ class TrainStep:
         from . import plan as P
         out = self.out
         for op in self.plan.ops:
+            if isinstance(op, P.TowerHead) and op.sigmoid and op.out.root is out.root and op.out.col0 == out.col0 and op.out.cols == out.cols:
+                args = getattr(op, "bwd_args", [])
+                return args[0] if len(args) == 1 and op.M == self.B else None
+        for op in self.plan.ops:
             if not isinstance(op, P.RowDot) or not op.sigmoid or op.row_offsets is not None or len(op.groups) != out.cols:
                 continue
             if all(g["out"].root is out.root and g["out"].col0 == out.col0 + i and g["out"].cols == 1 for i, g in enumerate(op.groups)):

@@ -125,6 +125,9 @@ typedef struct {
                                        the dense pass), 1 = v_rcp_f32 / v_sqrt_f32 (1 ulp each; ~6x fewer instructions; the
                                        replayed trajectory stays within 1e-7 of the exact one, see tests) */
     const float* inv_bc2;           /* fast_replay: device table [n_scalars] of 1/sqrt(1-beta2^t) */
+    const float* replay_tab;        /* fast_replay in scaled state (NULL = off): device table [n_scalars][2] of
+                                       {A_t = step_size_t * k1 * sqrt(1-beta2^t) / sqrt(k2),  E_t = eps * sqrt(1-beta2^t) / sqrt(k2)} */
+    float k1, k2;                   /* k1 = (1-beta1) * (2*l2 + wd),  k2 = (1-beta2) * (2*l2 + wd)^2  (fp32; both > 0 to enable) */
 } cdc_adam_hp;
 
 /* Exact dense-Adam semantics for the whole table, in three launches:
@@ -529,6 +532,54 @@ typedef struct {
 } cdc_rowdot_bwd_args;
 #define CDC_ROWDOT_PARTS 256
 int cdc_rowdot_bwd(const cdc_rowdot_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The tower head in one launch per direction (reference: BaseModel.tower_forward, model/layer.py:48-56 — the towers' output
+ * Linear(->1) model/layer.py:193, `y_logits += other` for the wide term FeaturesLinear model/layer.py:122-126 and further
+ * logits, Sigmoid, cat to [B, n_tower]; backward incl. BCELoss(mean) on the row's own tower, run.py:484,723):
+ *   shared[b]  = wide_x[b,:] . wide_w + wide_bias                         (formed once per row; optional)
+ *   out[b,t]   = sigmoid?( x_t[b,:] . w_t + bias_t + shared[b] + sum_i addend_i[b] )
+ * backward: d_t = d_out[b,t] (or the fused BCE gradient) * out (1 - out);  dx_t = d_t w_t;  dw_t = sum_b d_t x_t;  db_t = sum_b d_t;
+ *   dsum = sum_t d_t  ->  d_addend_i (+)= dsum;  wide_dx (+)= dsum wide_w;  wide_dw = sum_b dsum wide_x;  wide_dbias = sum_b dsum.
+ * Cross-row sums: CDC_ROWDOT_PARTS row parts in `workspace` (cdc_head_workspace_floats), added in index order (deterministic).
+ * ---------------------------------------------------------------------------------------- */
+#define CDC_HEAD_MAX_TOWERS 8
+typedef struct {
+    const float* x; int64_t ldx;          /* [M,K] the tower's last hidden activations */
+    const float* w; const float* bias;    /* [K], [1] or NULL */
+    float* dx; int64_t lddx;              /* backward: [M,K] or NULL */
+    float* dw; float* dbias;              /* backward: [K], [1] (may be NULL) */
+    int32_t K;
+    int32_t accumulate_dx;
+} cdc_head_tower;
+typedef struct {
+    int32_t n_tower, sigmoid, n_addend, pad_;
+    int64_t M;
+    float* out; int64_t ld_out;           /* [M, n_tower] forward output (read by the backward) */
+    const float* d_out; int64_t ld_dout;  /* backward without the fused loss: grad w.r.t. out */
+    const float* wide_x; int64_t ld_wide; /* [M, wide_K] or NULL: the wide term's input (the gathered embeddings) */
+    const float* wide_w; const float* wide_bias;
+    float* wide_out; int64_t ld_wide_out; /* optional copy of shared[b] ([M,1]), may be NULL */
+    float* wide_dx; int64_t ld_wide_dx;   /* backward: [M, wide_K] or NULL */
+    float* wide_dw; float* wide_dbias;
+    int32_t wide_K, accumulate_wide_dx;
+    const float* addend[2]; int64_t ld_addend[2];       /* further logits added to every tower ([M,1] each) */
+    float* d_addend[2]; int64_t ld_d_addend[2];         /* backward: their gradients (may be NULL) */
+    int32_t accumulate_d_addend[2];
+    float* workspace;                     /* backward: >= cdc_head_workspace_floats() floats */
+    /* fused BCELoss(mean) as in cdc_rowdot_bwd_args: set bce_y_i16 or bce_y_f32 */
+    const int64_t* bce_group;
+    const int16_t* bce_y_i16;
+    const float* bce_y_f32;
+    float* bce_loss;
+    double* bce_partial;                  /* >= CDC_ROWDOT_PARTS doubles */
+    float bce_inv_count;
+    int32_t pad2_;
+    cdc_head_tower t[CDC_HEAD_MAX_TOWERS];
+} cdc_head_args;
+int cdc_head_fwd(const cdc_head_args* a, void* stream);
+int cdc_head_bwd(const cdc_head_args* a, void* stream);
+int64_t cdc_head_workspace_floats(const cdc_head_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * Loss (reference: run.py:484,723 — BCELoss(mean) on probabilities gathered by group column,
