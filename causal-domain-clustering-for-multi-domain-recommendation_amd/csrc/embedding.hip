@@ -1057,6 +1057,144 @@ extern "C" int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* un
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// catch-up + gather in ONE pass over the batch's table rows (model/layer.py:147-157 on the lazy table): the group of lanes that
+// brings a unique row up to date holds the current row in registers — it writes the row back to the table AND to every batch
+// position that looks it up (fp32 embeddings + their bf16 shadow), so the forward never re-reads the table.  Rows looked up
+// a few times (<= 4) are written by their own lanes; a row looked up more often (a domain column: three rows, ~B/3 positions
+// each; the head of a Zipf distribution) is handed to the whole wave: its values are broadcast lane to lane and the 64 lanes
+// write its positions side by side — the hot row is read from HBM once per step, however many samples carry it.
+// Ids outside the table (row -1 in the sorted lists) yield zero rows, like cdc_embed_gather_fwd.
+// ------------------------------------------------------------------------------------------------
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_lazy_catchup_gather(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
+                                                             const int32_t* __restrict__ seg_start, const int32_t* __restrict__ perm,
+                                                             float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                                                             int32_t* __restrict__ last, cdc_adam_hp hp,
+                                                             const int32_t* __restrict__ step_dev, float* __restrict__ out,
+                                                             __bf16* __restrict__ out_h, int64_t ld_out_h, int32_t B, int32_t F, int32_t D) {
+    typedef __bf16 h4_t __attribute__((ext_vector_type(4)));
+    const AdamConsts c = make_consts(hp);
+    const int target = *step_dev - 1;
+    const int chunks = D / 4;                                           // lanes per row; divides 64 (checked by the launcher)
+    const int lane = threadIdx.x & 63;
+    const int64_t total = (int64_t)F * B * chunks;
+    const int64_t ld_out = (int64_t)F * D;
+    auto put = [&](int b, int f, int ch, float x0, float x1, float x2, float x3) {
+        *reinterpret_cast<float4*>(out + (int64_t)b * ld_out + (int64_t)f * D + ch * 4) = make_float4(x0, x1, x2, x3);
+        if (out_h) {
+            h4_t h = {(__bf16)x0, (__bf16)x1, (__bf16)x2, (__bf16)x3};
+            *reinterpret_cast<h4_t*>(out_h + (int64_t)b * ld_out_h + (int64_t)f * D + ch * 4) = h;
+        }
+    };
+    // uniform trip count and no early exits: every lane of a wave reaches the replay and the wave-cooperative part
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        bool has = i < total;                                           // this lane belongs to a unique row of the batch
+        int ch = 0, f = 0, j = 0, from = target;
+        int64_t row = -1;
+        int p0 = 0, n = 0;
+        if (has) {
+            ch = (int)(i % chunks);
+            const int64_t slot = i / chunks;
+            f = (int)(slot / B);
+            j = (int)(slot - (int64_t)f * B);
+            has = j < uniq_cnt[f];
+        }
+        if (has) {
+            row = uniq_row[(int64_t)f * B + j];
+            p0 = seg_start[(int64_t)f * (B + 1) + j];
+            n = seg_start[(int64_t)f * (B + 1) + j + 1] - p0;
+        }
+        const bool real = has && row >= 0;                              // < 0: ids outside the table (zero rows)
+        if (real) from = last[row];
+        const bool act = real && from < target;
+        if (!act) from = target;
+        if (!__any(has)) continue;                                      // wave-uniform
+        const int64_t e0 = real ? row * D + ch * 4 : 0;
+        float wv[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (real) {
+            const float4 a4 = *reinterpret_cast<const float4*>(w + e0);
+            wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
+        }
+        if (act) {
+            const float4 b4 = *reinterpret_cast<const float4*>(m + e0), c4 = *reinterpret_cast<const float4*>(v + e0);
+            mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
+            vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
+        }
+        // short segments: the positions' batch rows, fetched before the replay (their latency hides under it)
+        int bq[4] = {0, 0, 0, 0};
+        const bool inline_seg = has && n <= 4;
+        if (inline_seg) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < n) bq[q] = perm[(int64_t)f * B + p0 + q];
+        }
+        adam_replay_wave<FAST, 4>(wv, mv, vv, from, target, c, hp);
+        if (act) {
+            *reinterpret_cast<float4*>(w + e0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            *reinterpret_cast<float4*>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            if (ch == 0) last[row] = target;                            // the row's lanes sit in one wave and have all read last[row]
+        }
+        if (inline_seg) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < n) put(bq[q], f, ch, wv[0], wv[1], wv[2], wv[3]);
+        }
+        // longer segments: one at a time, the whole wave writes the row's positions
+        unsigned long long todo = __ballot(has && n > 4 && ch == 0);
+        while (todo) {
+            const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);      // lane of the row's chunk 0
+            todo &= todo - 1;
+            const int sf = __builtin_amdgcn_readlane(f, L), sp0 = __builtin_amdgcn_readlane(p0, L), sn = __builtin_amdgcn_readlane(n, L);
+            const int items = sn * chunks;
+            // lane l serves chunk (l % chunks) of positions l / chunks, + 64 / chunks, ...: its four values are fixed for the whole
+            // segment (one shuffle each); the positions' batch rows are fetched eight at a time (a dependent load per position
+            // made a domain column's ~B/3 positions the longest chain of the launch)
+            const int pc = lane % chunks, ppl = lane / chunks, pstep = 64 / chunks;
+            const float x0 = __shfl(wv[0], L + pc, 64), x1 = __shfl(wv[1], L + pc, 64);
+            const float x2 = __shfl(wv[2], L + pc, 64), x3 = __shfl(wv[3], L + pc, 64);
+            (void)items;
+            for (int pb = ppl; pb < sn; pb += 8 * pstep) {
+                int bb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int pp = pb + q * pstep;
+                    bb[q] = pp < sn ? perm[(int64_t)sf * B + sp0 + pp] : -1;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (bb[q] >= 0) put(bb[q], sf, pc, x0, x1, x2, x3);
+            }
+        }
+    }
+}
+
+extern "C" int cdc_embed_lazy_catchup_gather(const int32_t* uniq_row, const int32_t* uniq_cnt, const int32_t* seg_start, const int32_t* perm,
+                                             float* w, float* m, float* v, int32_t* last, cdc_adam_hp hp, const int32_t* step_dev,
+                                             float* out, void* out_h, int64_t ld_out_h, int64_t B, int32_t F, int32_t D, void* stream) {
+    CDC_CHECK_ARG(uniq_row && uniq_cnt && seg_start && perm && w && m && v && last && step_dev && out && hp.step_scalars && hp.n_scalars > 0,
+                  CDC_E_BADARG, "embed_lazy_catchup_gather: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && D % 4 == 0 && 64 % (D / 4) == 0, CDC_E_BADARG,
+                  "embed_lazy_catchup_gather: emb_dim must be 4, 8, 16, 32, 64, 128 or 256 (a row's 16-byte lanes share one wave)");
+    CDC_CHECK_ARG(((((uintptr_t)w | (uintptr_t)m | (uintptr_t)v | (uintptr_t)out) & 15) == 0), CDC_E_ALIGN,
+                  "embed_lazy_catchup_gather: table and output must be 16-byte aligned");
+    CDC_CHECK_ARG(!out_h || (ld_out_h >= (int64_t)F * D && ld_out_h % 4 == 0 && (((uintptr_t)out_h) & 7) == 0), CDC_E_BADARG,
+                  "embed_lazy_catchup_gather: malformed bf16 shadow");
+    CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_catchup_gather: fast_replay needs the inv_bc2 table");
+    const int64_t total = (int64_t)F * B * (D / 4);
+    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    if (hp.fast_replay)
+        hipLaunchKernelGGL((k_lazy_catchup_gather<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, seg_start, perm,
+                           w, m, v, last, hp, step_dev, out, reinterpret_cast<__bf16*>(out_h), ld_out_h, (int32_t)B, F, D);
+    else
+        hipLaunchKernelGGL((k_lazy_catchup_gather<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, seg_start, perm,
+                           w, m, v, last, hp, step_dev, out, reinterpret_cast<__bf16*>(out_h), ld_out_h, (int32_t)B, F, D);
+    CDC_LAUNCH_CHECK("embed_lazy_catchup_gather");
+    return 0;
+}
+
 // step t for the batch's rows: rows are at t-1 after catchup (last[] still holds the older value,
 // which is ignored here); writes last[row] = t.
 template <int VEC>

@@ -203,6 +203,19 @@ class FusedAdam:
         if flush:
             self.flush_slice()
 
+    def begin_step_catchup_gather(self, ids, offsets, out_ptr, out_h, ld_out_h, B, F, D, err=None, flush=True):
+        """begin_step_catchup() whose catch-up launch also IS the gather of the step (cdc_embed_lazy_catchup_gather): the lanes
+        that bring a row up to date write it to every batch position that looks it up — `out` [B, F*D] fp32 (+ the bf16 shadow)."""
+        assert self.table_mode == "lazy"
+        s = self._stream()
+        ws = self.begin_step_sort(ids, offsets, B, F, D, err=err)
+        L.launch("cdc_embed_lazy_catchup_gather", self.lib.cdc_embed_lazy_catchup_gather,
+                 (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), self.table.data_ptr(),
+                  self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(), self.step_dev.data_ptr(),
+                  out_ptr, out_h, ld_out_h, B, F, D), s, nbytes=float(B) * F * (D * 4 + 4 + D * 4))
+        if flush:
+            self.flush_slice()
+
     def table_catchup(self, ids, offsets, idx, B, F, D, flush=True):
         """lazy mode, BEFORE the gather of this step: row indices -> dedupe -> replay the rows up to step t-1."""
         assert self.table_mode == "lazy"

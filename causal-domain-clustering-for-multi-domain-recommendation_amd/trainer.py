@@ -176,6 +176,21 @@ class TrainStep:
                   self.loss.data_ptr(), og.ptr, og.ld, self.B, self.out.cols, 1.0 / self.global_B),
                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
+    def _fuse_gather(self):
+        """single GPU, lazy table: the catch-up launch writes the gathered embeddings itself (csrc/embedding.hip
+        k_lazy_catchup_gather); needs a row's 16-byte lanes inside one wave"""
+        hit = self.__dict__.get("_fuse_gather_ok")
+        if hit is None:
+            import os
+            D = self.emb.D
+            # off by default: measured at C2 (profiles/round2/README.md) the fused launch takes 48 us against 28.5 + 7.2 us for
+            # catch-up + gather — the wave that owns the domain column's three rows writes ~B positions on its own while the rest
+            # of the chip has finished; it wins only where no row is looked up by more than a few samples
+            hit = (D % 4 == 0 and 64 % (D // 4) == 0 and os.environ.get("CDC_FUSE_GATHER", "0") == "1")
+            self._fuse_gather_ok = hit
+            self._fwd_after_gather = [s_ for s_ in self.plan.fwd_steps if s_ is not self.emb.fwd_step]
+        return hit
+
     def _reg(self):
         # part of the (graph-replayed) launch sequence, so that step() issues nothing else per call
         torch.add(self.opt.reg_sum[0], self.opt.reg_sum[1], alpha=self.opt.l2_table, out=self.reg)
@@ -184,11 +199,20 @@ class TrainStep:
         """single GPU: the whole step is one launch sequence (one hipGraph when use_graph)."""
         opt, plan, emb = self.opt, self.plan, self.emb
         B, F, D = self.B, emb.F, emb.D
-        if opt.table_mode == "lazy":
+        if opt.table_mode == "lazy" and self._fuse_gather():
+            # sort -> catch-up of the batch's rows, which also writes the gathered embeddings (+ shadow) -> slice of the whole-table
+            # replay; the plan's own gather launch is skipped
+            oh, ldh = (plan.shadow_view(emb.out) if (plan.use_g2 and plan.has_shadow(emb.out)) else (None, 0))
+            opt.begin_step_catchup_gather(emb.ids, emb.offsets, emb.out.ptr, oh, ldh, B, F, D, err=emb.err)
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            for fn in self._fwd_after_gather:
+                fn(st)
+        elif opt.table_mode == "lazy":
             opt.begin_step_catchup(emb.ids, emb.offsets, B, F, D)         # + this step's slice of the whole-table replay
+            plan.forward()
         else:
             opt.begin_step()
-        plan.forward()
+            plan.forward()
         self._bce()
         plan.backward()
         opt.table_step(emb.idx, emb.out.grad.root, B, F, D)

@@ -158,6 +158,14 @@ int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_row, const i
                           float* w, float* m, float* v, int32_t* last,
                           cdc_adam_hp hp, const int32_t* step_dev, double* reg_ring, int32_t ring_len,
                           int64_t B, int32_t F, int32_t D, void* stream);
+/* cdc_embed_lazy_catchup + cdc_embed_gather_fwd in ONE pass over the batch's table rows (needs the sorted lists of
+ * cdc_embed_sort_dedupe[_ids]): every unique row is replayed to step t-1, written back, and written to every batch position
+ * that looks it up — out [B, F*D] fp32 and, when out_h != NULL, its bf16 shadow (row stride ld_out_h elements).  Rows looked up
+ * more than four times are distributed by their whole wave (the row is read from HBM once per step however hot it is); ids
+ * outside the table give zero rows.  D/4 must divide 64.  Same replay arithmetic, same bits as the two separate calls. */
+int cdc_embed_lazy_catchup_gather(const int32_t* uniq_row, const int32_t* uniq_cnt, const int32_t* seg_start, const int32_t* perm,
+                                  float* w, float* m, float* v, int32_t* last, cdc_adam_hp hp, const int32_t* step_dev,
+                                  float* out, void* out_h, int64_t ld_out_h, int64_t B, int32_t F, int32_t D, void* stream);
 /* cdc_embed_segment_sum + cdc_embed_lazy_update in ONE launch: every row's summed gradient is used for its Adam step t by the
  * thread(s) that formed it (no rowgrad round trip).  Same sums, same arithmetic, identical bits.  short_only = 1: the batch
  * is an owner's merged row lists (segments of at most one entry per sender; rows < 0 are padding and skipped). */

@@ -1,99 +1,62 @@
-"""AUC parity of the HIP training path against the CPU oracle driven with the reference's semantics (dense table
-gradient, whole-table L2, dense torch.optim.Adam) — same synthetic data with a planted teacher, same initial weights,
-same batches, dropout 0 (torch's dropout stream cannot be reproduced).  North-star bound: |dAUC| <= 1e-4."""
+"""AUC parity at the scale SURVEY.md 8d prescribes (fast variant): PLE-3 with the reference's dims, 26 fields x vocab 10k,
+emb_dim 16, 488 training steps of 4096 rows, 0.5 M evaluation rows, dropout 0, same synthetic data and initial tensors on
+both sides.
+
+The CPU sides were run in the build container by tools/auc_parity.py — the REFERENCE itself (/root/reference/model/ple.py driven
+like run.py:481-493), the reference with every batch's rows reversed (same mathematics, other summation order), and the CPU
+restatement (oracle) — and their AUC / logloss are the committed fixture tests/golden/auc_parity_v10k.json.  This test trains
+the HIP path (exact-fp32 and bf16 contractions) on the same data from the same initial state and holds it to
+
+    |AUC_hip - AUC_ref|  <=  max(1e-4, the largest CPU-vs-CPU gap at THIS scale)
+
+The north star's 1e-4 alone is not reachable by any implementation: the reference does not reproduce itself to 1e-4 under a
+change of summation order at this scale (profiles/round2/auc_parity.md: 1.4e-3 here, 1.8e-4 with Zipf ids, 5.9e-4 at
+vocab 1 M) — Adam turns rounding-level differences of near-zero gradients into +-lr moves and the trajectories part.
+"""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from helpers import O, is_pre_bn_bias, make_ids
+from helpers import O
 
 pytestmark = pytest.mark.gpu
 
-
-def _run_cpu(sd0, field_dims, Xtr, ytr, gtr, Xev, B, n_steps, reverse_rows=False, freeze_noise=False):
-    leaves = {k: v.clone().requires_grad_(True) for k, v in sd0.items() if v.dtype.is_floating_point and "running_" not in k}
-    sd = dict(sd0)
-    sd.update(leaves)
-    l2 = {n: 1e-5 for n in O.reg_names(list(sd), "ple")}
-    trained = [v for k, v in leaves.items() if not (freeze_noise and is_pre_bn_bias(k, set(sd0)))]
-    opt = torch.optim.Adam(trained, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
-    for s in range(n_steps):
-        sl = slice(s * B, (s + 1) * B)
-        xs, ys, gs_ = Xtr[sl], ytr[sl], gtr[sl]
-        if reverse_rows:                      # the same batch in reverse row order: identical mathematics, other rounding
-            xs, ys, gs_ = xs[::-1].copy(), ys[::-1].copy(), gs_[::-1].copy()
-        stats = {}
-        p = O.ple_forward(sd, xs, field_dims, 3, training=True, stats_out=stats)
-        p = p.gather(1, torch.from_numpy(gs_).reshape(-1, 1)).squeeze(1)
-        loss = O.bce_mean(p, torch.from_numpy(ys.astype(np.float32))) + O.reg_loss(sd, l2).sum()
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        sd.update(stats)
-    with torch.no_grad():
-        pe = O.ple_forward({k: v.detach() for k, v in sd.items()}, Xev, field_dims, 3, training=False)
-    return pe.numpy()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup(cuda, precision, table_mode, freeze_noise):
-    from cdcmdr_amd.model.ple import PLE
-    from cdcmdr_amd.optim import FusedAdam
-    from cdcmdr_amd.synth import make_dataset
-    from cdcmdr_amd.trainer import TrainStep
-    F, V, D, B, n_steps, n_eval = 12, 2000, 8, 1024, 100, 40000
-    field_dims = [V] * F
-    field_dims[10] = 3
-    X, y = make_dataset(B * n_steps + n_eval, field_dims, n_domain=3, domain_idx=10, seed=2000)
-    Xtr, ytr, Xev, yev = X[:B * n_steps], y[:B * n_steps], X[B * n_steps:], y[B * n_steps:]
-    gtr, gev = Xtr[:, 10].astype(np.int64), Xev[:, 10].astype(np.int64)
-    torch.manual_seed(2000)
-    model = PLE(field_dims, D, 3, 2, 2, ((64, 32), (16,)), (16, 8), dropout=0.0).to(cuda).set_precision(precision)
-    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    names = set(sd0)
-    frozen = [p for k, p in model.named_parameters() if freeze_noise and is_pre_bn_bias(k, names)]
-    opt = FusedAdam(model, table_mode=table_mode, frozen=frozen)
-    ts = TrainStep(model, opt, B, use_graph=True)
-    Xd, yd, gd = torch.from_numpy(Xtr).to(cuda), torch.from_numpy(ytr).to(cuda), torch.from_numpy(gtr).to(cuda)
-    for s in range(n_steps):
-        sl = slice(s * B, (s + 1) * B)
-        ts.step(Xd[sl], yd[sl], gd[sl])
-    opt.flush_table()
-    model.eval()
-    with torch.no_grad():
-        pg = torch.cat([model(torch.from_numpy(Xev[i:i + 5000]).to(cuda)) for i in range(0, n_eval, 5000)]).cpu().numpy()
-    return dict(field_dims=field_dims, sd0=sd0, Xtr=Xtr, ytr=ytr, gtr=gtr, Xev=Xev, yev=yev, gev=gev, B=B, n_steps=n_steps, pg=pg)
-
-
-def test_auc_parity_within_the_references_own_reproducibility(cuda):
-    """North-star target: |dAUC| <= 1e-4.  Measured fact: the reference's semantics do not reproduce THEMSELVES to 1e-4
-    at this scale — Adam turns rounding-level gradient differences of near-zero-gradient parameters into +-lr moves, so
-    two CPU runs that differ only in summation order (rows of every batch reversed; thread count) already differ by a
-    few 1e-4 in AUC.  The HIP path (fp32 and bf16 contractions, lazy table) must sit inside that band:
-    |AUC_hip - AUC_cpu| <= max(1e-4, 3 x the largest CPU-vs-CPU gap).  Also checked: freezing the noise-driven
-    pre-BatchNorm biases on both sides, logloss, per-domain AUC."""
-    runs = {}
+def test_auc_parity_at_the_protocol_scale(cuda):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import auc_parity as AP
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "auc_parity_v10k.json")))
+    cfg = fx["config"]
+    args = type("A", (), dict(vocab=cfg["vocab"], steps=cfg["steps"], eval_rows=cfg["eval_rows"], id_dist=cfg["id_dist"]))()
+    fd, train, ev = AP.dataset(args)
+    model, sd0, sha = AP.initial_state(fd)
+    if sha != fx["init_sha"]:
+        pytest.skip(f"this torch build ({torch.__version__}) initialises the model differently from the one the CPU sides were run "
+                    f"with ({fx['torch']}): the fixture's trajectories start elsewhere")
+    _, yev, gev = ev
+    ref = fx["cpu_sides"]["ref"]
+    floor = fx["cpu_vs_cpu_floor"]
+    band = max(1e-4, floor)
+    report = {}
     for precision in ("f32", "bf16"):
-        runs[precision] = _setup(cuda, precision, "lazy", freeze_noise=False)
-    c = runs["f32"]
-    args = (c["sd0"], c["field_dims"], c["Xtr"], c["ytr"], c["gtr"], c["Xev"], c["B"], c["n_steps"])
-    yev, gev = c["yev"], c["gev"]
-    sel = np.arange(len(yev))
-    pc = _run_cpu(*args)
-    pr = _run_cpu(*args, reverse_rows=True)
-    torch.set_num_threads(1)
-    p1 = _run_cpu(*args)
-    torch.set_num_threads(max(1, min(8, len(__import__("os").sched_getaffinity(0)))))
-    auc = {k: O.auc(yev, v[sel, gev]) for k, v in {"cpu": pc, "cpu_rows_reversed": pr, "cpu_1thread": p1,
-                                                  "hip_f32": runs["f32"]["pg"], "hip_bf16": runs["bf16"]["pg"]}.items()}
-    floor = max(abs(auc["cpu_rows_reversed"] - auc["cpu"]), abs(auc["cpu_1thread"] - auc["cpu"]), abs(auc["cpu_1thread"] - auc["cpu_rows_reversed"]))
-    print("AUC " + ", ".join(f"{k} {v:.6f}" for k, v in auc.items()) + f"; cpu-vs-cpu floor {floor:.2e}; "
-          f"hip_f32-cpu {auc['hip_f32'] - auc['cpu']:+.2e}, hip_bf16-cpu {auc['hip_bf16'] - auc['cpu']:+.2e}")
-    assert auc["cpu"] > 0.58, "the planted teacher must be learnable, otherwise AUC parity proves nothing"
-    band = max(1e-4, 3.0 * floor)
-    assert abs(auc["hip_f32"] - auc["cpu"]) <= band and abs(auc["hip_bf16"] - auc["cpu"]) <= band
-    ll = {k: O.logloss(yev, v[sel, gev]) for k, v in {"cpu": pc, "hip_f32": runs["f32"]["pg"], "hip_bf16": runs["bf16"]["pg"]}.items()}
-    assert abs(ll["hip_f32"] - ll["cpu"]) <= 2e-3 and abs(ll["hip_bf16"] - ll["cpu"]) <= 2e-3
-    for d in range(3):                                    # per-domain AUC as run.py:690-711 reports it
-        mk = gev == d
-        a_c = O.auc(yev[mk], pc[mk, d])
-        assert abs(O.auc(yev[mk], runs["f32"]["pg"][mk, d]) - a_c) <= 5 * band
+        p = AP.side_hip(args, fd, model, sd0, train, ev, precision)
+        assert np.isfinite(p).all()
+        report[precision] = {"auc": O.auc(yev, p), "logloss": O.logloss(yev, p),
+                             "domain_auc": [O.auc(yev[gev == k], p[gev == k]) for k in range(3)]}
+    print(f"AUC ref {ref['auc']:.6f}; cpu-vs-cpu floor at this scale {floor:.2e} (ref / ref rows reversed / oracle); "
+          + "; ".join(f"hip_{k} {v['auc']:.6f} ({v['auc'] - ref['auc']:+.2e})" for k, v in report.items()))
+    for k, v in report.items():
+        assert abs(v["auc"] - ref["auc"]) <= band, f"hip_{k}: |dAUC| {abs(v['auc'] - ref['auc']):.2e} > {band:.2e}"
+        # logloss and the per-domain AUCs (run.py:690-711) inside what the CPU sides spread over among themselves (x2 for the
+        # smaller per-domain populations)
+        ll_spread = max(abs(a["logloss"] - b["logloss"]) for a in fx["cpu_sides"].values() for b in fx["cpu_sides"].values())
+        assert abs(v["logloss"] - ref["logloss"]) <= max(1e-4, 3 * ll_spread), f"hip_{k}: logloss {v['logloss']} vs {ref['logloss']}"
+        for d in range(3):
+            spread = max(abs(a["domain_auc"][d] - b["domain_auc"][d]) for a in fx["cpu_sides"].values() for b in fx["cpu_sides"].values())
+            assert abs(v["domain_auc"][d] - ref["domain_auc"][d]) <= max(1e-4, 2 * spread), f"hip_{k}: domain {d} AUC"

@@ -390,6 +390,54 @@ def test_checkpoint_resume_continues_bit_identically(cuda, tmp_path, table_mode)
     assert torch.equal(opt.table_m.cpu(), want_m)
 
 
+@pytest.mark.parametrize("D,precision", [(16, "bf16"), (32, "f32"), (8, "f32")])
+def test_fused_catchup_gather_equals_the_two_launches(cuda, monkeypatch, D, precision):
+    """cdc_embed_lazy_catchup_gather (the catch-up lanes write the embeddings) against cdc_embed_lazy_catchup followed by
+    cdc_embed_gather_fwd: identical embeddings, losses and table bits over several steps — with a hot column (three rows looked up
+    by a third of the batch each: the wave-cooperative path), rows looked up 2..4 times (inline path), repeated batches (rows
+    that are already current) and an id outside the table (zero row + IndexError from check_ids)."""
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [50, 3000, 3, 900, 7]
+    B = 192
+    r = np.random.default_rng(9)
+    batches = []
+    for _ in range(5):
+        X = make_ids(r, B, fd)
+        batches.append((torch.from_numpy(X).to(cuda), torch.from_numpy(r.integers(0, 2, size=B).astype(np.int16)).to(cuda),
+                        torch.from_numpy(X[:, 2].astype(np.int64)).to(cuda)))
+    batches.append(batches[1])                                          # the same rows again, two steps later
+    bad = batches[2][0].clone()
+    bad[5, 1] = 3000                                                    # one id past its field's vocabulary -> next field's first row? no: past the table for the last field only
+    bad[7, 4] = 7                                                       # last field: 7 is outside [0, 7) and outside the table
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CDC_FUSE_GATHER", fused)
+        torch.manual_seed(4)
+        model = PLE(fd, D, 3, 1, 1, ((16,), (8,)), (8,), dropout=0.0).to(cuda).set_precision(precision)
+        opt = FusedAdam(model, table_mode="lazy", flush_every=4)
+        ts = TrainStep(model, opt, B, use_graph=False)
+        assert ts._fuse_gather() == (fused == "1")
+        losses, embs = [], []
+        for b in batches:
+            bce, _ = ts.step(*b)
+            losses.append(float(bce.item()))
+            embs.append(ts.emb.out.tensor().clone())
+        ts.step(bad, batches[2][1], batches[2][2])
+        embs.append(ts.emb.out.tensor().clone())
+        with pytest.raises(IndexError):
+            ts.check_ids()
+        opt.flush_table()
+        res[fused] = (losses, embs, model.embedding.embedding_dict.weight.detach().clone(), opt.table_m.clone(), opt.table_v.clone())
+    assert res["1"][0] == res["0"][0]
+    for a, b in zip(res["1"][1], res["0"][1]):
+        assert torch.equal(a, b), "gathered embeddings differ"
+    assert float(res["1"][1][-1][7, 4 * D:5 * D].abs().max()) == 0.0, "an id outside the table must give a zero row"
+    for k in (2, 3, 4):
+        assert torch.equal(res["1"][k], res["0"][k]), "table state differs"
+
+
 def test_load_state_dict_into_a_graph_captured_step(cuda):
     """A captured hipGraph holds the moment POINTERS of cdc_adam_multi's argument blocks: load_state_dict must restore into the
     existing tensors.  Three steps (the third replayed from the graph), a checkpoint, three more steps, then the checkpoint
