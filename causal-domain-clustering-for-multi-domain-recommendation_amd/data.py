@@ -167,6 +167,7 @@ def train_epoch(step, loader, log_interval=None, log=None):
                 log(float(acc.item()) / log_interval)
             acc.zero_()
             ts.check_ids()                       # the host is synchronised here anyway
+            step.refresh_table_reg()             # lazy table: the reported loss's table term, exact again from here
     step.check_ids()
     for sib in step.__dict__.get("_siblings", {}).values():
         sib.check_ids()

@@ -63,6 +63,7 @@ class FusedAdam:
         self.fast_replay = bool(fast_replay) and table_mode == "lazy"
         self.flush_every = int(flush_every) if table_mode == "lazy" else 0
         self.reg_sum = torch.zeros(2, dtype=torch.float64, device=dev)       # [0] dense params (l2 applied), [1] table sum(w^2)
+        self.table_reg = torch.zeros((), dtype=torch.float64, device=dev)    # lazy table: l2 * sum(w^2) at the last refresh
         f32 = lambda v: float(torch.tensor(v, dtype=torch.float64).to(torch.float32))  # noqa: E731
         self._lerp_w = f32(1.0 - betas[0])
         self._beta2 = f32(betas[1])

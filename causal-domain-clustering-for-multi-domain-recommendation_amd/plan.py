@@ -305,7 +305,7 @@ class Plan:
                 # four 64-row slabs per workgroup
                 T = 64 if all(g["N"] <= 64 and g["K"] <= 64 for g in chunk) else 128
                 tiles = sum(math.ceil(g["N"] / T) * math.ceil(g["K"] / T) for g in chunk)
-                S = max(1, min(int(os.environ.get("CDC_DW_BLOCKS", "768")) // max(tiles, 1), max(Mmax // 256, 1), 32))
+                S = max(1, min(int(os.environ.get("CDC_DW_BLOCKS", "512")) // max(tiles, 1), max(Mmax // 256, 1), 32))
             else:
                 tiles = sum(math.ceil(g["N"] / 64) * math.ceil(g["K"] / 64) for g in chunk)
                 S = max(1, min(1024 // max(tiles, 1), max(Mmax // 128, 1), 64))       # 1024: measured best of 384…2560 at C2

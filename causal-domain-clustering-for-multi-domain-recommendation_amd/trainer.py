@@ -192,8 +192,22 @@ class TrainStep:
         return hit
 
     def _reg(self):
-        # part of the (graph-replayed) launch sequence, so that step() issues nothing else per call
+        # part of the (graph-replayed) launch sequence, so that step() issues nothing else per call.  Dense table mode: the
+        # streaming pass sums w^2 of the whole table every step (reg_sum[1]).  Lazy table: nobody walks the table in a step;
+        # the table's term is the value of the last refresh_table_reg() (flush + exact sum), see there.
         torch.add(self.opt.reg_sum[0], self.opt.reg_sum[1], alpha=self.opt.l2_table, out=self.reg)
+        if self.opt.table_mode == "lazy":
+            self.reg.add_(self.opt.table_reg)
+
+    def refresh_table_reg(self):
+        """Lazy table: brings every row to the current step and re-evaluates the table's share of the reference's reported loss
+        (run.py:489: `loss += get_regularization_loss()`, i.e. l2 * sum(w^2) over the WHOLE table, model/layer.py:31,96-112).  The
+        value is exact for the weights the NEXT step's forward sees, and is what `step()` adds to its reg figure until the next
+        refresh (per step it changes by ~lr * 2 * l2 * sum|w|: 2e-8 relative at the reference's settings).  One pass over
+        the table: call it where the reference's value is looked at (the logging steps of train_epoch), not every step."""
+        if self.opt.table_mode == "lazy":
+            self.opt.table_reg.copy_(self.opt.table_reg_loss())
+        return self.opt.table_reg
 
     def _launch_all(self):
         """single GPU: the whole step is one launch sequence (one hipGraph when use_graph)."""

@@ -51,12 +51,17 @@ def test_auc_parity_at_the_protocol_scale(cuda):
                              "domain_auc": [O.auc(yev[gev == k], p[gev == k]) for k in range(3)]}
     print(f"AUC ref {ref['auc']:.6f}; cpu-vs-cpu floor at this scale {floor:.2e} (ref / ref rows reversed / oracle); "
           + "; ".join(f"hip_{k} {v['auc']:.6f} ({v['auc'] - ref['auc']:+.2e})" for k, v in report.items()))
+    sides = list(fx["cpu_sides"].values())
+    ll_spread = max(abs(a["logloss"] - b["logloss"]) for a in sides for b in sides)
+    print(f"logloss ref {ref['logloss']:.6f}, cpu spread {ll_spread:.2e}; "
+          + "; ".join(f"hip_{k} {v['logloss'] - ref['logloss']:+.2e}" for k, v in report.items()))
     for k, v in report.items():
         assert abs(v["auc"] - ref["auc"]) <= band, f"hip_{k}: |dAUC| {abs(v['auc'] - ref['auc']):.2e} > {band:.2e}"
-        # logloss and the per-domain AUCs (run.py:690-711) inside what the CPU sides spread over among themselves (x2 for the
-        # smaller per-domain populations)
-        ll_spread = max(abs(a["logloss"] - b["logloss"]) for a in fx["cpu_sides"].values() for b in fx["cpu_sides"].values())
-        assert abs(v["logloss"] - ref["logloss"]) <= max(1e-4, 3 * ll_spread), f"hip_{k}: logloss {v['logloss']} vs {ref['logloss']}"
+        # logloss (run.py:690-711): three CPU sides are a small sample of the trajectory spread, so 3x their largest gap, and
+        # never tighter than 5e-4 (1e-3 relative of the 0.435 logloss)
+        assert abs(v["logloss"] - ref["logloss"]) <= max(5e-4, 3 * ll_spread), f"hip_{k}: logloss {v['logloss']} vs {ref['logloss']}"
+        # per-domain AUCs: populations a third of the whole, so the overall band or twice the CPU sides' own spread of that domain
         for d in range(3):
-            spread = max(abs(a["domain_auc"][d] - b["domain_auc"][d]) for a in fx["cpu_sides"].values() for b in fx["cpu_sides"].values())
-            assert abs(v["domain_auc"][d] - ref["domain_auc"][d]) <= max(1e-4, 2 * spread), f"hip_{k}: domain {d} AUC"
+            spread = max(abs(a["domain_auc"][d] - b["domain_auc"][d]) for a in sides for b in sides)
+            gap = abs(v["domain_auc"][d] - ref["domain_auc"][d])
+            assert gap <= max(band, 2 * spread), f"hip_{k}: domain {d} AUC gap {gap:.2e} (cpu spread {spread:.2e})"

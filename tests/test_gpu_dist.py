@@ -37,11 +37,12 @@ def _data(world):
 
 
 def _build(kind, dev):
+    D = int(os.environ.get("CDC_TEST_EMB_DIM", "8"))            # (spawned workers inherit the environment)
     if kind == "star":
         from cdcmdr_amd.model.star import STAR
-        return STAR(FD, 8, 3, (32, 16), domain_idx=4, dropout=0.0).to(dev).set_precision("f32"), "star"
+        return STAR(FD, D, 3, (32, 16), domain_idx=4, dropout=0.0).to(dev).set_precision("f32"), "star"
     from cdcmdr_amd.model.mmoe import MMoE
-    return MMoE(FD, 8, 3, 4, (32, 16), (8,), dropout=0.0).to(dev).set_precision("f32"), "multi"
+    return MMoE(FD, D, 3, 4, (32, 16), (8,), dropout=0.0).to(dev).set_precision("f32"), "multi"
 
 
 def _single_process_reference(table_mode, kind="mmoe", world=2):
@@ -94,6 +95,13 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_
                os.path.join(out_dir, f"rank{rank}.pt"))
     dp.barrier()
     dp.close()
+
+
+def test_two_ranks_row_sharded_table_with_emb_dim_32(cuda, tmp_path, monkeypatch):
+    """C4's table shape (D = 32) through the row-sharded exchange: bucket, owner-side merge / catch-up / gather, expand, pack, owner
+    update — replicas identical after gather_table() and equal to the single-process step on the concatenated batch."""
+    monkeypatch.setenv("CDC_TEST_EMB_DIM", "32")
+    test_two_ranks_stay_identical(cuda, tmp_path, "lazy", False, "sharded")
 
 
 @pytest.mark.parametrize("table_mode,use_graph,table_dist", [("dense", False, None), ("lazy", False, "replicated"),

@@ -1,0 +1,126 @@
+"""Configurations the earlier parity tests did not reach: the C4 table shape (emb_dim 32) through a whole
+training step, STAR-30 and MMoE-8 with bf16 contractions, and the bf16 path against the reference's own fp32 golden vectors
+at the tolerance SURVEY.md 8c names (atol 5e-3 on probabilities)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import O, assert_close, compare_param_grads, is_pre_bn_bias, make_ids, oracle_grads, sd_cpu
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FD = [7, 100, 3, 50, 11, 29]
+
+
+def test_step_with_emb_dim_32_matches_the_oracle(cuda):
+    """C4's table shape (D = 32: 128-byte rows, eight 16-byte lanes per row) through gather, catch-up, per-row sums + lazy update
+    and flush: three training steps of a PLE on the lazy table against the oracle driven with the reference's semantics (dense
+    table gradient, whole-table L2, dense torch.optim.Adam), incl. rows no batch looks up and a hot column."""
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [40, 2500, 3, 700, 9]
+    D, B = 32, 96
+    torch.manual_seed(21)
+    model = PLE(fd, D, 3, 2, 2, ((32, 16), (8,)), (8, 4), dropout=0.0).to(cuda).set_precision("f32")
+    sd0 = sd_cpu(model)
+    opt = FusedAdam(model, table_mode="lazy", fast_replay=False, flush_every=2)
+    ts = TrainStep(model, opt, B)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd0.items() if v.dtype.is_floating_point and "running_" not in k}
+    sd = dict(sd0)
+    sd.update(leaves)
+    l2 = {n: 1e-5 for n in O.reg_names(list(sd), "ple")}
+    ref_opt = torch.optim.Adam(list(leaves.values()), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    rng = np.random.default_rng(3)
+    names = set(sd0)
+    for step in range(3):
+        X = make_ids(rng, B, fd)
+        y = rng.integers(0, 2, size=B).astype(np.int16)
+        g = X[:, 2].astype(np.int64)
+        ts.refresh_table_reg()
+        bce, reg = ts.step(torch.from_numpy(X).to(cuda), torch.from_numpy(y).to(cuda), torch.from_numpy(g).to(cuda))
+        stats = {}
+        p = O.ple_forward(sd, X, fd, 3, training=True, stats_out=stats).gather(1, torch.from_numpy(g).reshape(-1, 1)).squeeze(1)
+        want_bce = O.bce_mean(p, torch.from_numpy(y.astype(np.float32)))
+        want_reg = O.reg_loss(sd, l2).sum()
+        ref_opt.zero_grad()
+        (want_bce + want_reg).backward()
+        ref_opt.step()
+        sd.update(stats)
+        assert abs(float(bce.item()) - float(want_bce)) < 2e-5
+        assert_close(reg.reshape(1), want_reg.detach().reshape(1), 1e-5, 1e-7, f"reg at step {step}")
+        opt.flush_table()
+        got = sd_cpu(model)
+        for k in names:
+            if "num_batches" in k or is_pre_bn_bias(k, names):
+                continue
+            assert_close(got[k], sd[k].detach(), 5e-5, 5e-6, f"step {step}: {k}")
+    assert_close(opt.table_m.cpu(), ref_opt.state[leaves["embedding.embedding_dict.weight"]]["exp_avg"], 1e-3, 1e-7, "table exp_avg")
+
+
+def _bf16_vs_restatement(cuda, model, forward, B, field_dims, seed):
+    """forward + every parameter gradient of a bf16 model against the oracle's bf16 restatement (identical rounded operands)"""
+    rng = np.random.default_rng(seed)
+    x = make_ids(rng, B, field_dims)
+    model.train()
+    sd = sd_cpu(model)
+    out = model(torch.from_numpy(x).to(cuda))
+    gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed))
+    out.backward(gout.to(cuda))
+    stats = {}
+    O.MATMUL_BF16 = True
+    try:
+        ref, grads = oracle_grads(lambda s: forward(s, x, stats), sd, gout)
+    finally:
+        O.MATMUL_BF16 = False
+    assert_close(out, ref, 5e-3, 2e-3, "probabilities")
+    compare_param_grads(dict(model.named_parameters()), grads, 5e-3, 2e-3, bf16=True, all_names=list(sd), bn_active=True)
+    new_sd = sd_cpu(model)
+    for k, v in stats.items():
+        assert_close(new_sd[k], v, 5e-3, 2e-3, f"stat {k}")
+
+
+def test_mmoe8_bf16_against_the_bf16_restatement(cuda):
+    """C3's model (8 experts with BatchNorm, three softmax gates) with bf16 contractions"""
+    from cdcmdr_amd.model.mmoe import MMoE
+    fd = [1000] * 26
+    torch.manual_seed(2)
+    m = MMoE(fd, 16, 3, 8, (256, 128, 64), (64, 32), dropout=0.0).to(cuda).set_precision("bf16")
+    _bf16_vs_restatement(cuda, m, lambda s, x, st: O.mmoe_forward(s, x, fd, 3, training=True, stats_out=st), 512, fd, 7)
+
+
+def test_star30_bf16_against_the_bf16_restatement(cuda):
+    """C5's model (30 domain towers with W_d * W_s weights and partitioned BatchNorm) with bf16 contractions, every tower over
+    the full batch (the evaluation form, star.py:111-112)"""
+    from cdcmdr_amd.model.star import STAR
+    fd = [1000] * 26
+    torch.manual_seed(3)
+    m = STAR(fd, 16, 30, (256, 128, 64, 32), dropout=0.0).to(cuda).set_precision("bf16")
+    _bf16_vs_restatement(cuda, m, lambda s, x, st: O.star_forward(s, x, fd, 30, training=True, stats_out=st), 256, fd, 8)
+
+
+@pytest.mark.parametrize("name", ["g2_ple3", "g2_mmoe8", "g2_star30_all", "g2_dcnv2_mix", "g2_dcn13"])
+def test_bf16_path_against_the_references_fp32_goldens(cuda, name):
+    """bf16-input / fp32-accumulate kernels against the fp32 REFERENCE itself, atol 5e-3 on probabilities (train and
+    eval mode), BCE within 5e-3 — the golden vectors captured from /root/reference, not a restatement."""
+    from test_gpu_models_golden import build, load, sd_of
+    d = load(name)
+    model = build(name).to(cuda).set_precision("bf16")
+    model.load_state_dict(sd_of(d))
+    x = torch.from_numpy(d["x"]).to(cuda)
+    y = torch.from_numpy(d["y"]).to(cuda).reshape(-1).float()
+    group = torch.from_numpy(d["group"]).to(cuda) if "group" in d.files else None
+    model.train()
+    with torch.no_grad():
+        pred = model(x)
+    pred = pred.gather(1, group).squeeze(1) if group is not None else pred
+    assert_close(pred, d["train_pred"], 0.0, 5e-3, "train_pred (bf16 vs the fp32 reference)")
+    bce = torch.nn.BCELoss()(pred, y)
+    assert abs(float(bce) - float(d["bce"])) < 5e-3
+    model.eval()
+    with torch.no_grad():
+        ev = model(x)
+    ev = ev.gather(1, group).squeeze(1) if group is not None else ev
+    assert_close(ev, d["eval_pred"], 0.0, 5e-3, "eval_pred (bf16 vs the fp32 reference)")
