@@ -287,7 +287,9 @@ class Plan:
         groups = self._deferred_dw
         launches, cur = [], []
         for g in groups:
-            if cur and (len(cur) >= L.MAX_GROUPS or g["accumulate"]):
+            # (a launch is either all-shadows (csrc/gemm2.hip) or all-fp32-operands: layers too narrow for the bf16 tiles sit
+            # next to wide ones in small models)
+            if cur and (len(cur) >= L.MAX_GROUPS or g["accumulate"] or (g.get("dzh") is None) != (cur[0].get("dzh") is None)):
                 launches.append(cur)
                 cur = []
             cur.append(g)

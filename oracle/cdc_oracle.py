@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
-MATMUL_BF16 = False  # True: restate the bf16 MFMA path (operands of every contraction rounded to bf16, fp32 accumulate)
+MATMUL_BF16 = False  # True / "exact": restate the bf16 MFMA path (operands of every contraction rounded to bf16, fp32 accumulate)
 DROPOUT_P = 0.0     # parity runs use 0; bench.py's cpu_baseline sets the reference default (0.2) to time the same work
 
 
@@ -61,25 +61,51 @@ def _bf(t):
 
 class _Bf16Matmul(torch.autograd.Function):
     """y = x @ w^T exactly as the bf16 MFMA kernels contract it: operands rounded to bf16 (round-to-nearest-even) in the
-    forward AND in both backward contractions (dX = bf(dY) @ bf(W), dW = bf(dY)^T @ bf(X)), fp32 accumulation."""
+    forward AND in both backward contractions (dX = bf(dY) @ bf(W), dW = bf(dY)^T @ bf(X)).  Accumulation: fp32 in the library's
+    order (MATMUL_BF16 = True), or exact (fp64, MATMUL_BF16 = "exact") — the products of bf16 operands are exact in fp32, so
+    the exact sum is the value every fp32 summation order (MKL's, the MFMA tiles') approximates, and the better centre to
+    compare against: tools/grad_err_report.py measures the HIP path 2-3x closer to it than to the fp32-accumulated form."""
 
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        if MATMUL_BF16 == "exact":
+            return (_bf(x).double() @ _bf(w).double().t()).float()
         return _bf(x) @ _bf(w).t()
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        if MATMUL_BF16 == "exact":
+            return (_bf(dy).double() @ _bf(w).double()).float(), (_bf(dy).double().t() @ _bf(x).double()).float()
         return _bf(dy) @ _bf(w), _bf(dy).t() @ _bf(x)
 
 
-def _lin(x, sd, prefix, mfma=True):
-    """nn.Linear. `mfma=False` marks the single-output layers the HIP path runs as fp32 row dot products."""
-    b = sd.get(prefix + ".bias")
-    w = sd[prefix + ".weight"]
-    y = _Bf16Matmul.apply(x, w) if (MATMUL_BF16 and mfma) else x @ w.t()
+class _Bf16Bias(torch.autograd.Function):
+    """+ b of a bf16-contracted layer: the bias gradient is the column sum of the SAME bf16-rounded dY the weight gradient
+    contracts (csrc/gemm2.hip forms it with one more MFMA against a ones fragment), not of the fp32 dY."""
+
+    @staticmethod
+    def forward(ctx, y, b):
+        return y + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, (_bf(dy).double().sum(0).float() if MATMUL_BF16 == "exact" else _bf(dy).sum(0))
+
+
+def _mm(x, w, b, mfma=True):
+    """x @ w^T + b; `mfma=False` marks the single-output layers the HIP path runs as fp32 row dot products."""
+    if MATMUL_BF16 and mfma:
+        y = _Bf16Matmul.apply(x, w)
+        return y if b is None else _Bf16Bias.apply(y, b)
+    y = x @ w.t()
     return y if b is None else y + b
+
+
+def _lin(x, sd, prefix, mfma=True):
+    """nn.Linear"""
+    return _mm(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"), mfma)
 
 
 def _bn(x, sd, prefix, training, stats_out, gamma=None, beta=None):
@@ -468,7 +494,7 @@ def _star_tower(h, sd, g, training, stats_out):
     for i in range(n_layers):
         w = sd[f"domain_dnns.{g}.linears.{i}.weight"] * sd[f"shared_dnn.linears.{i}.weight"]
         b = sd[f"domain_dnns.{g}.linears.{i}.bias"] + sd[f"shared_dnn.linears.{i}.bias"]
-        h = h @ w.t() + b
+        h = _mm(h, w, b)                                            # (bf16 restatement: the FUSED weight is what gets rounded)
         if h.shape[0] > 1:
             h = _bn(h, sd, f"domain_dnns.{g}.bn.{i}", training, stats_out)
         h = torch.relu(h)

@@ -52,6 +52,8 @@ def assert_close(a, b, rtol, atol, what=""):
 def is_pre_bn_bias(k, names):
     """True for the bias of a Linear whose output feeds a BatchNorm: its gradient is mathematically zero
     (the batch mean removes any constant), so both sides only hold rounding noise there."""
+    if k == "shared_bn_bias" or (k.startswith("domain_norm.") and k.endswith(".bias")):
+        return "domain_dnns.0.bn.0.running_mean" in names  # STAR: beta_d + beta_s shifts the input of a Linear a BatchNorm follows
     if not k.endswith(".bias"):
         return False
     stem = k[:-5]
@@ -63,9 +65,13 @@ def is_pre_bn_bias(k, names):
     return False
 
 
-def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=None, bn_active=True):
+BF16_GRAD_MAX, BF16_GRAD_P90, BF16_GRAD_MEDIAN = 2.5e-1, 5e-2, 2.5e-2            # see compare_param_grads
+
+
+def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=None, bn_active=True, max_rel=None, median_rel=None):
     """Gradient check per parameter (pre-BatchNorm biases only have to be negligible)."""
     names = set(all_names) if all_names is not None else set(want)
+    rels = []
     for k, g in want.items():
         if g is None:
             continue
@@ -73,17 +79,33 @@ def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=No
         assert got is not None, f"no gradient for {k}"
         scale = max(float(g.abs().max()), 1e-6)
         if bn_active and is_pre_bn_bias(k, names):
-            wscale = float(want[k[:-5] + ".weight"].abs().max())
+            wk = {"shared_bn_bias": "shared_bn_weight"}.get(k, k[:-5] + ".weight")
+            wscale = float(want[wk].abs().max())
             # fp32: summation noise of a mathematically zero sum.  bf16: the bias gradient is the column sum of the bf16-rounded
             # dZ the weight gradient contracts (csrc/gemm2.hip), so the zero sum carries the roundings' noise (~2^-9 per element)
             bound = (1e-1 if bf16 else 1e-3) * max(wscale, 1e-3) + 1e-4
             assert float(got.abs().max()) <= bound, f"pre-BN bias grad {k} not ~0: {float(got.abs().max()):.3e} > {bound:.3e}"
             continue
         if bf16:
-            # against the oracle's bf16 restatement; a relu unit whose pre-activation sits within fp32 accumulation noise of
-            # zero may still flip, so the bound is on the relative L2 error of each gradient tensor
+            # Against the oracle's bf16 restatement with exact accumulation (O.MATMUL_BF16 = "exact"): relative L2 error per gradient
+            # tensor.  What the bound has to leave room for is not rounding but BRANCHES: an activation that lands on the other side
+            # of a bf16 rounding boundary moves the next layer's pre-activations by ~2.5e-4 sigma, a relu unit that close to zero takes
+            # the other branch, and that row's whole upstream gradient moves.  The density of such flips does not fall with the
+            # batch size, so neither does the error.  Measured (tools/grad_err_report.py, profiles/round2/grad_err.txt), max / median
+            # over the tensors of a model:
+            #     two CPU restatements, accumulation fp32 vs exact:  MMoE-8 1.7e-2 / 7.0e-3   PLE-3 1.6e-1 / 1.1e-2   STAR-30 6.8e-2 / 5.6e-4
+            #     HIP bf16 vs the exact restatement:                 MMoE-8 1.8e-2 / 8.5e-3   PLE-3 8.5e-3 / 3.3e-3   STAR-30 1.1e-1 / 4.3e-3
+            # (vs the fp32 oracle 1.8e-1 / 1.2e-1: bf16 operand rounding flips ~1e-3 of the units).  So: the MEDIAN over tensors — what a
+            # systematic error (a missed term, a wrong rounding point) moves — is held to 3x the worst measured median, nine tensors in
+            # ten to 5e-2, and a single tensor (a gate bias of four elements downstream of a flipped row; one of 30 small towers) to
+            # 2.5e-1.  A model small enough to have no flips is held to 5e-4 in tests/test_gpu_gaps.py.
             gd, wd = got.detach().cpu().double(), g.double()
             rel = float((gd - wd).norm() / max(float(wd.norm()), 1e-12))
-            assert rel < 5e-2 or float((gd - wd).abs().max()) < 1e-5, f"grad {k}: relative L2 error {rel:.3e} vs bf16 restatement"
+            rels.append(rel)
+            assert rel < (max_rel or BF16_GRAD_MAX) or float((gd - wd).abs().max()) < 1e-5, f"grad {k}: relative L2 error {rel:.3e} vs bf16 restatement"
         else:
             assert_close(got, g, rtol, atol * max(scale, 1.0), f"grad {k}")
+    if bf16 and len(rels) >= 8:
+        med, p90 = float(np.median(rels)), float(np.quantile(rels, 0.9))
+        assert med < (median_rel or BF16_GRAD_MEDIAN), f"median relative L2 error of the gradient tensors {med:.3e}"
+        assert p90 < (max_rel or BF16_GRAD_P90), f"90th percentile of the gradient tensors' relative L2 errors {p90:.3e}"

@@ -35,6 +35,7 @@ def test_step_with_emb_dim_32_matches_the_oracle(cuda):
     ref_opt = torch.optim.Adam(list(leaves.values()), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
     rng = np.random.default_rng(3)
     names = set(sd0)
+    params = dict(model.named_parameters())
     for step in range(3):
         X = make_ids(rng, B, fd)
         y = rng.integers(0, 2, size=B).astype(np.int16)
@@ -49,19 +50,29 @@ def test_step_with_emb_dim_32_matches_the_oracle(cuda):
         (want_bce + want_reg).backward()
         ref_opt.step()
         sd.update(stats)
-        assert abs(float(bce.item()) - float(want_bce)) < 2e-5
+        assert abs(float(bce.item()) - float(want_bce.detach())) < 2e-5
         assert_close(reg.reshape(1), want_reg.detach().reshape(1), 1e-5, 1e-7, f"reg at step {step}")
         opt.flush_table()
         got = sd_cpu(model)
         for k in names:
-            if "num_batches" in k or is_pre_bn_bias(k, names):
+            if "num_batches" in k:
+                continue
+            if is_pre_bn_bias(k, names):
+                # rounding-noise gradient whose SIGN Adam turns into a +-lr move: adopt the oracle's value and moments so that the
+                # batch statistics that contain it stay comparable (same rule as tests/test_gpu_train.py's three-step test)
+                params[k].data.copy_(sd[k].detach())
+                st, rs = opt.state[id(params[k])], ref_opt.state[leaves[k]]
+                st[0].copy_(rs["exp_avg"])
+                st[1].copy_(rs["exp_avg_sq"])
                 continue
             assert_close(got[k], sd[k].detach(), 5e-5, 5e-6, f"step {step}: {k}")
     assert_close(opt.table_m.cpu(), ref_opt.state[leaves["embedding.embedding_dict.weight"]]["exp_avg"], 1e-3, 1e-7, "table exp_avg")
 
 
-def _bf16_vs_restatement(cuda, model, forward, B, field_dims, seed):
-    """forward + every parameter gradient of a bf16 model against the oracle's bf16 restatement (identical rounded operands)"""
+def _bf16_vs_restatement(cuda, model, forward, B, field_dims, seed, max_rel=None, median_rel=None, mean_prob=2e-4):
+    """forward + every parameter gradient of a bf16 model against the oracle's bf16 restatement (identical rounded operands, exact
+    accumulation).  Probabilities: a handful of rows carry a bf16 rounding-boundary flip (max |d| ~1e-3), the rest agree to
+    accumulation noise, so the MEAN |d| is bounded as well (measured 4e-5 MMoE-8, 4e-6 STAR-30)."""
     rng = np.random.default_rng(seed)
     x = make_ids(rng, B, field_dims)
     model.train()
@@ -70,16 +81,31 @@ def _bf16_vs_restatement(cuda, model, forward, B, field_dims, seed):
     gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(seed))
     out.backward(gout.to(cuda))
     stats = {}
-    O.MATMUL_BF16 = True
+    O.MATMUL_BF16 = "exact"
     try:
         ref, grads = oracle_grads(lambda s: forward(s, x, stats), sd, gout)
     finally:
         O.MATMUL_BF16 = False
     assert_close(out, ref, 5e-3, 2e-3, "probabilities")
-    compare_param_grads(dict(model.named_parameters()), grads, 5e-3, 2e-3, bf16=True, all_names=list(sd), bn_active=True)
+    assert float((out.detach().cpu() - ref).abs().mean()) < mean_prob
+    compare_param_grads(dict(model.named_parameters()), grads, 5e-3, 2e-3, bf16=True, all_names=list(sd), bn_active=True,
+                        max_rel=max_rel, median_rel=median_rel)
     new_sd = sd_cpu(model)
     for k, v in stats.items():
         assert_close(new_sd[k], v, 5e-3, 2e-3, f"stat {k}")
+
+
+def test_bf16_backward_arithmetic_on_a_model_without_branch_flips(cuda):
+    """The whole bf16 backward chain (grad-input and grad-weight contractions from the bf16 copies, bias sums of the rounded dZ,
+    BatchNorm, softmax pooling, head) on a model small enough that no relu unit sits within noise of zero: every gradient tensor
+    within 5e-4 relative L2 of the exact-accumulation restatement (measured: worst 8.5e-5, median 5e-6).  One flipped unit would
+    show as ~3e-3 in its tower; seeds and kernels are deterministic, so this does not flicker."""
+    from cdcmdr_amd.model.mmoe import MMoE
+    fd = [1000] * 26
+    torch.manual_seed(2)
+    m = MMoE(fd, 16, 3, 2, (256,), (32,), dropout=0.0).to(cuda).set_precision("bf16")
+    _bf16_vs_restatement(cuda, m, lambda s, x, st: O.mmoe_forward(s, x, fd, 3, training=True, stats_out=st), 512, fd, 7,
+                         max_rel=5e-4, median_rel=1e-4, mean_prob=5e-6)
 
 
 def test_mmoe8_bf16_against_the_bf16_restatement(cuda):
@@ -98,7 +124,10 @@ def test_star30_bf16_against_the_bf16_restatement(cuda):
     fd = [1000] * 26
     torch.manual_seed(3)
     m = STAR(fd, 16, 30, (256, 128, 64, 32), dropout=0.0).to(cuda).set_precision("bf16")
-    _bf16_vs_restatement(cuda, m, lambda s, x, st: O.star_forward(s, x, fd, 30, training=True, stats_out=st), 256, fd, 8)
+    # 30 towers of 256 rows: a tower with one flipped unit in its 32-wide last layer is ~1e-1 off in all its tensors (measured worst
+    # 1.06e-1, tower 13; two CPU restatements against each other: 6.8e-2, tower 6); the median over the 400 tensors is the check
+    _bf16_vs_restatement(cuda, m, lambda s, x, st: O.star_forward(s, x, fd, 30, training=True, stats_out=st), 256, fd, 8,
+                         median_rel=1.3e-2)
 
 
 @pytest.mark.parametrize("name", ["g2_ple3", "g2_mmoe8", "g2_star30_all", "g2_dcnv2_mix", "g2_dcn13"])
