@@ -54,8 +54,11 @@ def eval_metrics(pred, label, domain=None, n_domain=1):
 
 
 class Evaluator:
-    """Mirror of Run.test (run.py:647-690) for the multi-tower and single-tower branches.
+    """Mirror of Run.test (run.py:647-690): the CDC, multi-tower and single-tower branches.
 
+    mode "cdc": `data_loader` is ({domain: loader of (X, y)}, domain_batch_seq) as data.make_domain_loaders returns them for the
+                validation / test split; for every d of the sequence the next batch of domain d is scored by the tower of d's
+                group: pred = model(X, mode='split', domain_i=d)                       (run.py:653-661, get_domain_data 499-526)
     mode "multi": batches are (X, y, group) and pred = model(X).gather(1, group)   (run.py:668-673)
     mode "single": batches are (X, y) and pred = model(X)                           (run.py:674-676)
     domain_cnt_weight: {domain: weight} or a sequence, as Run.domain_cnt_weight (mean_auc / mean_loss, run.py:706-707)."""
@@ -74,8 +77,11 @@ class Evaluator:
         preds, labels, domains = [], [], []
         try:
             with torch.no_grad():
-                for batch in data_loader:
-                    if self.mode == "multi":
+                for batch in (self._domain_batches(*data_loader) if self.mode == "cdc" else data_loader):
+                    if self.mode == "cdc":
+                        d, X, y = batch
+                        pred = model(X, mode='split', domain_i=d)
+                    elif self.mode == "multi":
                         X, y, group = batch
                         pred = model(X).gather(1, group.reshape(-1, 1).to(torch.int64))
                     else:
@@ -90,6 +96,22 @@ class Evaluator:
         if not preds:
             raise ValueError("empty evaluation set")
         return torch.cat(preds), torch.cat(labels), (torch.cat(domains) if domains else None)
+
+    @staticmethod
+    def _domain_batches(loaders, domain_batch_seq):
+        """Run.get_domain_data in 'valid' / 'test' mode (run.py:507-526): a generator per domain, restarted when exhausted; the
+        sequence holds ceil(rows_d / bs) entries of d, so one pass visits every row of every domain once."""
+        gens = {}
+        for d in domain_batch_seq:
+            d = int(d)
+            if d not in gens:
+                gens[d] = iter(loaders[d])
+            try:
+                X, y = next(gens[d])
+            except StopIteration:
+                gens[d] = iter(loaders[d])
+                X, y = next(gens[d])
+            yield d, X, y
 
     def test(self, data_loader):
         """The reference's result_dict: total_auc, total_loss (+ domain_auc, domain_loss, mean_auc, mean_loss)."""

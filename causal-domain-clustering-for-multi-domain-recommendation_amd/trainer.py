@@ -74,6 +74,7 @@ class TrainStep:
             F, D = self.emb.F, self.emb.D
             self.idx_all = torch.empty((self.global_B, F), dtype=torch.int32, device=dev)
             self.dE_all = torch.empty((self.global_B, F * D), dtype=torch.float32, device=dev)
+            self._loss_behind_arena()
         if self.dp_on and self.table_dist == "sharded":
             if optimizer.table_mode != "lazy":
                 raise ValueError("the row-sharded table needs table_mode='lazy'")
@@ -93,11 +94,15 @@ class TrainStep:
             self.grads_recv = torch.zeros((N, cap, F * D), dtype=torch.float32, **z)
             self.zero_offsets = torch.zeros(F, dtype=torch.int32, **z)
             optimizer.own_mod, optimizer.own_rem = N, dist.rank
-            # the loss scalar sits right behind the used part of the flat gradient arena: one all-reduce covers both
-            used = max(self.plan._arena_used, 1)
-            assert optimizer.grad_arena.numel() > used
-            self.arena_and_loss = optimizer.grad_arena[:used + 1]
-            self.loss = optimizer.grad_arena[used:used + 1]
+            self._loss_behind_arena()
+
+    def _loss_behind_arena(self):
+        """Data parallel: the loss scalar sits right behind the used part of the flat gradient arena, so ONE all-reduce covers the
+        dense gradients and the loss."""
+        used = max(self.plan._arena_used, 1)
+        assert self.opt.grad_arena.numel() > used
+        self.arena_and_loss = self.opt.grad_arena[:used + 1]
+        self.loss = self.opt.grad_arena[used:used + 1]
 
     def _build_plan(self):
         model, opt = self.model, self.opt
@@ -250,9 +255,8 @@ class TrainStep:
                 opt.table_catchup_rows(self.idx_all, self.global_B, F, D)
 
         def exchange():
-            dp.all_reduce_sum(opt.grad_arena[:max(plan._arena_used, 1)])
+            dp.all_reduce_sum(self.arena_and_loss)                      # dense gradients + the loss scalar behind them
             dp.all_gather_rows(self.dE_all, emb.out.grad.root)
-            dp.all_reduce_sum(self.loss)
 
         def update():
             opt.table_step(self.idx_all, self.dE_all, self.global_B, F, D)

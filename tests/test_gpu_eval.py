@@ -119,3 +119,56 @@ def test_evaluator_mirrors_run_test(cuda):
     loader1 = [(a, torch.ones_like(b), c) for a, b, c in loader]
     with pytest.raises(ValueError):
         ev.test(loader1)
+
+
+def test_evaluator_cdc_split_mode_mirrors_run_test(cuda):
+    """The CDC branch of Run.test (run.py:653-661): per-domain loaders walked in the shuffled domain sequence, every batch scored by
+    the tower of ITS domain's group (`model(X, mode='split', domain_i=d)`).  Predictions equal the oracle's eval forward +
+    cdc_forward's column pick; the metrics equal their definitions on those predictions."""
+    import types
+    from cdcmdr_amd.data import make_domain_loaders
+    from cdcmdr_amd.evaluate import Evaluator
+    from cdcmdr_amd.model.cdc import CDC
+    n_domain, n_cluster, domain_idx, bs = 6, 2, 4, 128
+    fd = [7, 300, 3, 50, n_domain, 29]
+    rng = np.random.default_rng(0)
+    n = 1500
+    Xn = np.stack([rng.integers(0, d, size=n) for d in fd], axis=1).astype(np.int32)
+    yn = rng.integers(0, 2, size=(n, 1)).astype(np.int16)
+    np.random.seed(1)
+    torch.manual_seed(1)
+    loaders, seq, w = make_domain_loaders(torch.from_numpy(Xn), torch.from_numpy(yn), bs, cuda, domain_idx, n_domain, shuffle=False)
+    cfg = types.SimpleNamespace(mmoe_n_expert=3, dataset_name="t", p_weight=0.5, p_weight_method="linear_decay", p_weight_exp_decay=0.9,
+                                old_matrix_weight=0.3, affinity_func="minus", use_atten=False)
+    cdc = CDC(fd, 4, n_cluster, n_domain, "mmoe", (16, 8), (8,), domain_idx, domain_cnt_weight=w, n_causal_mask=3, use_metric="loss",
+              device=cuda, dropout=0.2, config=cfg).to(cuda).set_precision("f32")
+    d2g = [0, 1, 1, 0, 1, 0]
+    cdc.domain2group.copy_(torch.tensor(d2g))
+    cdc.domain2group_list = list(d2g)
+    ev = Evaluator(cdc, mode="cdc", domain_idx=domain_idx, n_domain=n_domain, domain_cnt_weight=w)
+    res = ev.test((loaders, seq))
+    pred, label, dom = ev.predict((loaders, seq))
+    assert pred.numel() == n                                   # every row of every domain exactly once
+    sd = {k[len("base_model_instance."):]: v.detach().cpu() for k, v in cdc.state_dict().items() if k.startswith("base_model_instance.")}
+    # the same walk on the host: domain d's rows in their original order, batch by batch
+    pos = {d: 0 for d in range(n_domain)}
+    rows = {d: np.nonzero(Xn[:, domain_idx] == d)[0] for d in range(n_domain)}
+    order = []
+    for d in seq:
+        order.append(rows[d][pos[d]:pos[d] + bs])
+        pos[d] += bs
+    order = np.concatenate(order)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    Xo, yo = Xn[order], yn[order, 0]
+    assert np.array_equal(dom.cpu().numpy(), Xo[:, domain_idx]) and np.array_equal(label.cpu().numpy(), yo)
+    base = O.mmoe_forward(sd, Xo, fd, n_cluster, training=False)
+    want = base.gather(1, torch.tensor(d2g)[torch.from_numpy(Xo[:, domain_idx].astype(np.int64))].reshape(-1, 1)).squeeze(1).numpy()
+    got = pred.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
+    assert _close(res["total_auc"], O.auc(yo, got)) and _close(res["total_loss"], O.logloss(yo, got), 1e-11)
+    mean_auc = 0
+    for d in range(n_domain):
+        mk = Xo[:, domain_idx] == d
+        assert _close(res["domain_auc"][d], O.auc(yo[mk], got[mk]))
+        mean_auc += w[d] * O.auc(yo[mk], got[mk])
+    assert abs(res["mean_auc"] - mean_auc) < 1e-12
