@@ -9,6 +9,7 @@ dense Adam with the L2 term folded in), replayable as ONE hipGraph.  Nothing syn
 `TrainStep.step()` returns device scalars; read them (loss.item()) only when you log.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -226,6 +227,32 @@ class TrainStep:
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for fn in self._fwd_after_gather:
                 fn(st)
+        elif opt.table_mode == "lazy" and self._overlap():
+            # Two branches (two HIP streams; two branches of the hipGraph when captured):
+            #   main:  sort, catch-up | gather, forward, BCE, backward (gradient-input chain) | grad-weight launches, dense Adam | reg
+            #   side:                 | this step's slice of the whole-table replay           | per-row sums, Adam on the step's rows
+            # The replay slice is VALU-bound and touches no row of the batch (those are at step t-1 after the catch-up and are
+            # skipped), so it runs under the forward/backward, whose kernels wait on L2/LDS; the table update needs the replay
+            # finished (same stream) and dE (event), and runs beside the grad-weight contractions nothing else depends on.
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            opt.begin_step_catchup(emb.ids, emb.offsets, B, F, D, flush=False)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                opt.flush_slice()
+            plan.forward()
+            self._bce()
+            st = C.c_void_p(main.cuda_stream)
+            for fn in self._bwd_early:
+                fn(st)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
+            for fn in plan.deferred_dw_steps:
+                fn(st)
+            opt.dense_step(plan.param_grads, plan._param_refs)
+            main.wait_stream(side)
+            self._reg()
+            return
         elif opt.table_mode == "lazy":
             opt.begin_step_catchup(emb.ids, emb.offsets, B, F, D)         # + this step's slice of the whole-table replay
             plan.forward()
@@ -237,6 +264,22 @@ class TrainStep:
         opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
         opt.dense_step(plan.param_grads, plan._param_refs)
         self._reg()
+
+    def _overlap(self):
+        """CDC_OVERLAP=1 runs the step as two branches (below).  Off by default — measured at C2 (profiles/round2/README.md): the
+        branches do run side by side (kernel trace: two queues), but the replay slice's 4096 workgroups take every wave slot and the
+        forward's first launches wait behind them (0.622 vs 0.603 ms/step); capped at 512 workgroups the slice leaves room but needs
+        140 us instead of 108 (it is VALU-bound and wants the waves), of which the forward/backward hides 38 (0.613 ms/step)."""
+        if getattr(self, "_overlap_ok", None) is None:
+            self._overlap_ok = os.environ.get("CDC_OVERLAP", "0") == "1"
+            late = set(id(s_) for s_ in self.plan.deferred_dw_steps)
+            self._bwd_early = [s_ for s_ in self.plan.bwd_steps if id(s_) not in late]
+        return self._overlap_ok
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     # ---- data parallel: launch segments separated by the collectives (each segment replayable as a graph) ---------------
     def _dp_sequence(self):
@@ -443,11 +486,14 @@ class TrainStep:
             self._warm += 1
         return self.loss, self.reg
 
-    def profile(self, batches, n_steps=10, skip=2):
-        """Per-launch timing of `n_steps` eager steps (HIP events on the launch stream); the first `skip` are not counted.
-        Returns {name: {"ms_per_step", "launches_per_step", "flops_per_step", "bytes_per_step"}}.  Events are read back
-        and released every few steps: the runtime backs each timed event with a signal from a bounded pool."""
+    def profile(self, batches, n_steps=10, skip=2, overlap=True):
+        """Per-launch timing of `n_steps` eager steps (HIP events on the stream each launch goes to); the first `skip` are not
+        counted.  Returns {name: {"ms_per_step", "launches_per_step", "flops_per_step", "bytes_per_step"}}.  Events are read back
+        and released every few steps: the runtime backs each timed event with a signal from a bounded pool.
+        overlap=False: the whole step on one stream, i.e. every kernel's duration with the chip to itself."""
         was_graph, self.use_graph = self.use_graph, False
+        self._overlap()
+        was_overlap, self._overlap_ok = self._overlap_ok, bool(self._overlap_ok and overlap)
         rec = []
         out = {}
         used = max(n_steps - skip, 1)
@@ -475,6 +521,7 @@ class TrainStep:
         finally:
             L.PROFILE = None
             self.use_graph = was_graph
+            self._overlap_ok = was_overlap
         return out
 
     def sibling(self, batch_size):
