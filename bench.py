@@ -402,12 +402,13 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
         lane_rate = 256 * 64 * 2.4e9                       # fp32 lanes x clock
         roof["valu"] = {"element_steps_per_step": es, "element_steps_per_s": es / (d["ms_per_step"] * 1e-3),
                         "lane_cycles_per_element_step": lane_rate * d["ms_per_step"] * 1e-3 / es,
-                        "instruction_estimate_lane_cycles": 12.5,
-                        "standalone_lane_cycles": 11.8,
-                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved.  instruction_estimate = 9 packed-fp32 "
-                                "ops at 2 elements per issue + v_sqrt_f32 + v_rcp_f32 counted at quarter rate; standalone = the replay alone "
-                                "on a uniform table (tools/flush_bench.py, 3.34 T element-steps/s).  element_steps is the nominal R*D per "
-                                "step: rows looked up since their last flush replay fewer, so the cycles figure here is on the high side"}
+                        "instruction_estimate_lane_cycles": 11.0,
+                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved.  instruction_estimate: the scaled replay "
+                                "(csrc/common.h adam_scaled_step_pk) is 6 packed-fp32 operations per element PAIR and step (3 lane-cycles per "
+                                "element) + v_sqrt_f32 + v_rcp_f32 per element at quarter rate (8 lane-cycles): the two transcendentals are "
+                                "73% of the issue slots.  element_steps is the nominal R*D per step: rows looked up since their last flush "
+                                "replay fewer, so the measured cycles figure is on the high side of the work actually done.  SQ counters of "
+                                "this launch: profiles/round2/README.md"}
     traffic, traffic_src = profiled_traffic(name)
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": traffic,
                  "traffic_source": traffic_src,

@@ -201,9 +201,10 @@ class TrainStep:
         # part of the (graph-replayed) launch sequence, so that step() issues nothing else per call.  Dense table mode: the
         # streaming pass sums w^2 of the whole table every step (reg_sum[1]).  Lazy table: nobody walks the table in a step;
         # the table's term is the value of the last refresh_table_reg() (flush + exact sum), see there.
-        torch.add(self.opt.reg_sum[0], self.opt.reg_sum[1], alpha=self.opt.l2_table, out=self.reg)
         if self.opt.table_mode == "lazy":
-            self.reg.add_(self.opt.table_reg)
+            torch.add(self.opt.reg_sum[0], self.opt.table_reg, out=self.reg)
+        else:
+            torch.add(self.opt.reg_sum[0], self.opt.reg_sum[1], alpha=self.opt.l2_table, out=self.reg)
 
     def refresh_table_reg(self):
         """Lazy table: brings every row to the current step and re-evaluates the table's share of the reference's reported loss
