@@ -402,13 +402,14 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
         lane_rate = 256 * 64 * 2.4e9                       # fp32 lanes x clock
         roof["valu"] = {"element_steps_per_step": es, "element_steps_per_s": es / (d["ms_per_step"] * 1e-3),
                         "lane_cycles_per_element_step": lane_rate * d["ms_per_step"] * 1e-3 / es,
-                        "instruction_estimate_lane_cycles": 11.0,
-                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved.  instruction_estimate: the scaled replay "
-                                "(csrc/common.h adam_scaled_step_pk) is 6 packed-fp32 operations per element PAIR and step (3 lane-cycles per "
-                                "element) + v_sqrt_f32 + v_rcp_f32 per element at quarter rate (8 lane-cycles): the two transcendentals are "
-                                "73% of the issue slots.  element_steps is the nominal R*D per step: rows looked up since their last flush "
-                                "replay fewer, so the measured cycles figure is on the high side of the work actually done.  SQ counters of "
-                                "this launch: profiles/round2/README.md"}
+                        "instruction_estimate_lane_cycles": 8.0,
+                        "note": "bound by the quarter-rate transcendental pipe, not by HBM: 64 replayed steps per byte moved.  The scaled "
+                                "replay (csrc/common.h adam_scaled_step_pk) issues 6 packed-fp32 operations per element PAIR and step + "
+                                "v_sqrt_f32 + v_rcp_f32 per element; the two transcendentals cost 8 lane-cycles per element-step and the packed "
+                                "arithmetic issues beside them (SQ counters: profiles/round2/pmc_sq_wait_valu.txt, DESIGN.md section 3), so 8 is "
+                                "the floor of this instruction mix.  element_steps is the nominal R*D per step (rows looked up since their "
+                                "last flush replay fewer) and the time is the live HIP-event figure, which includes the event pair's latency: "
+                                "rocprofv3 puts the launch at 98 us = 9.3 lane-cycles"}
     traffic, traffic_src = profiled_traffic(name)
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": traffic,
                  "traffic_source": traffic_src,
