@@ -402,14 +402,15 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
         lane_rate = 256 * 64 * 2.4e9                       # fp32 lanes x clock
         roof["valu"] = {"element_steps_per_step": es, "element_steps_per_s": es / (d["ms_per_step"] * 1e-3),
                         "lane_cycles_per_element_step": lane_rate * d["ms_per_step"] * 1e-3 / es,
-                        "instruction_estimate_lane_cycles": 8.0,
-                        "note": "bound by the quarter-rate transcendental pipe, not by HBM: 64 replayed steps per byte moved.  The scaled "
-                                "replay (csrc/common.h adam_scaled_step_pk) issues 6 packed-fp32 operations per element PAIR and step + "
-                                "v_sqrt_f32 + v_rcp_f32 per element; the two transcendentals cost 8 lane-cycles per element-step and the packed "
-                                "arithmetic issues beside them (SQ counters: profiles/round2/pmc_sq_wait_valu.txt, DESIGN.md section 3), so 8 is "
-                                "the floor of this instruction mix.  element_steps is the nominal R*D per step (rows looked up since their "
-                                "last flush replay fewer) and the time is the live HIP-event figure, which includes the event pair's latency: "
-                                "rocprofv3 puts the launch at 98 us = 9.3 lane-cycles"}
+                        "instruction_estimate_lane_cycles": 9.4,
+                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved.  The scaled replay (csrc/common.h "
+                                "adam_scaled_step_pk) issues 10 VALU instructions per element PAIR and step (6 packed fp32 + 2 v_sqrt_f32 + "
+                                "2 v_rcp_f32); SQ counters put the launch at 7.5 issue cycles per instruction and wave, and a variant that "
+                                "traded 3 transcendentals for 5 multiplies per 4 elements was 9.7% slower, i.e. every instruction costs the "
+                                "same and the count is the floor: 5 instructions x 7.5 cycles / 4 SIMD-lane-groups = 9.4 lane-cycles per "
+                                "element-step (profiles/round2/pmc_sq_wait_valu.txt, DESIGN.md section 3).  element_steps is the nominal "
+                                "R*D per step (rows looked up since their last flush replay fewer); the time is the live HIP-event figure, "
+                                "which includes the event pair's latency (rocprofv3: 98 us per launch = 9.3 lane-cycles)"}
     traffic, traffic_src = profiled_traffic(name)
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": traffic,
                  "traffic_source": traffic_src,

@@ -173,6 +173,9 @@ __device__ __forceinline__ void adam_scaled_step_pk(cdc_f2& w, cdc_f2& M, cdc_f2
     r.y = __builtin_amdgcn_rcpf(d.y);
     w = __builtin_elementwise_fma(M * (-A), r, w);
 }
+// (Tried: ONE v_rcp_f32 for four denominators, 1/(d0 d1 d2 d3) times the complementary products — 5 instead of 8 transcendentals
+// per four element-steps for 5 more multiplies.  9.7 % SLOWER (107.5 vs 98 us per slice launch): a transcendental costs about
+// what a packed-fp32 instruction costs here, the replay is bound by the instruction COUNT, 10 per element pair and step.)
 template <int N>
 __device__ __forceinline__ void adam_replay_wave_scaled(float (&w)[N], float (&m)[N], float (&v)[N], int from, int to, const cdc_adam_hp& hp) {
     static_assert(N % 2 == 0, "pairs of elements");
