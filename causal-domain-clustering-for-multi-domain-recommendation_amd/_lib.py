@@ -135,10 +135,14 @@ class PoolBwdArgs(C.Structure):
                 ("mask_scale", c_f), ("accumulate", c_i32), ("d_experts_h", c_p), ("ld_dexp_h", c_i64), ("gate", PoolBwdGate * MAX_GATES)]
 
 
+BN_X_BF16, BN_Y_BF16, BN_DY_BF16 = 1, 2, 4
+
+
 class BnSeg(C.Structure):
     _fields_ = [("x", c_p), ("ldx", c_i64), ("y", c_p), ("ldy", c_i64), ("gamma", c_p), ("beta", c_p),
                 ("running_mean", c_p), ("running_var", c_p), ("save_mean", c_p), ("save_invstd", c_p),
-                ("num_batches_tracked", c_p), ("yh", c_p), ("ldyh", c_i64), ("C", c_i32), ("row_group", c_i32)]
+                ("num_batches_tracked", c_p), ("yh", c_p), ("ldyh", c_i64), ("C", c_i32), ("row_group", c_i32),
+                ("half", c_i32), ("pad_", c_i32)]
 
 
 class BnFwdArgs(C.Structure):
@@ -152,7 +156,7 @@ class BnBSeg(C.Structure):
     _fields_ = [("dy", c_p), ("lddy", c_i64), ("y", c_p), ("ldy", c_i64), ("x", c_p), ("ldx", c_i64),
                 ("dx", c_p), ("lddx", c_i64), ("gamma", c_p), ("save_mean", c_p), ("save_invstd", c_p),
                 ("dgamma", c_p), ("dbeta", c_p), ("dxh", c_p), ("lddxh", c_i64), ("C", c_i32), ("row_group", c_i32), ("accumulate_dx", c_i32),
-                ("pad_", c_i32)]
+                ("half", c_i32)]
 
 
 class BnBwdArgs(C.Structure):

@@ -63,6 +63,22 @@ __device__ __forceinline__ float cdc_uniform(uint64_t seed, uint64_t idx) {
     return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// The cheap dropout stream (32-bit "lowbias" mix, 16 bits per element: keep iff bits >= round(p * 65536)); ~25 issue cycles per
+// hash against ~150 for the 64-bit mix of cdc_uniform.  Never regenerated in backward: the mask is read off the saved output.
+__device__ __forceinline__ uint32_t g2_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t g2_seed32(uint64_t seed, const int32_t* step_dev, int stream_id) {
+    uint32_t s = (uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x9E3779B1U;
+    if (step_dev) s ^= (uint32_t)(*step_dev) * 0x85EBCA77U;
+    return g2_hash32(s + (uint32_t)stream_id * 0xC2B2AE3DU);
+}
+__device__ __forceinline__ uint32_t g2_drop_bits(uint32_t seed32, int row, int colpair) {      // two 16-bit uniforms: columns 2*colpair, 2*colpair+1
+    return g2_hash32(seed32 + (uint32_t)row * 0x9E3779B1U + (uint32_t)colpair * 0x85EBCA77U);
+}
+
+
 // One element of torch's CPU Adam (torch/optim/adam.py _single_tensor_adam, as run.py:720-721
 // configures it) with the L2 term of model/layer.py:96-112 folded into the gradient:
 //   g  = g_in + l2_twice*w          (autograd: grad of sum(l2*w^2))

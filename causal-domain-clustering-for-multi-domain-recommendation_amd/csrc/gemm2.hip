@@ -40,18 +40,7 @@ __device__ __forceinline__ int g2_xcd_remap(int bid, int nblk) {
 // Dropout decisions of this path: one 32-bit counter hash (lowbias32) per PAIR of neighbouring columns, 16 bits per element —
 // keep iff bits >= round(p * 65536).  (The 64-bit mix of cdc_uniform costs ~150 issue cycles per element: 4 us per 128x128
 // tile of the level-1 launch; this one ~25.)  Never regenerated in backward: the mask is read off the saved output.
-__device__ __forceinline__ uint32_t g2_hash32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ uint32_t g2_seed32(uint64_t seed, const int32_t* step_dev, int stream_id) {
-    uint32_t s = (uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x9E3779B1U;
-    if (step_dev) s ^= (uint32_t)(*step_dev) * 0x85EBCA77U;
-    return g2_hash32(s + (uint32_t)stream_id * 0xC2B2AE3DU);
-}
-__device__ __forceinline__ uint32_t g2_drop_bits(uint32_t seed32, int row, int colpair) {      // two 16-bit uniforms: columns 2*colpair, 2*colpair+1
-    return g2_hash32(seed32 + (uint32_t)row * 0x9E3779B1U + (uint32_t)colpair * 0x85EBCA77U);
-}
+// (g2_hash32 / g2_seed32 / g2_drop_bits: csrc/common.h)
 
 template <int BM, int BN, int NSTAGE>
 struct G2Cfg {

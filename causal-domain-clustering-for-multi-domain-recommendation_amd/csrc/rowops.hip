@@ -285,6 +285,10 @@ extern "C" int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream) {
 // block = 64 columns x 64 rows: lane = column, wave w takes rows w, w+4, ...
 // =================================================================================================
 struct BnTile { int seg, c0, row_lo, M, chunk, col_base; };
+// an operand stored as fp32 or (block-uniform choice) as bf16
+__device__ __forceinline__ float bn_ld(const void* p, bool half, int64_t i) {
+    return half ? (float)reinterpret_cast<const __bf16*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
 
 template <typename Args>
 __device__ __forceinline__ bool bn_locate(const Args& a, int n_chunks, BnTile& t) {
@@ -313,11 +317,12 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_stats(const cdc_bn_fwd_args 
     const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
     if (c < S.C) {
         constexpr int RPW = CDC_BN_ROWS_PER_BLOCK / WAVES_PER_BLOCK;      // a wave's rows of the chunk: all loads issued before the sums
+        const bool xh = S.half & CDC_BN_X_BF16;
         float xv[RPW];
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
             const int r = r_begin + wave + k * WAVES_PER_BLOCK;
-            xv[k] = r < r_end ? S.x[(int64_t)(t.row_lo + r) * S.ldx + c] : 0.f;
+            xv[k] = r < r_end ? bn_ld(S.x, xh, (int64_t)(t.row_lo + r) * S.ldx + c) : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {                                  // rows past r_end contribute exact zeros
@@ -406,11 +411,12 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
     const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK;
     const int r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
     constexpr int RPW = CDC_BN_ROWS_PER_BLOCK / WAVES_PER_BLOCK;
+    const bool xh = S.half & CDC_BN_X_BF16;
     float xv[RPW];
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {                                      // the wave's 16 loads are in flight together
         const int r = r_begin + wave + k * WAVES_PER_BLOCK;
-        xv[k] = r < r_end ? S.x[(int64_t)(t.row_lo + r) * S.ldx + c] : 0.f;
+        xv[k] = r < r_end ? bn_ld(S.x, xh, (int64_t)(t.row_lo + r) * S.ldx + c) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
@@ -424,10 +430,392 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply(const cdc_bn_fwd_args 
             const uint64_t e = ((uint64_t)(t.seg + 64) << 56) ^ ((uint64_t)gr * (uint64_t)S.C + (uint64_t)c);
             v = cdc_uniform(seed, e) < a.drop_p ? 0.f : v * keep_scale;
         }
-        S.y[gr * S.ldy + c] = v;
+        if (S.y) S.y[gr * S.ldy + c] = v;
         if (S.yh) reinterpret_cast<__bf16*>(S.yh)[gr * S.ldyh + c] = (__bf16)v;
     }
 }
+
+// -------------------------------------------------------------------------------------------------
+// BatchNorm with 16-byte lanes (all four kernels).  The kernels above give a lane ONE column, i.e. a wave instruction moves 256
+// bytes (128 for a bf16 operand): they are bound by the number of memory instructions, not by bytes (dropping a whole 33.5 MB
+// output stream did not move k_bn_apply).  Here a lane owns FOUR neighbouring columns of a row: LPR = 8..64 lanes per row
+// (tile of 4*LPR columns), 64/LPR rows per wave instruction, the block still covers one 64-row chunk, so the partial-sum
+// workspace layout ([chunk][column] pairs of doubles) is the same and the two families mix freely.  The rows' loads are issued
+// BEFORE the block sums the chunk partials (which is a chain of L2 reads of its own), and the dropout decisions come from the
+// 32-bit stream of csrc/common.h.  Requires C % 4 == 0 and 16-byte (bf16: 8-byte) aligned rows; anything else -> kernels above.
+// -------------------------------------------------------------------------------------------------
+struct bn_f4 { float v[4]; };
+__device__ __forceinline__ bn_f4 bn_ld4(const void* p, bool half, int64_t i) {
+    bn_f4 r;
+    if (half) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p) + i);
+        r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+        r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    } else {
+        const float4 f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + i);
+        r.v[0] = f.x; r.v[1] = f.y; r.v[2] = f.z; r.v[3] = f.w;
+    }
+    return r;
+}
+__device__ __forceinline__ void bn_st4h(void* p, int64_t i, const float (&v)[4]) {
+    union { __bf16 h[4]; uint2 u; } o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o.h[q] = (__bf16)v[q];
+    *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(p) + i) = o.u;
+}
+template <int LS, typename Args>
+__device__ __forceinline__ bool bn_locate_v(const Args& a, int n_chunks, BnTile& t) {
+    constexpr int TW = 4 << LS;
+    int tile = blockIdx.x / n_chunks;
+    t.chunk = blockIdx.x % n_chunks;
+    int64_t col_base = 0;
+    const int s = find_group<true>(a.n_seg, tile, [&](int l) { return (a.s[l].C + TW - 1) / TW; }, [&](int l) { return (int64_t)a.s[l].C; },
+                                   tile, &col_base);
+    if (s < 0) return false;
+    t.seg = s; t.c0 = tile * TW; t.col_base = (int)col_base;
+    t.row_lo = 0; t.M = (int)a.M;
+    if (a.row_offsets) { const int rg = a.s[s].row_group; t.row_lo = a.row_offsets[rg]; t.M = a.row_offsets[rg + 1] - t.row_lo; }
+    return true;
+}
+// lane geometry of a block (LS = log2 lanes per row)
+template <int LS> struct BnGeo {
+    static constexpr int LPR = 1 << LS, TW = 4 * LPR, RW = 64 / LPR, ITER = CDC_BN_ROWS_PER_BLOCK / (WAVES_PER_BLOCK * RW);
+};
+// per-lane partial sums (4 columns) -> workspace [chunk][column] pairs: lanes of the same columns inside the wave by shuffles,
+// then the four waves through LDS in wave order
+template <int LS>
+__device__ __forceinline__ void bn_store_partials(double (&s1)[4], double (&s2)[4], double* __restrict__ ws_chunk, int col0, int C) {
+    using G = BnGeo<LS>;
+    __shared__ double sh[2][WAVES_PER_BLOCK][G::TW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & (G::LPR - 1);
+#pragma unroll
+    for (int o = G::LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
+    }
+    if (lane < G::LPR) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sh[0][wave][cg * 4 + q] = s1[q]; sh[1][wave][cg * 4 + q] = s2[q]; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < G::TW; j += ROW_THREADS) {
+        if (col0 + j >= C) continue;
+        const double a1 = ((sh[0][0][j] + sh[0][1][j]) + sh[0][2][j]) + sh[0][3][j];
+        const double a2 = ((sh[1][0][j] + sh[1][1][j]) + sh[1][2][j]) + sh[1][3][j];
+        ws_chunk[(int64_t)j * 2] = a1; ws_chunk[(int64_t)j * 2 + 1] = a2;
+    }
+}
+// the block's TW columns: sums of the per-chunk partials in a fixed order -> LDS (every block of a column forms the same bits)
+template <int LS>
+__device__ __forceinline__ void bn_sum_partials_v(const double* __restrict__ ws, int used, int total_c, int col_base, int c0, int C,
+                                                  double (*out)[BnGeo<LS>::TW]) {
+    using G = BnGeo<LS>;
+    constexpr int NP = ROW_THREADS / G::TW > 0 ? ROW_THREADS / G::TW : 1;
+    __shared__ double part[2][NP][G::TW];
+    {
+        const int j = threadIdx.x % G::TW, pt = threadIdx.x / G::TW;    // NP threads per column, each takes chunks pt, pt+NP, ...
+        double a1 = 0.0, a2 = 0.0;
+        if (pt < NP && c0 + j < C) {
+#pragma unroll 4
+            for (int k = pt; k < used; k += NP) {
+                const double* p = ws + ((int64_t)k * total_c + col_base + c0 + j) * 2;
+                a1 += p[0]; a2 += p[1];
+            }
+        }
+        if (pt < NP) { part[0][pt][j] = a1; part[1][pt][j] = a2; }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < G::TW; j += ROW_THREADS) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) { a1 += part[0][pt][j]; a2 += part[1][pt][j]; }
+        out[0][j] = a1; out[1][j] = a2;
+    }
+    __syncthreads();
+}
+
+template <int LS>
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_stats_v4(const cdc_bn_fwd_args a, int n_chunks, int total_c) {
+    using G = BnGeo<LS>;
+    BnTile t;
+    if (!bn_locate_v<LS>(a, n_chunks, t)) return;
+    const cdc_bn_seg& S = a.s[t.seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & (G::LPR - 1), rs = lane >> LS;
+    const int c = t.c0 + cg * 4;
+    const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK, r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (c < S.C) {
+        const bool xh = S.half & CDC_BN_X_BF16;
+        bn_f4 xv[G::ITER];
+#pragma unroll
+        for (int k = 0; k < G::ITER; ++k) {
+            const int r = r_begin + (k * WAVES_PER_BLOCK + wave) * G::RW + rs;
+            if (r < r_end) xv[k] = bn_ld4(S.x, xh, (int64_t)(t.row_lo + r) * S.ldx + c);
+            else xv[k] = bn_f4{{0.f, 0.f, 0.f, 0.f}};
+        }
+#pragma unroll
+        for (int k = 0; k < G::ITER; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const double x = (double)xv[k].v[q]; s1[q] += x; s2[q] += x * x; }
+    }
+    bn_store_partials<LS>(s1, s2, a.workspace + ((int64_t)t.chunk * total_c + t.col_base + t.c0) * 2, t.c0, S.C);
+}
+
+template <int LS>
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_apply_v4(const cdc_bn_fwd_args a, int n_chunks, int total_c) {
+    using G = BnGeo<LS>;
+    BnTile t;
+    if (!bn_locate_v<LS>(a, n_chunks, t)) return;
+    const cdc_bn_seg& S = a.s[t.seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & (G::LPR - 1), rs = lane >> LS;
+    const int c = t.c0 + cg * 4;
+    const bool in_c = c < S.C;
+    const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK, r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
+    const bool xh = S.half & CDC_BN_X_BF16;
+    bn_f4 xv[G::ITER];
+#pragma unroll
+    for (int k = 0; k < G::ITER; ++k) {                                  // in flight while the statistics are put together
+        const int r = r_begin + (k * WAVES_PER_BLOCK + wave) * G::RW + rs;
+        if (in_c && r < r_end) xv[k] = bn_ld4(S.x, xh, (int64_t)(t.row_lo + r) * S.ldx + c);
+        else xv[k] = bn_f4{{0.f, 0.f, 0.f, 0.f}};
+    }
+    const bool global_stats = a.training && a.phase == 2 && a.exchange;
+    const int Ms = global_stats ? (int)(a.exchange[2 * (int64_t)total_c + t.seg] + 0.5) : t.M;
+    const bool skip_norm = (Ms == 1) || (a.skip_le1 && Ms <= 1);
+    __shared__ double sums[2][G::TW];
+    __shared__ float col_mean[G::TW], col_inv[G::TW];
+    if (a.training && !skip_norm && !global_stats)
+        bn_sum_partials_v<LS>(a.workspace, (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK, total_c, t.col_base, t.c0, S.C, sums);
+    for (int j = threadIdx.x; j < G::TW; j += ROW_THREADS) {             // one thread per column of the tile
+        const int cj = t.c0 + j;
+        float mean = 0.f, invstd = 1.f;
+        if (cj < S.C && !skip_norm) {
+            if (a.training) {
+                double s1 = sums[0][j], s2 = sums[1][j];
+                if (global_stats) {
+                    s1 = a.exchange[2 * (int64_t)(t.col_base + cj)];
+                    s2 = a.exchange[2 * (int64_t)(t.col_base + cj) + 1];
+                }
+                const double mu = Ms > 0 ? s1 / Ms : 0.0;
+                double var = Ms > 0 ? s2 / Ms - mu * mu : 0.0;
+                if (var < 0.0) var = 0.0;
+                mean = (float)mu;
+                invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+                if (t.chunk == 0) {
+                    if (S.save_mean) S.save_mean[cj] = mean;
+                    if (S.save_invstd) S.save_invstd[cj] = invstd;
+                    if (S.running_mean && Ms > 0) {
+                        const double unbiased = Ms > 1 ? var * ((double)Ms / (double)(Ms - 1)) : var;
+                        S.running_mean[cj] = (1.f - a.momentum) * S.running_mean[cj] + a.momentum * mean;
+                        S.running_var[cj] = (1.f - a.momentum) * S.running_var[cj] + a.momentum * (float)unbiased;
+                    }
+                }
+            } else {
+                mean = S.running_mean[cj];
+                invstd = 1.f / sqrtf(S.running_var[cj] + a.eps);
+            }
+        }
+        col_mean[j] = mean; col_inv[j] = invstd;
+    }
+    if (a.training && !skip_norm && t.chunk == 0 && t.c0 == 0 && threadIdx.x == 0 && S.num_batches_tracked) *S.num_batches_tracked += 1;
+    __syncthreads();
+    if (!in_c) return;
+    float mean[4], scale[4], bet[4], gamv[4];                           // (v - mean) * invstd * gamma + beta, in the scalar kernel's order
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        gamv[q] = (skip_norm || !S.gamma) ? 1.f : S.gamma[c + q];
+        bet[q] = (skip_norm || !S.beta) ? 0.f : S.beta[c + q];
+        mean[q] = col_mean[cg * 4 + q];
+        scale[q] = col_inv[cg * 4 + q];
+    }
+    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thr16 = (uint32_t)(a.drop_p * 65536.f + 0.5f);
+    const uint32_t seed32 = a.drop_p > 0.f ? g2_seed32(a.seed, a.seed_offset_dev, 64 + t.seg) : 0u;
+#pragma unroll
+    for (int k = 0; k < G::ITER; ++k) {
+        const int r = r_begin + (k * WAVES_PER_BLOCK + wave) * G::RW + rs;
+        if (r >= r_end) continue;
+        const int64_t gr = t.row_lo + r;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = xv[k].v[q];
+            if (!skip_norm) x = (x - mean[q]) * scale[q] * gamv[q] + bet[q];
+            if (a.relu) x = fmaxf(x, 0.f);
+            v[q] = x;
+        }
+        if (a.drop_p > 0.f) {
+            const uint32_t h0 = g2_drop_bits(seed32, (int)gr, c >> 1), h1 = g2_drop_bits(seed32, (int)gr, (c >> 1) + 1);
+            v[0] = (h0 & 0xFFFFu) < thr16 ? 0.f : v[0] * keep_scale;
+            v[1] = (h0 >> 16) < thr16 ? 0.f : v[1] * keep_scale;
+            v[2] = (h1 & 0xFFFFu) < thr16 ? 0.f : v[2] * keep_scale;
+            v[3] = (h1 >> 16) < thr16 ? 0.f : v[3] * keep_scale;
+        }
+        if (S.y) *reinterpret_cast<float4*>(S.y + gr * S.ldy + c) = make_float4(v[0], v[1], v[2], v[3]);
+        if (S.yh) bn_st4h(S.yh, gr * S.ldyh + c, v);
+    }
+}
+
+template <int LS>
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_stats_v4(const cdc_bn_bwd_args a, int n_chunks, int total_c) {
+    using G = BnGeo<LS>;
+    BnTile t;
+    if (!bn_locate_v<LS>(a, n_chunks, t)) return;
+    const cdc_bn_bseg& S = a.s[t.seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & (G::LPR - 1), rs = lane >> LS;
+    const int c = t.c0 + cg * 4;
+    const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK, r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (c < S.C && t.M != 1) {
+        const bool masked = a.relu || a.mask_scale != 1.f;
+        const bool xh = S.half & CDC_BN_X_BF16, yh = S.half & CDC_BN_Y_BF16, dyh = S.half & CDC_BN_DY_BF16;
+        bn_f4 dv[G::ITER], yv[G::ITER], xv[G::ITER];
+#pragma unroll
+        for (int k = 0; k < G::ITER; ++k) {
+            const int r = r_begin + (k * WAVES_PER_BLOCK + wave) * G::RW + rs;
+            const bool ok = r < r_end;
+            const int64_t gr = t.row_lo + (ok ? r : r_begin);
+            dv[k] = bn_ld4(S.dy, dyh, gr * S.lddy + c);
+            if (masked) yv[k] = bn_ld4(S.y, yh, gr * S.ldy + c);
+            xv[k] = bn_ld4(S.x, xh, gr * S.ldx + c);
+            if (!ok) dv[k] = bn_f4{{0.f, 0.f, 0.f, 0.f}};
+        }
+        float mean[4], invstd[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { mean[q] = S.save_mean[c + q]; invstd[q] = S.save_invstd[c + q]; }
+#pragma unroll
+        for (int k = 0; k < G::ITER; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float dz = dv[k].v[q];
+                if (masked) dz = yv[k].v[q] > 0.f ? dz * a.mask_scale : 0.f;
+                const float xhat = (xv[k].v[q] - mean[q]) * invstd[q];
+                s1[q] += (double)dz; s2[q] += (double)dz * (double)xhat;
+            }
+    }
+    bn_store_partials<LS>(s1, s2, a.workspace + ((int64_t)t.chunk * total_c + t.col_base + t.c0) * 2, t.c0, S.C);
+}
+
+template <int LS>
+__global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply_v4(const cdc_bn_bwd_args a, int n_chunks, int total_c) {
+    using G = BnGeo<LS>;
+    BnTile t;
+    if (!bn_locate_v<LS>(a, n_chunks, t)) return;
+    const cdc_bn_bseg& S = a.s[t.seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & (G::LPR - 1), rs = lane >> LS;
+    const int c = t.c0 + cg * 4;
+    const bool in_c = c < S.C;
+    const bool global_stats = a.training && a.phase == 2 && a.exchange;
+    const int Ms = global_stats ? (int)(a.exchange[2 * (int64_t)total_c + t.seg] + 0.5) : t.M;
+    const bool skip_norm = (Ms == 1);
+    const int r_begin = t.chunk * CDC_BN_ROWS_PER_BLOCK, r_end = min(r_begin + CDC_BN_ROWS_PER_BLOCK, t.M);
+    const bool masked = a.relu || a.mask_scale != 1.f;
+    const bool need_x = !skip_norm && a.training;
+    const bool xh = S.half & CDC_BN_X_BF16, yh = S.half & CDC_BN_Y_BF16, dyh = S.half & CDC_BN_DY_BF16;
+    bn_f4 dv[G::ITER], yv[G::ITER], xv[G::ITER];
+#pragma unroll
+    for (int k = 0; k < G::ITER; ++k) {                                  // in flight while the column sums are put together
+        const int r = r_begin + (k * WAVES_PER_BLOCK + wave) * G::RW + rs;
+        const bool ok = in_c && r < r_end;
+        const int64_t gr = t.row_lo + (r < r_end ? r : r_begin);
+        if (ok) {
+            dv[k] = bn_ld4(S.dy, dyh, gr * S.lddy + c);
+            if (masked) yv[k] = bn_ld4(S.y, yh, gr * S.ldy + c);
+            if (need_x) xv[k] = bn_ld4(S.x, xh, gr * S.ldx + c);
+        }
+    }
+    __shared__ double sums[2][G::TW];
+    if (!skip_norm)
+        bn_sum_partials_v<LS>(a.workspace, (t.M + CDC_BN_ROWS_PER_BLOCK - 1) / CDC_BN_ROWS_PER_BLOCK, total_c, t.col_base, t.c0, S.C, sums);
+    else {
+        for (int j = threadIdx.x; j < G::TW; j += ROW_THREADS) { sums[0][j] = 0.0; sums[1][j] = 0.0; }
+        __syncthreads();
+    }
+    if (t.chunk == 0) {
+        // parameter gradients stay LOCAL sums: the data-parallel all-reduce of the gradient arena adds the ranks up
+        for (int j = threadIdx.x; j < G::TW; j += ROW_THREADS) {
+            if (t.c0 + j >= S.C) continue;
+            if (S.dbeta) S.dbeta[t.c0 + j] = (float)sums[0][j];
+            if (S.dgamma) S.dgamma[t.c0 + j] = (float)sums[1][j];
+        }
+    }
+    if (!in_c) return;
+    float gam[4], mean[4], invstd[4], db[4], dg[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double s1 = sums[0][cg * 4 + q], s2 = sums[1][cg * 4 + q];
+        if (global_stats && !skip_norm) {      // the input gradient needs the sums over the GLOBAL batch
+            s1 = a.exchange[2 * (int64_t)(t.col_base + c + q)];
+            s2 = a.exchange[2 * (int64_t)(t.col_base + c + q) + 1];
+        }
+        gam[q] = (skip_norm || !S.gamma) ? 1.f : S.gamma[c + q];
+        mean[q] = skip_norm ? 0.f : S.save_mean[c + q];
+        invstd[q] = skip_norm ? 1.f : S.save_invstd[c + q];
+        db[q] = (float)s1; dg[q] = (float)s2;
+    }
+    const float invM = Ms > 0 ? 1.f / (float)Ms : 0.f;
+#pragma unroll
+    for (int k = 0; k < G::ITER; ++k) {
+        const int r = r_begin + (k * WAVES_PER_BLOCK + wave) * G::RW + rs;
+        if (r >= r_end) continue;
+        const int64_t gr = t.row_lo + r;
+        float dx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dz = dv[k].v[q];
+            if (masked) dz = yv[k].v[q] > 0.f ? dz * a.mask_scale : 0.f;
+            if (skip_norm) dx[q] = dz;
+            else if (a.training) {
+                const float xhat = (xv[k].v[q] - mean[q]) * invstd[q];
+                dx[q] = gam[q] * invstd[q] * (dz - invM * (db[q] + xhat * dg[q]));
+            } else dx[q] = gam[q] * invstd[q] * dz;
+        }
+        if (S.dx) {
+            float4* dst = reinterpret_cast<float4*>(S.dx + gr * S.lddx + c);
+            if (S.accumulate_dx) { const float4 o = *dst; dx[0] = o.x + dx[0]; dx[1] = o.y + dx[1]; dx[2] = o.z + dx[2]; dx[3] = o.w + dx[3]; }
+            *dst = make_float4(dx[0], dx[1], dx[2], dx[3]);
+        }
+        if (S.dxh) bn_st4h(S.dxh, gr * S.lddxh + c, dx);
+    }
+}
+
+// 16-byte lanes usable?  -> log2(lanes per row) for the launch (3..6), or -1
+static inline bool bn_al(const void* p, int64_t ld, bool half) {
+    return !p || ((((uintptr_t)p) & (half ? 7 : 15)) == 0 && ld % 4 == 0);
+}
+static int bn_fwd_ls(const cdc_bn_fwd_args* a) {
+    int cmax = 0;
+    for (int s = 0; s < a->n_seg; ++s) {
+        const cdc_bn_seg& S = a->s[s];
+        if (S.C % 4 || !bn_al(S.x, S.ldx, S.half & CDC_BN_X_BF16) || !bn_al(S.y, S.ldy, false) || !bn_al(S.yh, S.ldyh, true)) return -1;
+        cmax = std::max(cmax, (int)S.C);
+    }
+    return cmax >= 256 ? 6 : cmax >= 128 ? 5 : cmax >= 64 ? 4 : 3;
+}
+static int bn_bwd_ls(const cdc_bn_bwd_args* a) {
+    int cmax = 0;
+    for (int s = 0; s < a->n_seg; ++s) {
+        const cdc_bn_bseg& S = a->s[s];
+        if (S.C % 4 || !bn_al(S.x, S.ldx, S.half & CDC_BN_X_BF16) || !bn_al(S.y, S.ldy, S.half & CDC_BN_Y_BF16) ||
+            !bn_al(S.dy, S.lddy, S.half & CDC_BN_DY_BF16) || !bn_al(S.dx, S.lddx, false) || !bn_al(S.dxh, S.lddxh, true)) return -1;
+        cmax = std::max(cmax, (int)S.C);
+    }
+    return cmax >= 256 ? 6 : cmax >= 128 ? 5 : cmax >= 64 ? 4 : 3;
+}
+#define BN_V4_LAUNCH(KERN, LS, GRID, ...)                                                                                   \
+    do {                                                                                                                    \
+        switch (LS) {                                                                                                       \
+            case 6: hipLaunchKernelGGL((KERN<6>), dim3(GRID), dim3(ROW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+            case 5: hipLaunchKernelGGL((KERN<5>), dim3(GRID), dim3(ROW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL((KERN<4>), dim3(GRID), dim3(ROW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERN<3>), dim3(GRID), dim3(ROW_THREADS), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+        }                                                                                                                   \
+    } while (0)
 
 // data parallel, between the two phases: per-column sums over the row chunks (fixed order) + the segment's row count go to
 // the exchange buffer [2*total_c | n_seg] that the caller all-reduces (SUM) across ranks
@@ -460,7 +848,8 @@ extern "C" int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream) {
     int total_c = 0, col_tiles = 0;
     for (int s = 0; s < a->n_seg; ++s) {
         const cdc_bn_seg& S = a->s[s];
-        CDC_CHECK_ARG(S.x && S.y && S.C > 0 && S.ldx >= S.C && S.ldy >= S.C, CDC_E_BADARG, "bn_fwd: segment %d malformed", s);
+        CDC_CHECK_ARG(S.x && (S.y || S.yh) && S.C > 0 && S.ldx >= S.C && (!S.y || S.ldy >= S.C) && (!S.yh || S.ldyh >= S.C) &&
+                          (S.half & ~CDC_BN_X_BF16) == 0, CDC_E_BADARG, "bn_fwd: segment %d malformed", s);
         CDC_CHECK_ARG(a->training || (S.running_mean && S.running_var), CDC_E_BADARG, "bn_fwd: eval needs running stats");
         total_c += S.C;
         col_tiles += (S.C + 63) / 64;
@@ -471,8 +860,13 @@ extern "C" int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream) {
     const int n_chunks = (int)cdc_ceil_div(a->M, CDC_BN_ROWS_PER_BLOCK);
     const int64_t grid = (int64_t)col_tiles * n_chunks;
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "bn_fwd: grid too large");
+    const int ls = bn_fwd_ls(a);                                         // 16-byte lanes (k_bn_*_v4) when every segment allows them
+    int64_t grid_v = 0;
+    if (ls >= 0)
+        for (int s = 0; s < a->n_seg; ++s) grid_v += (int64_t)cdc_ceil_div(a->s[s].C, 4 << ls) * n_chunks;
     if (a->training && a->phase != 2 && !a->stats_ready) {
-        hipLaunchKernelGGL(k_bn_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+        if (ls >= 0) BN_V4_LAUNCH(k_bn_stats_v4, ls, grid_v, *a, n_chunks, total_c);
+        else hipLaunchKernelGGL(k_bn_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
         CDC_LAUNCH_CHECK("bn_stats");
     }
     if (a->phase == 1) {
@@ -481,7 +875,8 @@ extern "C" int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream) {
         CDC_LAUNCH_CHECK("bn_collect");
         return 0;
     }
-    hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+    if (ls >= 0) BN_V4_LAUNCH(k_bn_apply_v4, ls, grid_v, *a, n_chunks, total_c);
+    else hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
     CDC_LAUNCH_CHECK("bn_apply");
     return 0;
 }
@@ -500,15 +895,16 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_stats(const cdc_bn_bwd_a
         const float mean = S.save_mean[c], invstd = S.save_invstd[c];
         constexpr int RPW = CDC_BN_ROWS_PER_BLOCK / WAVES_PER_BLOCK;
         const bool masked = a.relu || a.mask_scale != 1.f;
+        const bool xh = S.half & CDC_BN_X_BF16, yh = S.half & CDC_BN_Y_BF16, dyh = S.half & CDC_BN_DY_BF16;
         float dv[RPW], yv[RPW], xv[RPW];
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {                                  // 48 loads in flight per lane instead of 3
             const int r = r_begin + wave + k * WAVES_PER_BLOCK;
             const bool ok = r < r_end;
             const int64_t gr = t.row_lo + (ok ? r : r_begin);
-            dv[k] = ok ? S.dy[gr * S.lddy + c] : 0.f;
-            yv[k] = (ok && masked) ? S.y[gr * S.ldy + c] : 1.f;
-            xv[k] = S.x[gr * S.ldx + c];
+            dv[k] = ok ? bn_ld(S.dy, dyh, gr * S.lddy + c) : 0.f;
+            yv[k] = (ok && masked) ? bn_ld(S.y, yh, gr * S.ldy + c) : 1.f;
+            xv[k] = bn_ld(S.x, xh, gr * S.ldx + c);
         }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {                                  // rows past r_end carry dz = 0: exact zeros in both sums
@@ -561,15 +957,16 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
     constexpr int RPW = CDC_BN_ROWS_PER_BLOCK / WAVES_PER_BLOCK;
     const bool masked = a.relu || a.mask_scale != 1.f;
     const bool need_x = !skip_norm && a.training;
+    const bool xh = S.half & CDC_BN_X_BF16, yh = S.half & CDC_BN_Y_BF16, dyh = S.half & CDC_BN_DY_BF16;
     float dv[RPW], yv[RPW], xv[RPW];
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
         const int r = r_begin + wave + k * WAVES_PER_BLOCK;
         const bool ok = r < r_end;
         const int64_t gr = t.row_lo + (ok ? r : r_begin);
-        dv[k] = ok ? S.dy[gr * S.lddy + c] : 0.f;
-        yv[k] = (ok && masked) ? S.y[gr * S.ldy + c] : 1.f;
-        xv[k] = need_x ? S.x[gr * S.ldx + c] : 0.f;
+        dv[k] = ok ? bn_ld(S.dy, dyh, gr * S.lddy + c) : 0.f;
+        yv[k] = (ok && masked) ? bn_ld(S.y, yh, gr * S.ldy + c) : 1.f;
+        xv[k] = need_x ? bn_ld(S.x, xh, gr * S.ldx + c) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
@@ -584,9 +981,11 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
             const float xhat = (xv[k] - mean) * invstd;
             dx = gam * invstd * (dz - invM * (db + xhat * dg));
         } else dx = gam * invstd * dz;
-        float* dst = S.dx + gr * S.lddx + c;
-        if (S.accumulate_dx) dx = *dst + dx;
-        *dst = dx;
+        if (S.dx) {
+            float* dst = S.dx + gr * S.lddx + c;
+            if (S.accumulate_dx) dx = *dst + dx;
+            *dst = dx;
+        }
         if (S.dxh) reinterpret_cast<__bf16*>(S.dxh)[gr * S.lddxh + c] = (__bf16)dx;
     }
 }
@@ -596,7 +995,8 @@ extern "C" int cdc_bn_bwd(const cdc_bn_bwd_args* a, void* stream) {
     int total_c = 0, col_tiles = 0;
     for (int s = 0; s < a->n_seg; ++s) {
         const cdc_bn_bseg& S = a->s[s];
-        CDC_CHECK_ARG(S.dy && S.y && S.x && S.dx && S.save_mean && S.save_invstd && S.C > 0, CDC_E_BADARG, "bn_bwd: segment %d malformed", s);
+        CDC_CHECK_ARG(S.dy && S.y && S.x && (S.dx || (S.dxh && !S.accumulate_dx)) && S.save_mean && S.save_invstd && S.C > 0, CDC_E_BADARG,
+                      "bn_bwd: segment %d malformed", s);
         total_c += S.C;
         col_tiles += (S.C + 63) / 64;
     }
@@ -606,8 +1006,13 @@ extern "C" int cdc_bn_bwd(const cdc_bn_bwd_args* a, void* stream) {
     const int n_chunks = (int)cdc_ceil_div(a->M, CDC_BN_ROWS_PER_BLOCK);
     const int64_t grid = (int64_t)col_tiles * n_chunks;
     CDC_CHECK_ARG(grid < (1ll << 31), CDC_E_TOOBIG, "bn_bwd: grid too large");
+    const int ls = bn_bwd_ls(a);
+    int64_t grid_v = 0;
+    if (ls >= 0)
+        for (int s = 0; s < a->n_seg; ++s) grid_v += (int64_t)cdc_ceil_div(a->s[s].C, 4 << ls) * n_chunks;
     if (a->phase != 2) {
-        hipLaunchKernelGGL(k_bn_bwd_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+        if (ls >= 0) BN_V4_LAUNCH(k_bn_bwd_stats_v4, ls, grid_v, *a, n_chunks, total_c);
+        else hipLaunchKernelGGL(k_bn_bwd_stats, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
         CDC_LAUNCH_CHECK("bn_bwd_stats");
     }
     if (a->phase == 1) {
@@ -616,7 +1021,8 @@ extern "C" int cdc_bn_bwd(const cdc_bn_bwd_args* a, void* stream) {
         CDC_LAUNCH_CHECK("bn_bwd_collect");
         return 0;
     }
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
+    if (ls >= 0) BN_V4_LAUNCH(k_bn_bwd_apply_v4, ls, grid_v, *a, n_chunks, total_c);
+    else hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a, n_chunks, total_c);
     CDC_LAUNCH_CHECK("bn_bwd_apply");
     return 0;
 }

@@ -204,10 +204,14 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
                 n_extra += 1
         if use_bn:
             op = P.GLinear(plan, groups, relu=False, dropout=False)
+            post = None
             if dst is None:
                 post = plan.new(n * width)
                 dst = [post.slice(i * width, (i + 1) * width) for i in range(n)]
             segs = [_bn_seg(pre.slice(i * width, (i + 1) * width), m.hidden[j][1], out=dst[i]) for i, m in enumerate(mlps)]
+            if j < depth - 1 and width % 8 == 0 and post is not None:
+                for sg in segs:                       # read by the next layer's contractions only (see the BatchNorm-free case below)
+                    sg["half_only"] = True
             P.BatchNorm(plan, segs, relu=True, dropout=True)
             cur = dst
         else:

@@ -418,6 +418,18 @@ class Plan:
     def is_half_only(self, buf):
         return id(buf.root) in self._half_only
 
+    def make_value_half_only(self, buf):
+        """like make_half_only for the values alone (their gradient keeps its fp32 form)"""
+        self._half_only.add(id(buf.root))
+        buf.root.fill_(float("nan"))
+
+    def make_grad_half_only(self, buf):
+        """the GRADIENT of buf is only ever read by bf16 contractions (dZ of a linear layer whose grad-input / grad-weight launches
+        read the shadow): it is written as bf16 alone"""
+        g = self._root_grad(buf.root)
+        self._half_only.add(id(g))
+        g.fill_(float("nan"))
+
     def shadow_convert_step(self, buf):
         """a launch step that rewrites buf's shadow from its fp32 values (for a caller that fills buf behind the plan's back:
         the row-sharded trainer replaces the gather launch by its row exchange)"""
@@ -691,7 +703,7 @@ class GLinear:
     def build_bwd(self, plan, gs):
         # dZ of every group lives in y.grad (pre-activation gradient, see module docstring)
         for g in self.groups:
-            if plan.is_half_only(g["y"]):
+            if plan.is_half_only(g["y"]) or plan.is_half_only(g["y"].grad):
                 if not plan.has_shadow(g["y"].grad):
                     raise RuntimeError("the gradient of a shadow-only activation was not written by a bf16 grad-input launch")
                 continue
@@ -718,7 +730,7 @@ class GLinear:
                                           "db": db, "M": self.M, "N": N, "K": K, "accumulate": 1 if acc_w else 0,
                                           "dzh": plan.shadow_view(dz) if self.g2 else None,
                                           "xh": plan.shadow_view(g["x"]) if self.g2 else None,
-                                          "needs_shadows": plan.is_half_only(g["x"]) or plan.is_half_only(g["y"])})
+                                          "needs_shadows": plan.is_half_only(g["x"]) or plan.is_half_only(g["y"]) or plan.is_half_only(dz)})
         for c0 in (range(0, len(self.groups), L.MAX_GROUPS) if not defer else []):
             chunk = self.groups[c0:c0 + L.MAX_GROUPS]
             a = L.LinBwdwArgs()
@@ -850,7 +862,7 @@ class GLinear:
                 O = a.o[oi]
                 xg = x.grad
                 acc = gs.claim(x)                          # (invalidates an older shadow of x.grad)
-                half = plan.is_half_only(x)
+                half = plan.is_half_only(xg)               # (the values of x may be bf16-only while their gradient is not)
                 if half:
                     if acc:
                         raise RuntimeError("an activation kept as a bf16 shadow only feeds more than one grad-input launch")
@@ -1017,6 +1029,15 @@ class BatchNorm:
                 S = a.s[i]
                 S.x, S.ldx = s["x"].ptr, s["x"].ld
                 S.y, S.ldy = s["y"].ptr, s["y"].ld
+                S.half = 0
+                prod = plan._lin_producer.get((id(s["x"].root), s["x"].col0, s["x"].cols))
+                s["_lin_g2"] = bool(prod is not None and getattr(prod["op"], "g2", False) and prod["G"].act_cols == 0)
+                # the caller vouches (seg["half_only"]) that y is read by bf16 contractions only — and one did ask for the shadow:
+                # y then exists as bf16 alone (its sign is the relu/dropout mask of the backward)
+                if (s.get("half_only") and plan.use_g2 and plan.shadow_wanted(s["y"]) and self.row_offsets is None and
+                        os.environ.get("CDC_HALF_ONLY", "1") != "0"):
+                    plan.make_value_half_only(s["y"])
+                    S.y = None
                 S.gamma, S.beta = s["gamma"].data_ptr(), s["beta"].data_ptr()
                 S.running_mean, S.running_var = s["running_mean"].data_ptr(), s["running_var"].data_ptr()
                 S.save_mean, S.save_invstd = s["save_mean"].data_ptr(), s["save_invstd"].data_ptr()
@@ -1095,7 +1116,12 @@ class BatchNorm:
                 plan.ensure_grad(s["y"], gs)
                 yg = s["y"].grad
                 S.dy, S.lddy = yg.ptr, yg.ld
-                S.y, S.ldy = s["y"].ptr, s["y"].ld
+                S.half = 0
+                if plan.is_half_only(s["y"]):
+                    S.y, S.ldy = plan.shadow_view(s["y"])
+                    S.half |= L.BN_Y_BF16
+                else:
+                    S.y, S.ldy = s["y"].ptr, s["y"].ld
                 S.x, S.ldx = s["x"].ptr, s["x"].ld
                 S.accumulate_dx = 0
                 S.dxh = None
@@ -1115,6 +1141,11 @@ class BatchNorm:
                     if plan.use_g2 and plan.shadow_wanted(xg):
                         S.dxh, S.lddxh = plan.shadow_view(xg)
                         plan.mark_shadow(xg)
+                        # x is the output of a bf16 linear launch whose backward reads dZ through the shadow only
+                        if (s.get("_lin_g2") and not S.accumulate_dx and self.row_offsets is None and
+                                os.environ.get("CDC_HALF_ONLY", "1") != "0"):
+                            plan.make_grad_half_only(s["x"])
+                            S.dx = None
                 S.gamma = s["gamma"].data_ptr()
                 if plan.training:
                     S.save_mean, S.save_invstd = s["save_mean"].data_ptr(), s["save_invstd"].data_ptr()

@@ -420,16 +420,21 @@ int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream);
  * ---------------------------------------------------------------------------------------- */
 #define CDC_MAX_BN_SEGS 24
 #define CDC_BN_ROWS_PER_BLOCK 64      /* rows per partial-sum block: workspace holds ceil(M/64) partials */
+#define CDC_BN_X_BF16 1               /* `half` bits: the operand is stored as bf16 (pointer and ld are those of the bf16 array) */
+#define CDC_BN_Y_BF16 2
+#define CDC_BN_DY_BF16 4
 typedef struct {
-    const float* x; int64_t ldx;      /* [M,C] pre-norm */
-    float* y; int64_t ldy;            /* [M,C] output */
+    const void* x; int64_t ldx;       /* [M,C] pre-norm; fp32, or bf16 with half & CDC_BN_X_BF16 */
+    float* y; int64_t ldy;            /* [M,C] output; may be NULL when yh is given (the output then exists as bf16 only) */
     const float* gamma; const float* beta;
     float* running_mean; float* running_var;  /* updated in training */
     float* save_mean; float* save_invstd;     /* [C] saved for backward (training) */
     int64_t* num_batches_tracked;     /* incremented in training when the segment is normalised (may be NULL) */
-    void* yh; int64_t ldyh;           /* optional bf16 shadow of y, or NULL */
+    void* yh; int64_t ldyh;           /* optional bf16 copy of y, or NULL */
     int32_t C;
     int32_t row_group;                /* index into row_offsets (ragged rows) */
+    int32_t half;                     /* CDC_BN_X_BF16 or 0 */
+    int32_t pad_;
 } cdc_bn_seg;
 typedef struct {
     int32_t n_seg;
@@ -453,10 +458,10 @@ typedef struct {
 int cdc_bn_fwd(const cdc_bn_fwd_args* a, void* stream);
 
 typedef struct {
-    const float* dy; int64_t lddy;    /* grad w.r.t. the post-activation output */
-    const float* y;  int64_t ldy;     /* post-activation output (relu/dropout mask) */
-    const float* x;  int64_t ldx;     /* pre-norm input */
-    float* dx; int64_t lddx;
+    const void* dy; int64_t lddy;     /* grad w.r.t. the post-activation output (bf16 with half & CDC_BN_DY_BF16) */
+    const void* y;  int64_t ldy;      /* post-activation output: only its sign is used (relu/dropout mask); bf16 with CDC_BN_Y_BF16 */
+    const void* x;  int64_t ldx;      /* pre-norm input (bf16 with CDC_BN_X_BF16) */
+    float* dx; int64_t lddx;          /* may be NULL when dxh is given and accumulate_dx is 0 (dx then exists as bf16 only) */
     const float* gamma;
     const float* save_mean; const float* save_invstd;      /* training: batch stats; eval: the running
                                                               mean and 1/sqrt(running_var+eps) */
@@ -465,7 +470,7 @@ typedef struct {
     int32_t C;
     int32_t row_group;
     int32_t accumulate_dx;            /* 1: dx += (several segments normalise the same input: STAR's domain_norm) */
-    int32_t pad_;
+    int32_t half;                     /* CDC_BN_X_BF16 | CDC_BN_Y_BF16 | CDC_BN_DY_BF16 */
 } cdc_bn_bseg;
 typedef struct {
     int32_t n_seg;
