@@ -48,6 +48,7 @@ STRUCTS = {
     "cdc_star_fuse_args": "StarFuseArgs", "cdc_transpose_args": "TransposeArgs", "cdc_add_n_args": "AddNArgs",
     "cdc_g2_out": "G2Out", "cdc_g2_seg": "G2Seg", "cdc_g2_args": "G2Args", "cdc_wshadow_args": "WShadowArgs",
     "cdc_shadow_args": "ShadowArgs", "cdc_head_tower": "HeadTower", "cdc_head_args": "HeadArgs",
+    "cdc_tower_layer": "TowerLayer", "cdc_tower_desc": "TowerDesc", "cdc_tower_args": "TowerArgs",
 }
 
 
@@ -80,7 +81,8 @@ def test_limits_match_the_header():
     for macro, val in [("CDC_MAX_GROUPS", _lib.MAX_GROUPS), ("CDC_MAX_TENSORS", _lib.MAX_TENSORS), ("CDC_MAX_GATES", _lib.MAX_GATES),
                        ("CDC_MAX_SEL", _lib.MAX_SEL), ("CDC_MAX_BN_SEGS", _lib.MAX_BN_SEGS), ("CDC_SORT_MAX_B", _lib.SORT_MAX_B), ("CDC_SORT_MAX_ROWS", _lib.SORT_MAX_ROWS),
                        ("CDC_BN_ROWS_PER_BLOCK", _lib.BN_ROWS_PER_BLOCK), ("CDC_ROWDOT_PARTS", _lib.ROWDOT_PARTS),
-                       ("CDC_G2_MAX_OUT", _lib.G2_MAX_OUT), ("CDC_G2_MAX_SEG", _lib.G2_MAX_SEG), ("CDC_HEAD_MAX_TOWERS", _lib.HEAD_MAX_TOWERS)]:
+                       ("CDC_G2_MAX_OUT", _lib.G2_MAX_OUT), ("CDC_G2_MAX_SEG", _lib.G2_MAX_SEG), ("CDC_HEAD_MAX_TOWERS", _lib.HEAD_MAX_TOWERS),
+                       ("CDC_TOWER_MAX", _lib.TOWER_MAX), ("CDC_TOWER_MAX_LAYERS", _lib.TOWER_MAX_LAYERS), ("CDC_TOWER_MAX_DIM", _lib.TOWER_MAX_DIM)]:
         m = re.search(rf"#define\s+{macro}\s+(\d+)", src)
         assert m and int(m.group(1)) == val, macro
 
