@@ -380,6 +380,24 @@ def profiled_traffic(call_name):
     return None, None
 
 
+def event_pair_floor_ms(ts, n=64):
+    """median HIP-event time around a one-element cdc_fill_f32 launch, taken exactly like the per-launch times of ts.profile()"""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    buf = torch.zeros(4, dtype=torch.float32, device=ts.device)
+    rec = []
+    L.PROFILE = rec
+    try:
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(n):
+            L.launch("floor", ts.lib.cdc_fill_f32, (buf.data_ptr(), 0.0, 1), st)
+        torch.cuda.synchronize()
+        times = sorted(e0.elapsed_time(e1) for _, e0, e1, _, _ in rec)
+    finally:
+        L.PROFILE = None
+    return times[len(times) // 2]
+
+
 def measure_roofline(args, ts, opt, Xd, yd, gd):
     """Per-launch HIP-event timing of instrumented eager steps (same launches as the timed region, which may be
     replayed as a graph where events cannot be placed).  The roofline object is for the step's dominant kernel."""
@@ -417,8 +435,12 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
                                 "R*D per step (rows looked up since their last flush replay fewer); the time is the live HIP-event figure, "
                                 "which includes the event pair's latency (rocprofv3: 98 us per launch = 9.3 lane-cycles)"}
     traffic, traffic_src = profiled_traffic(name)
+    floor_ms = event_pair_floor_ms(ts)
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": traffic,
                  "traffic_source": traffic_src,
+                 # what the same event pair reads around a one-element fill launch (~2 us of kernel): the part of avg_launch_ms that is
+                 # the events' own dispatch latency, not the kernel — rocprofv3's per-kernel average has no such term
+                 "event_pair_floor_ms": floor_ms, "avg_launch_ms_less_event_floor": max(per_launch_ms - max(floor_ms - 0.002, 0.0), 0.0),
                  "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown, "breakdown_all": breakdown_all})
     # all MFMA launches together (north-star figure: expert GEMMs vs bf16 peak)
     gm = [v for k, v in prof.items() if "glinear" in k]

@@ -13,6 +13,8 @@ Reference citations (file:line under the reference repository):
   CrossNetwork             model/layer.py:303-329
   CrossNetV2 / CrossNetMix model/layer.py:332-407
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -202,7 +204,13 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
             o = pre.slice(i * width, (i + 1) * width) if (use_bn or dst is None) else dst[i]
             groups.append({"x": cur[i], "w": lin.weight, "b": lin.bias, "out": o})
         n_extra = 0
-        if j == 0 and extra_groups:
+        # The gates read the level's input like the first layer, but the first layer's launch is exactly one round of tiles at C2
+        # (8 experts x 256 columns x 4096 rows = 512 tiles of 128 x 128 on 256 CUs x 2) and the gates' 128 nearly empty tiles
+        # made it a second round: 28.9 us against 13.6 us for the second layer's launch, which has 256 slots to spare.  So with
+        # two or more layers the gates ride in the LAST layer's forward launch; their grad-input stays with the first layer's
+        # (further reduction segments of the same output: adopt_bwd_x below).
+        gate_layer = depth - 1 if (depth >= 2 and plan.use_g2 and os.environ.get("CDC_GATES_LATE", "1") != "0") else 0
+        if j == gate_layer and extra_groups:
             for g in extra_groups:
                 g = dict(g)
                 g["act_cols"] = 0
@@ -229,8 +237,12 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
                     g["half_only"] = True
             op = P.GLinear(plan, groups, relu=True, dropout=True)
             cur = [op.outs[i] for i in range(n)]
+        if j == 0:
+            first_op = op
         if n_extra:
             extra_outs = op.outs[n:]
+            if op is not first_op:
+                first_op.adopt_bwd_x(op, op.groups[n:])
     if mlps[0].out_linear is not None and head_out is not None:
         # the output layers of all towers, the wide term and the sigmoid in one launch per direction (csrc/head.hip)
         towers = [{"x": cur[i], "w": m.out_linear.weight, "b": m.out_linear.bias} for i, m in enumerate(mlps)]

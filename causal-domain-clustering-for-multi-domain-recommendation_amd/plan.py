@@ -598,6 +598,7 @@ class GLinear:
         self.M = plan.B if M is None else M
         self.seed = plan._next_seed()
         self.outs = []
+        self.adopted = []                 # groups of ANOTHER launch whose grad-input this op's backward forms (adopt_bwd_x)
         for g in groups:
             N, K = g["w"].shape
             assert g["x"].cols == K, f"linear input has {g['x'].cols} columns, weight expects {K}"
@@ -636,6 +637,18 @@ class GLinear:
             if S > 1:
                 plan.need_gemm_ws(S * sum(g["w"].numel() + g["w"].shape[0] for g in chunk))
         plan.add(self)
+
+    def adopt_bwd_x(self, other, groups):
+        """`groups` of the launch `other` read an input that this launch's groups read too: their grad-input contributions become
+        further reduction segments of THIS op's grad-input output instead of an output (and tiles) of their own in `other`'s.
+        (PLE / MMoE: the gates read the level's input like the first expert layer, but their forward rides in the LAST expert
+        layer's launch, which has tile slots to spare.)  Both launches must be on the bf16-shadow path."""
+        if not (self.g2 and other.g2 and self.row_offsets is None and other.row_offsets is None and self.M == other.M):
+            return False
+        for g in groups:
+            g["no_dx"] = True
+            self.adopted.append(g)
+        return True
 
     def _build_fwd_g2(self, plan):
         plan.ensure_shadows([g["x"] for g in self.groups], plan.fwd_steps)
@@ -711,7 +724,7 @@ class GLinear:
                 continue
             plan.ensure_grad(g["y"], gs)
         if self.g2:                                  # grad-input and grad-weight read dZ through its bf16 shadow
-            plan.ensure_shadows([g["y"].grad for g in self.groups], plan.bwd_steps)
+            plan.ensure_shadows([g["y"].grad for g in self.groups + self.adopted], plan.bwd_steps)
         # ---- grad-weight / grad-bias
         # leaf weights (parameters): deferred to one launch with every other layer's at the end of backward.
         # fused weights (STAR's W_d*W_s: their gradient feeds a further backward op) and ragged groups: right here.
@@ -762,9 +775,10 @@ class GLinear:
             fl = sum(2.0 * self.M * g["w"].shape[0] * g["w"].shape[1] for g in chunk)
             plan.bwd_steps.append(plan.call("cdc_glinear_bwd_w", C.byref(a), plan.prec, flops=fl))
         # ---- grad-input: groups reading the same x reduce into one output
-        outs = []      # list of (x Buf, [group indices])
-        for gi, g in enumerate(self.groups):
-            if g.get("no_dx"):
+        outs = []      # list of (x Buf, [group indices]); indices run over this op's groups, then the adopted ones
+        allg = self.groups + self.adopted
+        for gi, g in enumerate(allg):
+            if g.get("no_dx") and gi < len(self.groups):
                 continue
             x = g["x"]
             for o in outs:
@@ -792,7 +806,7 @@ class GLinear:
             assert len(outs) == len(self.groups) and len(outs) <= L.MAX_GROUPS, "ragged launch limited to one chunk"
             launches = [outs]
         if self.g2:
-            return self._build_bwd_x_g2(plan, gs, outs)
+            return self._build_bwd_x_g2(plan, gs, outs, allg)
         ragged_acc = {}
         for la in launches:
             # all outputs of one launch share the mask scale (one plan-wide dropout rate)
@@ -841,7 +855,7 @@ class GLinear:
             plan.bwd_steps.append(plan.call("cdc_glinear_bwd_x", C.byref(a), plan.prec, flops=fl))
 
 
-    def _build_bwd_x_g2(self, plan, gs, outs):
+    def _build_bwd_x_g2(self, plan, gs, outs, allg):
         """grad-input from the bf16 shadows of dZ and the per-step W^T copies; outputs: x.grad in fp32, plus its bf16 shadow
         when the layer that produced x reads its dZ through one"""
         launches, cur_o, cur_s = [], [], 0
@@ -888,7 +902,7 @@ class GLinear:
                     O.mask, O.act_cols, O.mask_bf16 = None, 0, 0
                 O.M, O.N, O.accumulate, O.stream_id = self.M, x.cols, 1 if acc else 0, oi
                 for gi in gis:
-                    g = self.groups[gi]
+                    g = allg[gi]
                     S = a.s[si]
                     S.a, S.lda = plan.shadow_view(g["y"].grad)
                     _, wt = plan.wshadow(g["w"])
@@ -897,7 +911,7 @@ class GLinear:
                     si += 1
             a.n_seg = si
             self._keep.append(a)
-            fl = sum(2.0 * self.M * self.groups[gi]["w"].shape[0] * self.groups[gi]["w"].shape[1] for _, gis in la for gi in gis)
+            fl = sum(2.0 * self.M * allg[gi]["w"].shape[0] * allg[gi]["w"].shape[1] for _, gis in la for gi in gis)
             plan.bwd_steps.append(plan.call("cdc_gemm_bf16_nt", C.byref(a), what="cdc_glinear_bwd_x", flops=fl))
 
 
