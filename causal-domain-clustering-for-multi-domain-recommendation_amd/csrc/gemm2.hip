@@ -660,7 +660,10 @@ int g2_launch_bwd_w(const cdc_lin_bwdw_args* a, int64_t slab_stride, hipStream_t
         if (G.K > max_k) max_k = G.K;
     }
     const int S = a->split_k > 1 ? a->split_k : 1;
-    const bool small = max_n <= 64 && max_k <= 64;
+    // 64x64 output tiles when no group has more than 64 output rows (gates, narrow layers: a 128-row tile would be mostly
+    // padding), whatever their K; the caller keeps such groups in launches of their own (plan.py: _emit_deferred_dw)
+    const bool small = max_n <= 64;
+    (void)max_k;
     int64_t t = 0;
     for (int g = 0; g < a->n_groups; ++g)
         t += small ? cdc_ceil_div(a->g[g].N, 64) * cdc_ceil_div(a->g[g].K, 64) : cdc_ceil_div(a->g[g].N, 128) * cdc_ceil_div(a->g[g].K, 128);
@@ -674,7 +677,7 @@ int g2_launch_bwd_w(const cdc_lin_bwdw_args* a, int64_t slab_stride, hipStream_t
 }
 bool g2_bwd_w_uses_small_tiles(const cdc_lin_bwdw_args* a) {
     for (int g = 0; g < a->n_groups; ++g)
-        if (a->g[g].N > 64 || a->g[g].K > 64) return false;
+        if (a->g[g].N > 64) return false;
     return true;
 }
 

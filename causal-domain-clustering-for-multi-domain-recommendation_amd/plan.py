@@ -285,11 +285,20 @@ class Plan:
         """All layers' grad-weight contractions are independent of the rest of backward once their dZ exists: they go out
         together at the end, in launches that fill the chip (instead of one under-filled launch per layer)."""
         groups = self._deferred_dw
+        # narrow outputs (N <= 64: gates, the last expert level, towers) go to launches of their own: the grad-weight kernel then
+        # uses 64x64 tiles for them instead of padding each to 128 rows (a gate with 4 outputs filled 3 % of its tiles).  The
+        # order inside a class is kept (a group that accumulates follows its base; both have the same N)
+        if os.environ.get("CDC_DW_CLASSES", "1") != "0":
+            groups = ([g for g in groups if g.get("dzh") is not None and g["N"] > 64] +
+                      [g for g in groups if g.get("dzh") is not None and g["N"] <= 64] +
+                      [g for g in groups if g.get("dzh") is None])
         launches, cur = [], []
+        narrow = lambda g: g.get("dzh") is not None and g["N"] <= 64      # noqa: E731
         for g in groups:
             # (a launch is either all-shadows (csrc/gemm2.hip) or all-fp32-operands: layers too narrow for the bf16 tiles sit
             # next to wide ones in small models)
-            if cur and (len(cur) >= L.MAX_GROUPS or g["accumulate"] or (g.get("dzh") is None) != (cur[0].get("dzh") is None)):
+            if cur and (len(cur) >= L.MAX_GROUPS or g["accumulate"] or (g.get("dzh") is None) != (cur[0].get("dzh") is None) or
+                        narrow(g) != narrow(cur[0])):
                 launches.append(cur)
                 cur = []
             cur.append(g)
@@ -305,7 +314,7 @@ class Plan:
             if all(g.get("dzh") is not None for g in chunk):
                 # shadows (csrc/gemm2.hip k_g2_tn): 128x128 output tiles unless every group is at most 64x64; a row slice of at least
                 # four 64-row slabs per workgroup
-                T = 64 if all(g["N"] <= 64 and g["K"] <= 64 for g in chunk) else 128
+                T = 64 if all(g["N"] <= 64 for g in chunk) else 128
                 tiles = sum(math.ceil(g["N"] / T) * math.ceil(g["K"] / T) for g in chunk)
                 S = max(1, min(int(os.environ.get("CDC_DW_BLOCKS", "512")) // max(tiles, 1), max(Mmax // 256, 1), 32))
             else:
