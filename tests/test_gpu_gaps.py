@@ -100,6 +100,8 @@ def test_bf16_backward_arithmetic_on_a_model_without_branch_flips(cuda):
     BatchNorm, softmax pooling, head) on a model small enough that no relu unit sits within noise of zero: every gradient tensor
     within 5e-4 relative L2 of the exact-accumulation restatement (measured: worst 8.5e-5, median 5e-6).  One flipped unit would
     show as ~3e-3 in its tower; seeds and kernels are deterministic, so this does not flicker."""
+    if os.environ.get("CDC_GEMM2") == "0":
+        pytest.skip("the round-1 contraction path sums the bias gradient from the fp32 dZ; the restatement follows csrc/gemm2.hip")
     from cdcmdr_amd.model.mmoe import MMoE
     fd = [1000] * 26
     torch.manual_seed(2)
@@ -160,6 +162,8 @@ def test_fused_tower_forward_launch_equals_the_five_launches(cuda, monkeypatch):
     grid-wide barriers.  Same contractions on the same bf16 operands, same statistics up to the summation order of the 64-row
     partial sums: probabilities, every gradient (the backward launches are the unfused ones and read what the fused forward
     wrote), running statistics — in training mode over two steps (the barrier counters must come back to zero) and in eval mode."""
+    if os.environ.get("CDC_GEMM2") == "0":
+        pytest.skip("the fused tower launch belongs to the bf16-copy contraction path")
     from cdcmdr_amd.model.ple import PLE
     fd = [1000] * 26
     rng = np.random.default_rng(4)
