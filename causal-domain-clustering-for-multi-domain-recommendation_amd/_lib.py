@@ -267,6 +267,7 @@ _SIGNATURES = {
     "cdc_embed_lazy_catchup_gather": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_update": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p]),
     "cdc_embed_lazy_flush": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "cdc_embed_lazy_flush_bg": (c_i32, [c_p, c_p, c_p, c_p, c_i64, c_i32, AdamHP, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "cdc_embed_merge_dedupe": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "cdc_eval_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "cdc_eval_metrics": (c_i32, [c_p, c_p, c_p, c_i64, c_i64, c_i32, c_p, c_p, c_p, c_p, c_i64, c_p]),

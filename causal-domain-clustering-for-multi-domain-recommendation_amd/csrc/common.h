@@ -36,6 +36,10 @@ static inline int64_t cdc_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / 
 // ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
+// Wave issue priority (s_setprio, 0..3; waves start at 0).  The launches of the forward/backward chain raise theirs, so that a
+// VALU-only background launch sharing the CUs (the lazy table's replay slice, which stays at 0) only takes the issue cycles
+// the chain's waves leave idle while they wait on L2 / LDS / MFMA results.
+#define CDC_PRIO_MAIN() __builtin_amdgcn_s_setprio(2)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

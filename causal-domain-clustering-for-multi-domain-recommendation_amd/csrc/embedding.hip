@@ -16,6 +16,7 @@ __global__ void __launch_bounds__(256) k_gather_fwd(const int32_t* __restrict__ 
                                                     __bf16* __restrict__ out_h, int64_t ld_out_h,
                                                     int32_t* __restrict__ idx_out, int32_t* __restrict__ err_flag,
                                                     int64_t n_pos, int32_t F, int32_t D, int64_t R) {
+    CDC_PRIO_MAIN();
     const int chunks = D / VEC;                       // chunks of VEC floats per row
     const int64_t total = n_pos * chunks;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1288,39 +1289,54 @@ __global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float
     const int64_t n_rows = (row_hi - first + stride - 1) / stride;
     const int chunks = D / VEC;
     const int64_t total = n_rows * chunks;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = base + threadIdx.x;
-        bool act = i < total;
-        const int64_t row = act ? first + (i / chunks) * stride : first;
-        const int64_t e0 = row * D + (act ? (i % chunks) * VEC : 0);
-        int from = act ? last[row] : target;
-        act = act && from < target;
-        if (!act) from = target;
-        if (!__any(act)) continue;                               // wave-uniform
-        float wv[VEC], mv[VEC], vv[VEC];
+    // software pipeline: the loads of the NEXT item are in flight under the replay of this one (the background form of this
+    // launch runs with one or two waves per SIMD, too few to hide a ~2 us load behind other waves)
+    struct Item { bool act; int from; int64_t row, e0, i; float wv[VEC], mv[VEC], vv[VEC]; };
+    auto fetch = [&](int64_t base, Item& it) {
+        it.i = base + threadIdx.x;
+        it.act = base < total && it.i < total;
+        it.row = it.act ? first + (it.i / chunks) * stride : first;
+        it.e0 = it.row * D + (it.act ? (it.i % chunks) * VEC : 0);
+        it.from = it.act ? last[it.row] : target;
+        it.act = it.act && it.from < target;
+        if (!it.act) it.from = target;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { wv[k] = 0.f; mv[k] = 0.f; vv[k] = 1.f; }
-        if (act) {
+        for (int k = 0; k < VEC; ++k) { it.wv[k] = 0.f; it.mv[k] = 0.f; it.vv[k] = 1.f; }
+        if (it.act) {
             if (VEC == 4) {
-                const float4 a4 = *reinterpret_cast<const float4*>(w + e0), b4 = *reinterpret_cast<const float4*>(m + e0),
-                             c4 = *reinterpret_cast<const float4*>(v + e0);
-                wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w;
-                mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
-                vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
+                // streamed once per flush period: non-temporal, so that the slice does not push the contractions' operands out of L2
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v a4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(w + it.e0)),
+                          b4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m + it.e0)),
+                          c4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v + it.e0));
+                it.wv[0] = a4.x; it.wv[1] = a4.y; it.wv[2] = a4.z; it.wv[3] = a4.w;
+                it.mv[0] = b4.x; it.mv[1] = b4.y; it.mv[2] = b4.z; it.mv[3] = b4.w;
+                it.vv[0] = c4.x; it.vv[1] = c4.y; it.vv[2] = c4.z; it.vv[3] = c4.w;
             } else {
-                wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0];
+                it.wv[0] = w[it.e0]; it.mv[0] = m[it.e0]; it.vv[0] = v[it.e0];
             }
         }
-        adam_replay_wave<FAST, VEC>(wv, mv, vv, from, target, c, hp);
-        if (!act) continue;
-        if (VEC == 4) {
-            *reinterpret_cast<float4*>(w + e0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-            *reinterpret_cast<float4*>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-            *reinterpret_cast<float4*>(v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        } else {
-            w[e0] = wv[0]; m[e0] = mv[0]; v[e0] = vv[0];
+    };
+    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
+    Item cur, nxt;
+    fetch((int64_t)blockIdx.x * blockDim.x, cur);
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += gstride) {
+        fetch(base + gstride, nxt);                              // (past the end: an inactive item, no loads)
+        if (__any(cur.act)) {                                    // wave-uniform
+            adam_replay_wave<FAST, VEC>(cur.wv, cur.mv, cur.vv, cur.from, target, c, hp);
+            if (cur.act) {
+                if (VEC == 4) {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((f4v){cur.wv[0], cur.wv[1], cur.wv[2], cur.wv[3]}, reinterpret_cast<f4v*>(w + cur.e0));
+                    __builtin_nontemporal_store((f4v){cur.mv[0], cur.mv[1], cur.mv[2], cur.mv[3]}, reinterpret_cast<f4v*>(m + cur.e0));
+                    __builtin_nontemporal_store((f4v){cur.vv[0], cur.vv[1], cur.vv[2], cur.vv[3]}, reinterpret_cast<f4v*>(v + cur.e0));
+                } else {
+                    w[cur.e0] = cur.wv[0]; m[cur.e0] = cur.mv[0]; v[cur.e0] = cur.vv[0];
+                }
+                if (mark && (cur.i % chunks) == 0) last[cur.row] = target;   // the row's lanes share one wave (see k_lazy_catchup)
+            }
         }
-        if (mark && (i % chunks) == 0) last[row] = target;        // the row's lanes share one wave (see k_lazy_catchup)
+        cur = nxt;
     }
 }
 __global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ last, int64_t R, const int32_t* __restrict__ step_dev,
@@ -1338,9 +1354,9 @@ __global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ las
     }
 }
 
-extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D, cdc_adam_hp hp,
-                                    const int32_t* step_dev, int32_t step_bias, int32_t period, int32_t own_mod, int32_t own_rem,
-                                    void* stream) {
+static int lazy_flush_launch(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D, cdc_adam_hp hp,
+                             const int32_t* step_dev, int32_t step_bias, int32_t period, int32_t own_mod, int32_t own_rem,
+                             int32_t waves_per_simd, void* stream) {
     CDC_CHECK_ARG(w && m && v && last && step_dev && hp.step_scalars && hp.n_scalars > 0, CDC_E_BADARG, "embed_lazy_flush: null pointer");
     CDC_CHECK_ARG(R > 0 && D > 0 && period >= 0 && own_mod >= 0 && (own_mod <= 1 || (own_rem >= 0 && own_rem < own_mod)), CDC_E_BADARG,
                   "embed_lazy_flush: bad sizes");
@@ -1349,6 +1365,16 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
     int64_t rows_call = period > 1 ? cdc_ceil_div(R, period) : R;
     if (own_mod > 1) rows_call = cdc_ceil_div(rows_call, own_mod) + 1;
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(cdc_ceil_div(rows_call * D / (vec ? 4 : 1), 256), 256 * 16));
+    if (waves_per_simd > 0) {                                    // background form: a workgroup of 256 threads = one wave per SIMD of its CU
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v_ = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v_, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v_ <= 0) v_ = 256;
+            n_cu = v_;
+        }
+        const int64_t cap = (int64_t)waves_per_simd * n_cu;
+        if (blocks > cap) blocks = (int)cap;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int32_t chunks = vec ? D / 4 : D;
     const int32_t mark = (64 % chunks == 0) ? 1 : 0;             // last[] advanced inside the kernel; else by k_lazy_set_last
@@ -1366,6 +1392,16 @@ extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last,
         CDC_LAUNCH_CHECK("embed_lazy_set_last");
     }
     return 0;
+}
+extern "C" int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D, cdc_adam_hp hp,
+                                    const int32_t* step_dev, int32_t step_bias, int32_t period, int32_t own_mod, int32_t own_rem,
+                                    void* stream) {
+    return lazy_flush_launch(w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, 0, stream);
+}
+extern "C" int cdc_embed_lazy_flush_bg(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D, cdc_adam_hp hp,
+                                       const int32_t* step_dev, int32_t step_bias, int32_t period, int32_t own_mod, int32_t own_rem,
+                                       int32_t waves_per_simd, void* stream) {
+    return lazy_flush_launch(w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, waves_per_simd, stream);
 }
 
 

@@ -444,6 +444,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // =================================================================================================
 template <bool BF16, int BM, int BN, int DEPTH>
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_args a) {
+    CDC_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int g = find_group<false>(a.n_groups, tile, [&](int l) { return ((a.g[l].M + BM - 1) / BM) * ((a.g[l].N + BN - 1) / BN); },
@@ -565,6 +566,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_fwd(const cdc_lin_fwd_
 // =================================================================================================
 template <bool BF16, int BM, int BN, bool WT, int DEPTH>
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bwdx_args a) {
+    CDC_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int o = find_group<false>(a.n_out, tile, [&](int l) { return ((a.o[l].M + BM - 1) / BM) * ((a.o[l].K + BN - 1) / BN); },
@@ -686,6 +688,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_x(const cdc_lin_bw
 // =================================================================================================
 template <bool BF16, int BM, int BN>
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bwdw_args a, int64_t slab_stride) {
+    CDC_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = a.split_k > 1 ? a.split_k : 1;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -762,6 +765,7 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
 }
 
 __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a, int64_t slab_stride, int64_t total) {
+    CDC_PRIO_MAIN();
     // one flat index space over all groups: a slab IS the concatenation [dW_0 | db_0 | dW_1 | db_1 | ...]
     __shared__ int64_t first[CDC_MAX_GROUPS + 1];                      // first flat index of every group (scan by wave 0)
     if (threadIdx.x < 64) {
@@ -875,6 +879,7 @@ __device__ __forceinline__ bf16x8_t tr_fragment(const __bf16* tile, int row_base
 }
 
 __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w_tr(const cdc_lin_bwdw_args a, int64_t slab_stride) {
+    CDC_PRIO_MAIN();
     __shared__ __attribute__((aligned(16))) __bf16 As[TR_BK * TR_STRIDE];
     __shared__ __attribute__((aligned(16))) __bf16 Bs[TR_BK * TR_STRIDE];
     const int S = a.split_k > 1 ? a.split_k : 1;

@@ -62,6 +62,7 @@ template <int N> __device__ __forceinline__ void g2_wait_vmcnt() { asm volatile(
 
 template <int BM, int BN, int NSTAGE>
 __global__ void __launch_bounds__(G2_THREADS, (G2Cfg<BM, BN, NSTAGE>::BLOCKS_PER_CU)) k_g2_nt(const cdc_g2_args a) {
+    CDC_PRIO_MAIN();
     typedef G2Cfg<BM, BN, NSTAGE> Cfg;
     constexpr int G2_BM = BM;                                        // (the epilogue below predates the BM template parameter)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -516,6 +517,7 @@ __device__ __forceinline__ bf16x8_t g2_tr_fragment(const unsigned char* tile, in
 
 template <int BMO, int BNO, int NSTAGE>
 __global__ void __launch_bounds__(G2_THREADS, 2) k_g2_tn(const cdc_lin_bwdw_args a, int64_t slab_stride) {
+    CDC_PRIO_MAIN();
     typedef G2Tn<BMO> TA;
     typedef G2Tn<BNO> TB;
     constexpr int STAGE = TA::BYTES + TB::BYTES;

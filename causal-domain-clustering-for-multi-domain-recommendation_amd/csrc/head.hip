@@ -37,6 +37,7 @@ __device__ __forceinline__ float head_dot(const float* __restrict__ x, const flo
 
 #define HEAD_TJ 1            /* a lane's share of a tower row up to K = 64 */
 __global__ void __launch_bounds__(HEAD_THREADS) k_head_fwd(const cdc_head_args a) {
+    CDC_PRIO_MAIN();
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * HEAD_WAVES + (threadIdx.x >> 6);
     if (r >= a.M) return;
@@ -131,6 +132,7 @@ __device__ __forceinline__ int head_section(const cdc_head_args& a, int t) {    
 
 #define HEAD_BWD_WAVES 8
 __global__ void __launch_bounds__(HEAD_BWD_WAVES * 64) k_head_bwd(const cdc_head_args a, int width) {
+    CDC_PRIO_MAIN();
     extern __shared__ float head_sh[];                                   // [HEAD_BWD_WAVES][width]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int part = blockIdx.x;
@@ -288,6 +290,7 @@ __global__ void __launch_bounds__(HEAD_BWD_WAVES * 64) k_head_bwd(const cdc_head
 // one wave per output element: lane l adds parts l, l+64, ... in ascending order, a butterfly adds the 64 lane sums; the last
 // block's first wave adds the loss partials
 __global__ void __launch_bounds__(HEAD_THREADS) k_head_bwd_final(const cdc_head_args a, int width) {
+    CDC_PRIO_MAIN();
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * HEAD_WAVES + (threadIdx.x >> 6);
     if (k == width) {

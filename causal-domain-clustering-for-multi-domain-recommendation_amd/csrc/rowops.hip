@@ -11,6 +11,7 @@
 // gate softmax + pooling   (model/ple.py:89-94,105-123 ; model/mmoe.py:37-40,58-60)
 // =================================================================================================
 __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_fwd(const cdc_pool_fwd_args a) {
+    CDC_PRIO_MAIN();
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= a.B) return;
@@ -68,6 +69,7 @@ static bool pool_vec_ok(int H, const void* experts, int64_t ld_exp) {
     return H % 4 == 0 && gl >= 1 && gl <= 64 && (gl & (gl - 1)) == 0 && (((uintptr_t)experts & 15) == 0) && ld_exp % 4 == 0;
 }
 __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_fwd_v4(const cdc_pool_fwd_args a) {
+    CDC_PRIO_MAIN();
     const int lane = threadIdx.x & 63;
     const int gl = a.H / 4, l = lane % gl;
     const int64_t row = ((int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * (64 / gl) + lane / gl;
@@ -137,6 +139,7 @@ extern "C" int cdc_gate_pool_fwd(const cdc_pool_fwd_args* a, void* stream) {
 }
 
 __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd(const cdc_pool_bwd_args a) {
+    CDC_PRIO_MAIN();
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= a.B) return;
@@ -198,6 +201,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd(const cdc_pool_bw
 // 16-byte-lane form of the backward (see k_gate_pool_fwd_v4): H/4 lanes per row, sub-wave xor reductions for the gate
 // gradients, float4 expert-gradient accumulators in LDS ([expert][lane] per wave).
 __global__ void __launch_bounds__(ROW_THREADS) k_gate_pool_bwd_v4(const cdc_pool_bwd_args a) {
+    CDC_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gl = a.H / 4, l = lane % gl;
@@ -537,6 +541,7 @@ __device__ __forceinline__ void bn_sum_partials_v(const double* __restrict__ ws,
 
 template <int LS>
 __global__ void __launch_bounds__(ROW_THREADS) k_bn_stats_v4(const cdc_bn_fwd_args a, int n_chunks, int total_c) {
+    CDC_PRIO_MAIN();
     using G = BnGeo<LS>;
     BnTile t;
     if (!bn_locate_v<LS>(a, n_chunks, t)) return;
@@ -565,6 +570,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_stats_v4(const cdc_bn_fwd_ar
 
 template <int LS>
 __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply_v4(const cdc_bn_fwd_args a, int n_chunks, int total_c) {
+    CDC_PRIO_MAIN();
     using G = BnGeo<LS>;
     BnTile t;
     if (!bn_locate_v<LS>(a, n_chunks, t)) return;
@@ -661,6 +667,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_apply_v4(const cdc_bn_fwd_ar
 
 template <int LS>
 __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_stats_v4(const cdc_bn_bwd_args a, int n_chunks, int total_c) {
+    CDC_PRIO_MAIN();
     using G = BnGeo<LS>;
     BnTile t;
     if (!bn_locate_v<LS>(a, n_chunks, t)) return;
@@ -702,6 +709,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_stats_v4(const cdc_bn_bw
 
 template <int LS>
 __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply_v4(const cdc_bn_bwd_args a, int n_chunks, int total_c) {
+    CDC_PRIO_MAIN();
     using G = BnGeo<LS>;
     BnTile t;
     if (!bn_locate_v<LS>(a, n_chunks, t)) return;
@@ -1031,6 +1039,7 @@ extern "C" int cdc_bn_bwd(const cdc_bn_bwd_args* a, void* stream) {
 // row dot products (+addends, +sigmoid)  (model/layer.py:122-126, :193 + :50-55, dcn.py:42)
 // =================================================================================================
 __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_fwd(const cdc_rowdot_fwd_args a) {
+    CDC_PRIO_MAIN();
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.y;
     const cdc_rowdot_group& G = a.g[g];
@@ -1067,6 +1076,7 @@ extern "C" int cdc_rowdot_fwd(const cdc_rowdot_fwd_args* a, void* stream) {
 // backward: rows are split into CDC_ROWDOT_PARTS contiguous parts; each part's block writes its partial
 // (dw[K], dbias) to the workspace; a second launch adds the parts in order.
 __global__ void __launch_bounds__(ROW_THREADS) k_rowdot_bwd(const cdc_rowdot_bwd_args a, int kmax) {
+    CDC_PRIO_MAIN();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = blockIdx.y, part = blockIdx.x;
     const cdc_rowdot_bgroup& G = a.g[g];

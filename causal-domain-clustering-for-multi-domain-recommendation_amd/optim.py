@@ -159,16 +159,23 @@ class FusedAdam:
                  (ids.data_ptr(), offsets.data_ptr(), idx.data_ptr(), None if err is None else err.data_ptr(), B, F,
                   self.table.shape[0]), self._stream())
 
-    def flush_slice(self):
+    def flush_slice(self, background_waves=0):
         """lazy mode, once per step AFTER the catch-up of the step's rows: replays slice (t-1 mod flush_every) of the table
-        up to step t-1.  Rows of the current batch are already at t-1 and are skipped."""
+        up to step t-1.  Rows of the current batch are already at t-1 and are skipped.  background_waves > 0: the capped,
+        lowest-priority form of the launch (cdc_embed_lazy_flush_bg) for a second stream beside the forward/backward."""
         if self.table_mode != "lazy" or self.flush_every <= 1:
+            return
+        nb = 24.0 * self.table.numel() / self.flush_every / max(self.own_mod, 1)
+        if background_waves > 0:
+            L.launch("cdc_embed_lazy_flush(slice)", self.lib.cdc_embed_lazy_flush_bg,
+                     (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
+                      self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every,
+                      self.own_mod, self.own_rem, int(background_waves)), self._stream(), nbytes=nb)
             return
         L.launch("cdc_embed_lazy_flush(slice)", self.lib.cdc_embed_lazy_flush,
                  (self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(),
                   self.table.shape[0], self.table.shape[1], self._hp(), self.step_dev.data_ptr(), -1, self.flush_every,
-                  self.own_mod, self.own_rem), self._stream(),
-                 nbytes=24.0 * self.table.numel() / self.flush_every / max(self.own_mod, 1))
+                  self.own_mod, self.own_rem), self._stream(), nbytes=nb)
 
     def table_catchup_rows(self, idx, B, F, D, tag="", runs=0, flush=True):
         """lazy mode, BEFORE the gather of this step, on already computed row indices [B,F] (the gathered batch under DP).

@@ -229,29 +229,25 @@ class TrainStep:
             for fn in self._fwd_after_gather:
                 fn(st)
         elif opt.table_mode == "lazy" and self._overlap():
-            # Two branches (two HIP streams; two branches of the hipGraph when captured):
-            #   main:  sort, catch-up | gather, forward, BCE, backward (gradient-input chain) | grad-weight launches, dense Adam | reg
-            #   side:                 | this step's slice of the whole-table replay           | per-row sums, Adam on the step's rows
-            # The replay slice is VALU-bound and touches no row of the batch (those are at step t-1 after the catch-up and are
-            # skipped), so it runs under the forward/backward, whose kernels wait on L2/LDS; the table update needs the replay
-            # finished (same stream) and dE (event), and runs beside the grad-weight contractions nothing else depends on.
+            # Two chains on two hardware queues (two HIP streams; two branches of the hipGraph when captured):
+            #   main:  sort, catch-up | gather, forward, BCE, backward, grad-weight launches, dense Adam | per-row sums + Adam on the
+            #   side:                 | this step's slice of the whole-table replay                      |   step's rows, reg
+            # The replay slice is VALU-only and touches no row of the batch (those are at step t-1 after the catch-up and are
+            # skipped); it goes out in its background form (a capped grid of two waves per SIMD at the lowest issue priority,
+            # cdc_embed_lazy_flush_bg) and the chain's kernels raise their priority (CDC_PRIO_MAIN), so the slice takes the issue
+            # cycles the chain leaves idle while it waits on L2 / LDS / MFMA results.  The table update needs the slice finished:
+            # it goes last on the main chain, behind the one join.
             main, side = torch.cuda.current_stream(), self._side_stream()
             opt.begin_step_catchup(emb.ids, emb.offsets, B, F, D, flush=False)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                opt.flush_slice()
+                opt.flush_slice(background_waves=self._overlap_waves)
             plan.forward()
             self._bce()
-            st = C.c_void_p(main.cuda_stream)
-            for fn in self._bwd_early:
-                fn(st)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
-            for fn in plan.deferred_dw_steps:
-                fn(st)
+            plan.backward()
             opt.dense_step(plan.param_grads, plan._param_refs)
             main.wait_stream(side)
+            opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
             self._reg()
             return
         elif opt.table_mode == "lazy":
@@ -267,14 +263,13 @@ class TrainStep:
         self._reg()
 
     def _overlap(self):
-        """CDC_OVERLAP=1 runs the step as two branches (below).  Off by default — measured at C2 (profiles/round2/README.md): the
-        branches do run side by side (kernel trace: two queues), but the replay slice's 4096 workgroups take every wave slot and the
-        forward's first launches wait behind them (0.622 vs 0.603 ms/step); capped at 512 workgroups the slice leaves room but needs
-        140 us instead of 108 (it is VALU-bound and wants the waves), of which the forward/backward hides 38 (0.613 ms/step)."""
+        """The replay slice of the lazy table on a second stream beside the forward/backward (single GPU).  CDC_OVERLAP=0 puts it
+        back on the main chain, CDC_OVERLAP_WAVES sets the slice's waves per SIMD.  Measured at C2 (profiles/round3/README.md):
+        serial 0.550 ms/step; side by side with the full grid 0.596 (round 2: its 4096 workgroups take every wave slot); capped at
+        two waves per SIMD, lowest priority, table update behind a single join: 0.515."""
         if getattr(self, "_overlap_ok", None) is None:
-            self._overlap_ok = os.environ.get("CDC_OVERLAP", "0") == "1"
-            late = set(id(s_) for s_ in self.plan.deferred_dw_steps)
-            self._bwd_early = [s_ for s_ in self.plan.bwd_steps if id(s_) not in late]
+            self._overlap_ok = os.environ.get("CDC_OVERLAP", "1") != "0"
+            self._overlap_waves = int(os.environ.get("CDC_OVERLAP_WAVES", "2"))
         return self._overlap_ok
 
     def _side_stream(self):

@@ -176,11 +176,18 @@ int cdc_embed_segsum_lazy_update(const float* d_out, const int32_t* seg_start, c
  * period <= 1: all R rows.  period > 1: only slice (target mod period) of the table (ceil(R/period) consecutive rows), so
  * that calling it every step brings every row up to date once per `period` steps — this bounds the gaps the per-batch
  * catch-up sees, spreads the replay work evenly over the steps, and the slice is chosen on the device (graph-replay safe).
- * The slice launch touches no row whose last >= target (the step's own rows after their catch-up).  Measured: running it
- * on a second stream beside the forward/backward gains nothing — both sides are bound by VALU issue. */
+ * The slice launch touches no row whose last >= target (the step's own rows after their catch-up). */
 int cdc_embed_lazy_flush(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D,
                          cdc_adam_hp hp, const int32_t* step_dev, int32_t step_bias, int32_t period,
-                         int32_t own_mod, int32_t own_rem, void* stream);   /* own_mod > 1: only rows r with r % own_mod == own_rem */
+                         int32_t own_mod, int32_t own_rem, void* stream);
+/* The same as a BACKGROUND launch: the grid is capped at waves_per_simd workgroups of 256 threads per compute unit (a
+ * grid-stride loop covers the slice), its waves keep the lowest issue priority and the loads of the next item are in flight
+ * under the replay of the current one.  Issued on a second stream beside the forward/backward (whose kernels raise their
+ * priority) the VALU-only replay takes the issue cycles those leave idle instead of every wave slot of the chip
+ * (profiles/round3/README.md: 2 waves per SIMD measured best).  waves_per_simd <= 0: the full grid of cdc_embed_lazy_flush. */
+int cdc_embed_lazy_flush_bg(float* w, float* m, float* v, int32_t* last, int64_t R, int32_t D,
+                            cdc_adam_hp hp, const int32_t* step_dev, int32_t step_bias, int32_t period,
+                            int32_t own_mod, int32_t own_rem, int32_t waves_per_simd, void* stream);   /* own_mod > 1: only rows r with r % own_mod == own_rem */
 
 /* Row-sharded table under data parallelism (no counterpart in the reference, which is single-process): row r belongs to
  * rank r % n_rank.  Every kernel that walks unique-row lists skips entries < 0, so an owner can treat the row lists it

@@ -12,6 +12,8 @@ Sides (each trains from the same state on the same batches in the same order, th
                  weight_decay 1e-8) on every parameter).  Only where /root/reference is mounted (the build container).
     ref_rev      the same with the rows of every batch reversed: identical mathematics, other summation order — the
                  reference's own reproducibility floor at this scale.
+    ref_perm<k>  the same with the rows of every batch in a seeded random order (k = 1, 2, ...): further samples of that
+                 floor, so that the band the HIP sides are held to is a distribution and not one pair.
     oracle       oracle/cdc_oracle.py (the CPU restatement) with the same loop.
     hip_f32 / hip_bf16   the HIP path (TrainStep, lazy table, hipGraph) with exact-fp32 / bf16 contractions.  Needs a GPU.
 
@@ -49,6 +51,7 @@ def parse():
     ap.add_argument("--summarise", action="store_true")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--id-dist", default="uniform")
+    ap.add_argument("--teacher-std", type=float, default=0.3)
     return ap.parse_args()
 
 
@@ -56,7 +59,8 @@ def dataset(args):
     from cdcmdr_amd.synth import make_dataset
     fd = [args.vocab] * F
     n = B * args.steps + args.eval_rows
-    X, y = make_dataset(n, fd, n_domain=N_DOMAIN, domain_idx=DOMAIN_IDX, seed=2000, dist=args.id_dist)
+    X, y = make_dataset(n, fd, n_domain=N_DOMAIN, domain_idx=DOMAIN_IDX, seed=2000, dist=args.id_dist,
+                        teacher_std=float(getattr(args, "teacher_std", 0.3)))
     ntr = B * args.steps
     g = X[:, DOMAIN_IDX].astype(np.int64)
     return fd, (X[:ntr], y[:ntr], g[:ntr]), (X[ntr:], y[ntr:], g[ntr:])
@@ -76,7 +80,7 @@ def initial_state(fd):
     return model, sd, h.hexdigest()[:16]
 
 
-def side_ref(args, fd, sd0, train, ev, reverse):
+def side_ref(args, fd, sd0, train, ev, reverse, perm_seed=None):
     import tempfile
     import torch
     if not os.path.isdir(REF):
@@ -99,6 +103,9 @@ def side_ref(args, fd, sd0, train, ev, reverse):
         xs, ys, gs = Xtr[sl], ytr[sl], gtr[sl]
         if reverse:
             xs, ys, gs = xs[::-1].copy(), ys[::-1].copy(), gs[::-1].copy()
+        if perm_seed is not None:                                            # same rows, another order inside the batch
+            pi = np.random.Generator(np.random.PCG64(1_000_003 * perm_seed + s)).permutation(B)
+            xs, ys, gs = xs[pi].copy(), ys[pi].copy(), gs[pi].copy()
         X = torch.from_numpy(xs)
         y = torch.from_numpy(ys).reshape(-1, 1)
         group = torch.from_numpy(gs).reshape(-1, 1)
@@ -186,7 +193,8 @@ def summarise(args, ev, init_hash=None):
                       "steps": args.steps, "eval_rows": int(len(yev)), "dropout": 0.0, "id_dist": args.id_dist},
            "sides": {}}
     preds = {}
-    for name in ("ref", "ref_rev", "oracle", "hip_f32", "hip_bf16"):
+    names = ["ref", "ref_rev"] + sorted(f[:-4] for f in os.listdir(args.out) if f.startswith("ref_perm") and f.endswith(".npy"))
+    for name in names + ["oracle", "hip_f32", "hip_bf16"]:
         path = os.path.join(args.out, name + ".npy")
         if os.path.exists(path):
             preds[name] = np.load(path)
@@ -206,6 +214,17 @@ def summarise(args, ev, init_hash=None):
                 res["sides"][name]["max_abs_pred_diff_vs_" + base] = float(np.abs(preds[name] - preds[base]).max())
         if "ref_rev" in preds and base == "ref":
             res["cpu_vs_cpu_floor"] = abs(res["sides"]["ref_rev"]["auc"] - res["sides"]["ref"]["auc"])
+        reorder = [n for n in preds if n == "ref" or n.startswith("ref_")]
+        if len(reorder) >= 3:
+            # the reference against itself under row reorderings of every batch: the distribution the band comes from
+            aucs = np.array([res["sides"][n]["auc"] for n in reorder])
+            lls = np.array([res["sides"][n]["logloss"] for n in reorder])
+            dom = np.array([res["sides"][n]["domain_auc"] for n in reorder])
+            res["ref_reorderings"] = {"sides": reorder, "auc_mean": float(aucs.mean()), "auc_max_dev": float(np.abs(aucs - aucs.mean()).max()),
+                                      "auc_std": float(aucs.std(ddof=1)), "logloss_mean": float(lls.mean()),
+                                      "logloss_max_dev": float(np.abs(lls - lls.mean()).max()),
+                                      "domain_auc_mean": dom.mean(0).tolist(),
+                                      "domain_auc_max_dev": np.abs(dom - dom.mean(0)).max(0).tolist()}
     path = os.path.join(args.out, "summary.json")
     json.dump(res, open(path, "w"), indent=1)
     print(json.dumps(res, indent=1))
@@ -233,6 +252,8 @@ def main():
             p = side_ref(args, fd, sd0, train, ev, reverse=False)
         elif side == "ref_rev":
             p = side_ref(args, fd, sd0, train, ev, reverse=True)
+        elif side.startswith("ref_perm"):
+            p = side_ref(args, fd, sd0, train, ev, reverse=False, perm_seed=int(side[len("ref_perm"):]))
         elif side == "oracle":
             p = side_oracle(args, fd, sd0, train, ev)
         elif side in ("hip_f32", "hip_bf16"):
