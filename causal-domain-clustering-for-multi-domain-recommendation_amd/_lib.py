@@ -135,6 +135,52 @@ class PoolBwdArgs(C.Structure):
                 ("mask_scale", c_f), ("accumulate", c_i32), ("d_experts_h", c_p), ("ld_dexp_h", c_i64), ("gate", PoolBwdGate * MAX_GATES)]
 
 
+MID_MAX_EXPERT, MID_MAX_GATE = 16, 8
+
+
+class MidGate1(C.Structure):
+    _fields_ = [("logits", c_p), ("ld_logits", c_i64), ("probs", c_p), ("pooled_h", c_p), ("ld_pooled_h", c_i64),
+                ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL), ("pad_", c_i32)]
+
+
+class MidExpert2(C.Structure):
+    _fields_ = [("w", c_p), ("ldw", c_i64), ("bias", c_p), ("src", c_i32), ("stream_id", c_i32)]
+
+
+class MidGate2(C.Structure):
+    _fields_ = [("w", c_p), ("ldw", c_i64), ("bias", c_p), ("probs", c_p), ("out", c_p), ("ld_out", c_i64),
+                ("out_h", c_p), ("ld_out_h", c_i64), ("src", c_i32), ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL)]
+
+
+class CgcMidFwdArgs(C.Structure):
+    _fields_ = [("B", c_i64), ("H1", c_i32), ("H2", c_i32), ("n_exp1", c_i32), ("n_gate1", c_i32), ("n_exp2", c_i32), ("n_gate2", c_i32),
+                ("ex1", c_p), ("ld_ex1", c_i64), ("ex2", c_p), ("ld_ex2", c_i64), ("relu", c_i32), ("drop_p", c_f),
+                ("seed", C.c_uint64), ("seed_offset_dev", c_p),
+                ("g1", MidGate1 * MID_MAX_GATE), ("e2", MidExpert2 * MID_MAX_EXPERT), ("g2", MidGate2 * MID_MAX_GATE)]
+
+
+class MidBGate1(C.Structure):
+    _fields_ = [("probs", c_p), ("d_logits", c_p), ("ld_dlogits", c_i64), ("d_logits_h", c_p), ("ld_dlogits_h", c_i64),
+                ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL), ("pad_", c_i32)]
+
+
+class MidBExpert2(C.Structure):
+    _fields_ = [("wt", c_p), ("ldwt", c_i64), ("src", c_i32), ("pad_", c_i32)]
+
+
+class MidBGate2(C.Structure):
+    _fields_ = [("d_out", c_p), ("ld_dout", c_i64), ("probs", c_p), ("d_logits", c_p), ("ld_dlogits", c_i64),
+                ("d_logits_h", c_p), ("ld_dlogits_h", c_i64), ("wt", c_p), ("ldwt", c_i64), ("src", c_i32), ("n_sel", c_i32),
+                ("sel", c_i32 * MAX_SEL)]
+
+
+class CgcMidBwdArgs(C.Structure):
+    _fields_ = [("B", c_i64), ("H1", c_i32), ("H2", c_i32), ("n_exp1", c_i32), ("n_gate1", c_i32), ("n_exp2", c_i32), ("n_gate2", c_i32),
+                ("ex1", c_p), ("ld_ex1", c_i64), ("ex2", c_p), ("ld_ex2", c_i64), ("dz1_h", c_p), ("ld_dz1_h", c_i64),
+                ("dz2_h", c_p), ("ld_dz2_h", c_i64), ("mask1", c_i32), ("mask2", c_i32), ("scale1", c_f), ("scale2", c_f),
+                ("g1", MidBGate1 * MID_MAX_GATE), ("e2", MidBExpert2 * MID_MAX_EXPERT), ("g2", MidBGate2 * MID_MAX_GATE)]
+
+
 BN_X_BF16, BN_Y_BF16, BN_DY_BF16 = 1, 2, 4
 
 
@@ -282,6 +328,8 @@ _SIGNATURES = {
     "cdc_shadow_bf16": (c_i32, [C.POINTER(ShadowArgs), c_p]),
     "cdc_glinear_bwd_w": (c_i32, [C.POINTER(LinBwdwArgs), c_i32, c_p]),
     "cdc_gate_pool_fwd": (c_i32, [C.POINTER(PoolFwdArgs), c_p]),
+    "cdc_cgc_mid_fwd": (c_i32, [C.POINTER(CgcMidFwdArgs), c_p]),
+    "cdc_cgc_mid_bwd": (c_i32, [C.POINTER(CgcMidBwdArgs), c_p]),
     "cdc_gate_pool_bwd": (c_i32, [C.POINTER(PoolBwdArgs), c_p]),
     "cdc_bn_fwd": (c_i32, [C.POINTER(BnFwdArgs), c_p]),
     "cdc_bn_bwd": (c_i32, [C.POINTER(BnBwdArgs), c_p]),
@@ -390,11 +438,16 @@ def check(rc, what):
 # optional per-launch timing (bench.py / tools): HIP events on the launch stream around every C-ABI call
 # ---------------------------------------------------------------------------------------------------------
 PROFILE = None      # None, or a list receiving (name, start_event, end_event, flops, bytes)
+TRACE = os.environ.get("CDC_TRACE_LAUNCH") == "1"      # development aid: every launch's name on stderr before it is issued
 
 
 def launch(name, fn, args, stream, flops=0.0, nbytes=0.0):
     """Calls fn(*args, stream); with PROFILE set, brackets it with timing events recorded on the current stream
     (the one every launch of this package goes to)."""
+    if TRACE:
+        import sys
+        sys.stderr.write(f"[cdc launch] {name}\n")
+        sys.stderr.flush()
     if PROFILE is None:
         rc = fn(*args, stream)
     else:

@@ -1,0 +1,654 @@
+// cgc.hip — the boundary between two extraction levels of PLE as one launch per direction (include/cdcmdr.h: cdc_cgc_mid_*).
+//
+// Reference: CGC.forward called level after level (model/ple.py:54-57,96-125): level k's softmax gates pool its experts, the
+// pooled vectors are the inputs of level k+1's experts (one nn.Linear + ReLU + dropout each, model/layer.py:185-191) and gates
+// (model/ple.py:89-94), whose outputs are pooled again.  Unfused that is pool -> grouped contraction -> pool: three launches
+// whose intermediates ([B, n_gate*H1] pooled vectors, [B, n_exp*H2] expert tiles) make a round trip through memory between
+// latency-bound launches.  Here a workgroup owns 16 batch rows and walks the whole boundary: the pooled vectors are formed once
+// into LDS as bf16 (the MFMA A operand — the same rounding the shadow gets), the level-k+1 experts are 16 x 16 MFMA tiles whose
+// B fragments come straight from the L2-resident bf16 weights, and the second pooling reads the tiles out of LDS.  The
+// backward runs the same chain in reverse (pool backward -> grad-input contraction -> pool backward) and writes only what the
+// grad-weight launches and the next grad-input launch read: bf16 dZ of both expert levels and the gate-logit gradients.
+//
+// Shape of the kernels (what three slower versions taught, profiles/round3/README.md):
+//   * 1024 threads per workgroup: in the row-wise phases wave w IS batch row w (lane = column: two columns of H1 = 128, one of
+//     H2 = 64), in the MFMA phases wave w takes tiles w, w+16, ...  A 256-thread version ran one wave per SIMD and every LDS /
+//     DPP / scalar-load latency of its dependent chains lay bare (30 / 47 us); four waves per SIMD cover each other.
+//   * nothing is unrolled over (gate, expert): a fully unrolled version was 50-85 KB of straight-line code that is executed
+//     once per workgroup, i.e. fetched cold.  Loops are rolled; what they index with run-time values sits in LDS, put there by
+//     direct-to-LDS loads issued at kernel entry (no registers, so the issuing loop is rolled as well).
+//   * every global load that depends on nothing is issued at entry (expert rows, B fragments + bias of the wave's tiles); no
+//     load sits between a value's first use and the previous barrier.
+//   * the argument block is read through the kernarg segment pointer (indexing the by-value struct with run-time values makes
+//     the compiler keep a private copy of all 2.5 KB of it in scratch), and descriptor fields are copied to locals before the
+//     loops that use them: reads through that pointer are not treated as invariant across stores.
+#include "common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+#define MID_BM 16
+#define MID_THREADS 1024
+#define MID_WAVES (MID_THREADS / 64)
+#define MID_G CDC_MID_MAX_GATE
+#define MID_E CDC_MID_MAX_EXPERT
+#define MID_KARG __attribute__((address_space(4)))   /* the kernarg segment: constant address space */
+#define MID_JPW 3                       /* forward: MFMA tiles per wave whose B fragments are fetched at kernel entry */
+#define MID_JPW2 2                      /* backward: the same for the grad-input tiles */
+#define MID_XCH 8                       /* backward: experts whose rows a lane holds in registers at once */
+#define MID_MAXSTEP 6                   /* K steps of 32 per grad-input tile: 2 per expert reading the source + 1 per gate */
+
+template <int H1, int H2>
+struct MidCfg {
+    static constexpr int PH_LD = H1 + 8;                            // bf16 row stride of the pooled level-k vectors in LDS
+    static constexpr int E2_LD = H2 + 4;                            // fp32 row stride of the level-k+1 expert tiles
+    static constexpr int DZ_LD = H2 + 8;                            // bf16 row stride of dZ (level k+1) in LDS
+    static constexpr int DP_LD = H1 + 4;                            // fp32 row stride of d(pooled level-k) in LDS
+    static constexpr int DL_LD = 32 + 8;                            // bf16 row stride of the gate-logit gradients (one K step of 32)
+    static constexpr int NT1 = H1 / 16, NT2 = H2 / 16;
+    static_assert(H1 == 128 && H2 == 64, "lane = column mapping: two columns of H1, one of H2");
+};
+
+__device__ __forceinline__ void mid_glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void mid_glds4(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+// sum over the 64 lanes of a wave, result in every lane: four cross-lane adds in the VALU inside each DPP row of 16 (quad_perm
+// [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then two ds_bpermute steps across the rows
+__device__ __forceinline__ float mid_wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// sel lists and position tables in LDS: sel[g][j] (bytes) and pos[g][e] = index of expert e in gate g's ascending sel list or -1
+template <typename GatePtr>
+__device__ __forceinline__ void mid_fill_tables(signed char (*pos)[MID_E], unsigned char (*sel)[CDC_MAX_SEL], GatePtr gates, int n_gate, int tid) {
+    if (tid < MID_G * MID_E) {
+        const int g = tid / MID_E, e = tid % MID_E;                  // (MID_E == CDC_MAX_SEL: the same thread fills sel[g][e])
+        int p = -1, sv = 0;
+        if (g < n_gate) {
+            const int ns = gates[g].n_sel;
+            for (int j = 0; j < ns; ++j)
+                if (gates[g].sel[j] == e) p = j;
+            if (e < ns) sv = gates[g].sel[e];
+        }
+        pos[g][e] = (signed char)p;
+        sel[g][e] = (unsigned char)sv;
+    }
+}
+static_assert(MID_E == CDC_MAX_SEL, "mid_fill_tables fills both tables with one index");
+
+// softmax over n_sel <= 16 values exactly as cdc_gate_pool_fwd computes it (max-subtract, expf, sum in index order, one divide)
+__device__ __forceinline__ void mid_softmax(float (&p)[CDC_MAX_SEL], int n_sel) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < CDC_MAX_SEL; ++j) {
+        if (j >= n_sel) p[j] = -INFINITY;
+        mx = fmaxf(mx, p[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < CDC_MAX_SEL; ++j) {
+        p[j] = j < n_sel ? expf(p[j] - mx) : 0.f;
+        sum += p[j];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] *= inv;
+}
+
+// =====================================================================================================================
+// forward
+// =====================================================================================================================
+template <int H1, int H2>
+__global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_cgc_mid_fwd(const cdc_cgc_mid_fwd_args a_by_value) {
+    CDC_PRIO_MAIN();
+    (void)a_by_value;
+    const MID_KARG cdc_cgc_mid_fwd_args& a = *(const MID_KARG cdc_cgc_mid_fwd_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef MidCfg<H1, H2> Cfg;
+    constexpr int KS = H1 / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ signed char pos1[MID_G][MID_E], pos2[MID_G][MID_E];
+    __shared__ unsigned char sel1[MID_G][CDC_MAX_SEL], sel2[MID_G][CDC_MAX_SEL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // uniform: descriptor reads indexed by it are scalar loads
+    const int64_t row0 = (int64_t)blockIdx.x * MID_BM;
+    const int64_t B = a.B;
+    const int ng1 = a.n_gate1, ng2 = a.n_gate2, ne1 = a.n_exp1, ne2 = a.n_exp2;
+    // LDS: p1 [16][ng1][16] f32 | p2 [16][ng2][16] f32 | pooled [ng1][16][PH_LD] bf16 | U = { xs [ne1][16][H1] f32 (phase A) ,
+    //      x2 [ne2][16][E2_LD] f32 (phases B..D) }
+    float* p1 = reinterpret_cast<float*>(smem);
+    float* p2 = p1 + MID_BM * ng1 * 16;
+    __bf16* ph = reinterpret_cast<__bf16*>(p2 + MID_BM * ng2 * 16);
+    float* xs = reinterpret_cast<float*>(ph + (size_t)ng1 * MID_BM * Cfg::PH_LD);
+    float* x2 = xs;
+    const int n_tile_jobs = ne2 * Cfg::NT2, n_jobs = n_tile_jobs + ng2;
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    const int r = wave;                                                // row-wise phases: wave = batch row, lane = column
+    const int64_t row = row0 + r;
+    const bool live = row < B;
+    const int64_t last_row = B - 1;
+
+    // ---- entry: every load that depends on nothing.  (1) the level-k expert rows of the block -> LDS, 1 KiB (two rows of one
+    //      expert) per wave instruction; rows past the batch re-read the last row (their results are never stored)
+    {
+        constexpr int CH_PER_E = MID_BM * H1 * 4 / 1024;
+        const float* ex1 = a.ex1;
+        const int64_t ld_ex1 = a.ld_ex1;
+        for (int k = wave; k < ne1 * CH_PER_E; k += MID_WAVES) {
+            const int e = k / CH_PER_E, rr = (k % CH_PER_E) * (256 / H1) + lane / (H1 / 4);
+            int64_t grow = row0 + rr;
+            grow = grow < B ? grow : last_row;
+            mid_glds16(ex1 + grow * ld_ex1 + (int64_t)e * H1 + (lane % (H1 / 4)) * 4, reinterpret_cast<unsigned char*>(xs) + (size_t)k * 1024);
+        }
+    }
+    // (2) the B fragments (and the bias of the lane's output column) of this wave's tiles: job = wave + 16 * i -> expert tile (e, nt) or gate t
+    auto load_w = [&](bf16x8_t (&w)[KS], float& bias, int i) __attribute__((always_inline)) {
+        const int job = wave + MID_WAVES * i;
+        const bool on = job < n_jobs, is_gate = job >= n_tile_jobs;
+        const int e = (on && !is_gate) ? job / Cfg::NT2 : 0, nt = (on && !is_gate) ? job % Cfg::NT2 : 0;
+        const int t = (on && is_gate) ? job - n_tile_jobs : 0;
+        const __bf16* W = reinterpret_cast<const __bf16*>(is_gate ? a.g2[t].w : a.e2[e].w);
+        const int64_t ldw = is_gate ? a.g2[t].ldw : a.e2[e].ldw;
+        const float* bp = is_gate ? a.g2[t].bias : a.e2[e].bias;
+        const int n_rows = is_gate ? a.g2[t].n_sel : H2;               // weight rows (= output columns) that exist
+        const int wrow = nt * 16 + frow;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            w[ks] = (on && wrow < n_rows) ? *reinterpret_cast<const bf16x8_t*>(W + (int64_t)wrow * ldw + ks * 32 + fk) : (bf16x8_t)(__bf16)0.f;
+        bias = (on && bp && wrow < n_rows) ? bp[wrow] : 0.f;
+    };
+    bf16x8_t wq[MID_JPW][KS];
+    float bq[MID_JPW];
+#pragma unroll
+    for (int i = 0; i < MID_JPW; ++i) load_w(wq[i], bq[i], i);
+    uint32_t seed_base = 0u;                                           // g2_seed32 without its per-call read of the step counter
+    const float drop_p = a.drop_p;
+    const int relu = a.relu;
+    if (drop_p > 0.f) {
+        const uint64_t seed = a.seed;
+        const int32_t* sp = a.seed_offset_dev;
+        seed_base = (uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x9E3779B1U;
+        if (sp) seed_base ^= (uint32_t)(*sp) * 0x85EBCA77U;
+    }
+    mid_fill_tables(pos1, sel1, a.g1, ng1, tid);
+    mid_fill_tables(pos2, sel2, a.g2, ng2, tid);
+    // ---- A1: level-k gate probabilities: lane g of wave r takes (row r, gate g)
+    if (lane < ng1) {
+        const int g = lane;
+        const int ns = a.g1[g].n_sel;
+        const float* lg = a.g1[g].logits + row * a.g1[g].ld_logits;
+        float* pr = a.g1[g].probs + row * ns;
+        float p[CDC_MAX_SEL];
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] = (live && j < ns) ? lg[j] : 0.f;
+        mid_softmax(p, ns);
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) {
+            p1[(r * ng1 + g) * 16 + j] = p[j];
+            if (j < ns && live) pr[j] = p[j];
+        }
+    }
+    __syncthreads();                                                   // (waits for the direct-to-LDS loads as well)
+    // ---- A2: pooled level-k vectors; sel ascending = the summation order of the reference
+    {
+        const int c = lane * 2;
+        for (int g = 0; g < ng1; ++g) {
+            const int ns = a.g1[g].n_sel;
+            __bf16* gp = reinterpret_cast<__bf16*>(a.g1[g].pooled_h);
+            const int64_t ldp = a.g1[g].ld_pooled_h;
+            f32x2_t acc = {0.f, 0.f};
+            for (int j = 0; j < ns; ++j) {
+                const int e = sel1[g][j];
+                acc += p1[(r * ng1 + g) * 16 + j] * *reinterpret_cast<const f32x2_t*>(xs + ((size_t)e * MID_BM + r) * H1 + c);
+            }
+            const bf16x2_t h = {(__bf16)acc[0], (__bf16)acc[1]};
+            *reinterpret_cast<bf16x2_t*>(ph + ((size_t)g * MID_BM + r) * Cfg::PH_LD + c) = h;
+            if (live && gp) *reinterpret_cast<bf16x2_t*>(gp + row * ldp + c) = h;
+        }
+    }
+    __syncthreads();                                                   // pooled vectors complete; xs is dead from here (x2 takes its place)
+    // ---- B: level-k+1 experts (16 x 16 tiles, K = H1) and gate logits
+    {
+        const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+        const uint32_t thr16 = (uint32_t)(drop_p * 65536.f + 0.5f);
+        auto tile = [&](const bf16x8_t (&w)[KS], float bv, int i) __attribute__((always_inline)) {
+            const int job = wave + MID_WAVES * i;
+            if (job >= n_jobs) return;
+            const bool is_gate = job >= n_tile_jobs;
+            const int e = is_gate ? 0 : job / Cfg::NT2, nt = is_gate ? 0 : job % Cfg::NT2;
+            const int t = is_gate ? job - n_tile_jobs : 0;
+            const int src = is_gate ? a.g2[t].src : a.e2[e].src;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(ph + ((size_t)src * MID_BM + frow) * Cfg::PH_LD + ks * 32 + fk);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, w[ks], acc, 0, 0, 0);
+            }
+            const int col = nt * 16 + (lane & 15);
+            if (is_gate) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = (lane >> 4) * 4 + r4;
+                    p2[(rl * ng2 + t) * 16 + col] = acc[r4] + bv;                 // logits; columns >= n_sel are ignored by the softmax
+                }
+            } else {
+                const uint32_t seed32 = g2_hash32(seed_base + (uint32_t)a.e2[e].stream_id * 0xC2B2AE3DU);     // = g2_seed32(seed, step, stream_id)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int rl = (lane >> 4) * 4 + r4;
+                    float x = acc[r4] + bv;
+                    if (relu) x = fmaxf(x, 0.f);
+                    if (drop_p > 0.f) {
+                        const uint32_t h = g2_drop_bits(seed32, (int)(row0 + rl), col >> 1);
+                        const uint32_t bits = (col & 1) ? (h >> 16) : (h & 0xFFFFu);
+                        x = bits < thr16 ? 0.f : x * keep_scale;
+                    }
+                    x2[((size_t)e * MID_BM + rl) * Cfg::E2_LD + col] = x;
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < MID_JPW; ++i) tile(wq[i], bq[i], i);
+        for (int i = MID_JPW; wave + MID_WAVES * i < n_jobs; ++i) {      // more tiles than the entry fetch covers (n_exp2 > 11)
+            load_w(wq[0], bq[0], i);
+            tile(wq[0], bq[0], i);
+        }
+    }
+    __syncthreads();
+    // ---- D1: level-k+1 gate probabilities, in place: lane t of wave r takes (row r, gate t)
+    if (lane < ng2) {
+        const int t = lane;
+        const int ns = a.g2[t].n_sel;
+        float* pr = a.g2[t].probs + row * ns;
+        float p[CDC_MAX_SEL];
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] = j < ns ? p2[(r * ng2 + t) * 16 + j] : 0.f;
+        mid_softmax(p, ns);
+#pragma unroll
+        for (int j = 0; j < CDC_MAX_SEL; ++j) {
+            p2[(r * ng2 + t) * 16 + j] = p[j];
+            if (j < ns && live) pr[j] = p[j];
+        }
+    }
+    __syncthreads();
+    // ---- D2: second pooling out of LDS (lane = column); the expert tiles go to memory for the backward
+    {
+        const int c2 = lane;
+        if (live) {
+            float* ex2 = a.ex2 + row * a.ld_ex2 + c2;
+            for (int e = 0; e < ne2; ++e) ex2[(int64_t)e * H2] = x2[((size_t)e * MID_BM + r) * Cfg::E2_LD + c2];
+        }
+        for (int g = 0; g < ng2; ++g) {
+            const int ns = a.g2[g].n_sel;
+            float* out = a.g2[g].out;
+            __bf16* outh = reinterpret_cast<__bf16*>(a.g2[g].out_h);
+            const int64_t ldo = a.g2[g].ld_out, ldoh = a.g2[g].ld_out_h;
+            float acc = 0.f;
+            for (int j = 0; j < ns; ++j) acc += p2[(r * ng2 + g) * 16 + j] * x2[((size_t)sel2[g][j] * MID_BM + r) * Cfg::E2_LD + c2];
+            if (live) {
+                if (out) out[row * ldo + c2] = acc;
+                if (outh) outh[row * ldoh + c2] = (__bf16)acc;
+            }
+        }
+    }
+}
+
+template <int H1, int H2>
+static size_t mid_fwd_lds(int ng1, int ng2, int ne1, int ne2) {
+    typedef MidCfg<H1, H2> Cfg;
+    const size_t xs = (size_t)ne1 * MID_BM * H1 * 4, x2 = (size_t)ne2 * MID_BM * Cfg::E2_LD * 4;
+    return (size_t)MID_BM * ng1 * 16 * 4 + (size_t)MID_BM * ng2 * 16 * 4 + (size_t)ng1 * MID_BM * Cfg::PH_LD * 2 + (xs > x2 ? xs : x2);
+}
+
+static int mid_check_sel(const int32_t* sel, int n_sel, int n_expert) {
+    if (n_sel <= 0 || n_sel > CDC_MAX_SEL) return 0;
+    for (int j = 0; j < n_sel; ++j) {
+        if (sel[j] < 0 || sel[j] >= n_expert) return 0;
+        if (j && sel[j] <= sel[j - 1]) return 0;
+    }
+    return 1;
+}
+
+extern "C" int cdc_cgc_mid_fwd(const cdc_cgc_mid_fwd_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->B >= 0 && a->ex1 && a->ex2, CDC_E_BADARG, "cgc_mid_fwd: null pointer");
+    CDC_CHECK_ARG(a->H1 == 128 && a->H2 == 64, CDC_E_BADARG, "cgc_mid_fwd: built for expert widths (128, 64), got (%d, %d)", a->H1, a->H2);
+    CDC_CHECK_ARG(a->n_exp1 > 0 && a->n_exp1 <= MID_E && a->n_exp2 > 0 && a->n_exp2 <= MID_E && a->n_gate1 > 0 && a->n_gate1 <= MID_G &&
+                      a->n_gate2 > 0 && a->n_gate2 <= MID_G, CDC_E_BADARG, "cgc_mid_fwd: bad counts");
+    CDC_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f, CDC_E_BADARG, "cgc_mid_fwd: dropout p out of range");
+    CDC_CHECK_ARG((((uintptr_t)a->ex1 | (uintptr_t)a->ex2) & 15) == 0 && a->ld_ex1 % 4 == 0 && a->ld_ex2 % 4 == 0 &&
+                      a->ld_ex1 >= (int64_t)a->n_exp1 * a->H1 && a->ld_ex2 >= (int64_t)a->n_exp2 * a->H2, CDC_E_ALIGN,
+                  "cgc_mid_fwd: expert buffers must be 16-byte aligned and wide enough");
+    for (int g = 0; g < a->n_gate1; ++g) {
+        const cdc_mid_gate1& G = a->g1[g];
+        CDC_CHECK_ARG(G.logits && G.probs && mid_check_sel(G.sel, G.n_sel, a->n_exp1), CDC_E_BADARG, "cgc_mid_fwd: level-k gate %d malformed (sel ascending)", g);
+        CDC_CHECK_ARG(!G.pooled_h || ((((uintptr_t)G.pooled_h) & 15) == 0 && G.ld_pooled_h % 8 == 0 && G.ld_pooled_h >= a->H1), CDC_E_ALIGN,
+                      "cgc_mid_fwd: level-k gate %d: bf16 output must be 16-byte aligned", g);
+    }
+    for (int e = 0; e < a->n_exp2; ++e) {
+        const cdc_mid_expert2& E = a->e2[e];
+        CDC_CHECK_ARG(E.w && E.src >= 0 && E.src < a->n_gate1 && E.ldw >= a->H1, CDC_E_BADARG, "cgc_mid_fwd: expert %d malformed", e);
+        CDC_CHECK_ARG((((uintptr_t)E.w) & 15) == 0 && E.ldw % 8 == 0, CDC_E_ALIGN, "cgc_mid_fwd: expert %d: weight must be 16-byte aligned", e);
+    }
+    for (int g = 0; g < a->n_gate2; ++g) {
+        const cdc_mid_gate2& G = a->g2[g];
+        CDC_CHECK_ARG(G.w && G.probs && (G.out || G.out_h) && G.src >= 0 && G.src < a->n_gate1 && G.ldw >= a->H1 &&
+                          mid_check_sel(G.sel, G.n_sel, a->n_exp2), CDC_E_BADARG, "cgc_mid_fwd: level-k+1 gate %d malformed (sel ascending)", g);
+        CDC_CHECK_ARG((((uintptr_t)G.w) & 15) == 0 && G.ldw % 8 == 0 && (!G.out || ((((uintptr_t)G.out) & 15) == 0 && G.ld_out % 4 == 0)) &&
+                          (!G.out_h || ((((uintptr_t)G.out_h) & 7) == 0 && G.ld_out_h % 4 == 0)), CDC_E_ALIGN,
+                      "cgc_mid_fwd: level-k+1 gate %d: misaligned operand", g);
+    }
+    if (a->B == 0) return 0;
+    const size_t lds = mid_fwd_lds<128, 64>(a->n_gate1, a->n_gate2, a->n_exp1, a->n_exp2);
+    CDC_CHECK_ARG(lds <= 150 * 1024, CDC_E_TOOBIG, "cgc_mid_fwd: %zu bytes of LDS needed", lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_cgc_mid_fwd<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_cgc_mid_fwd<128, 64>), dim3((unsigned)cdc_ceil_div(a->B, MID_BM)), dim3(MID_THREADS), lds, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("cgc_mid_fwd");
+    return 0;
+}
+
+// =====================================================================================================================
+// backward
+// =====================================================================================================================
+struct MidStep { const __bf16* wt; int32_t ldwt; int32_t a_off; int32_t a_ld; int32_t pad_; };
+
+template <int H1, int H2>
+__global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_cgc_mid_bwd(const cdc_cgc_mid_bwd_args a_by_value) {
+    CDC_PRIO_MAIN();
+    (void)a_by_value;
+    const MID_KARG cdc_cgc_mid_bwd_args& a = *(const MID_KARG cdc_cgc_mid_bwd_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef MidCfg<H1, H2> Cfg;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ signed char pos1[MID_G][MID_E], pos2[MID_G][MID_E];
+    __shared__ unsigned char sel1[MID_G][CDC_MAX_SEL], sel2[MID_G][CDC_MAX_SEL];
+    __shared__ MidStep steps[MID_G][MID_MAXSTEP];
+    __shared__ int n_steps[MID_G];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = (int64_t)blockIdx.x * MID_BM;
+    const int64_t B = a.B;
+    const int ng1 = a.n_gate1, ng2 = a.n_gate2, ne1 = a.n_exp1, ne2 = a.n_exp2;
+    // LDS: p1, dp1 [ng1][16][16] f32 | p2, dp2 [ng2][16][16] f32 | V = { dO2 [ng2][16][H2] f32 (phase 1), dP1 [ng1][16][DP_LD] f32
+    //      (phases 2, 3) } | dz2 [ne2][16][DZ_LD] bf16 | dl2 [ng2][16][DL_LD] bf16
+    float* p1 = reinterpret_cast<float*>(smem);
+    float* dp1 = p1 + ng1 * MID_BM * 16;
+    float* p2 = dp1 + ng1 * MID_BM * 16;
+    float* dp2 = p2 + ng2 * MID_BM * 16;
+    float* dP1 = dp2 + ng2 * MID_BM * 16;
+    float* dO2 = dP1;
+    const size_t v_floats = (size_t)ng1 * MID_BM * Cfg::DP_LD > (size_t)ng2 * MID_BM * H2 ? (size_t)ng1 * MID_BM * Cfg::DP_LD : (size_t)ng2 * MID_BM * H2;
+    __bf16* dz2 = reinterpret_cast<__bf16*>(dP1 + v_floats);
+    __bf16* dl2 = dz2 + (size_t)ne2 * MID_BM * Cfg::DZ_LD;
+    const int dl2_off = ne2 * MID_BM * Cfg::DZ_LD;
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    const int r = wave;                                                // row-wise phases: wave = batch row, lane = column
+    const int64_t row = row0 + r;
+    const bool live = row < B;
+    const int64_t last_row = B - 1;
+
+    // ---- entry: direct-to-LDS loads of the gradients of the level-k+1 pooled outputs (1 KiB = four rows per wave instruction)
+    //      and of both levels' probabilities (256 B = four rows of one gate per wave instruction; slots j >= n_sel hold a
+    //      duplicate and are never read); rows past the batch re-read the last row (nothing of theirs is stored)
+    {
+        constexpr int CH = MID_BM * H2 * 4 / 1024;
+        for (int k = wave; k < ng2 * CH; k += MID_WAVES) {
+            const int t = k / CH, rr = (k % CH) * (256 / H2) + lane / (H2 / 4);
+            int64_t grow = row0 + rr;
+            grow = grow < B ? grow : last_row;
+            mid_glds16(a.g2[t].d_out + grow * a.g2[t].ld_dout + (lane % (H2 / 4)) * 4, reinterpret_cast<unsigned char*>(dO2) + (size_t)k * 1024);
+        }
+        for (int k = wave; k < (ng1 + ng2) * 4; k += MID_WAVES) {
+            const bool lvl2 = k >= ng1 * 4;
+            const int g = (lvl2 ? k - ng1 * 4 : k) / 4, rr = (k % 4) * 4 + lane / 16;
+            const int ns = lvl2 ? a.g2[g].n_sel : a.g1[g].n_sel;
+            const float* pr = lvl2 ? a.g2[g].probs : a.g1[g].probs;
+            int64_t grow = row0 + rr;
+            grow = grow < B ? grow : last_row;
+            const int j = (lane & 15) < ns ? (lane & 15) : ns - 1;
+            mid_glds4(pr + grow * ns + j, reinterpret_cast<unsigned char*>(lvl2 ? p2 : p1) + ((size_t)g * MID_BM + (k % 4) * 4) * 64);
+        }
+    }
+    // the expert rows of both pool backwards: one column of level k+1 and two of level k per lane, MID_XCH experts at a time in
+    // registers (all of them when a level has at most MID_XCH experts — then no load of theirs is issued after this point)
+    float x2r[MID_XCH];
+    f32x2_t x1r[MID_XCH];
+    const float* ex2p = a.ex2 + row * a.ld_ex2 + lane;
+    const float* ex1p = a.ex1 + row * a.ld_ex1 + lane * 2;
+    auto load_x2 = [&](int e0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int el = 0; el < MID_XCH; ++el) x2r[el] = (live && e0 + el < ne2) ? ex2p[(int64_t)(e0 + el) * H2] : 0.f;
+    };
+    auto load_x1 = [&](int e0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int el = 0; el < MID_XCH; ++el)
+            x1r[el] = (live && e0 + el < ne1) ? *reinterpret_cast<const f32x2_t*>(ex1p + (int64_t)(e0 + el) * H1) : f32x2_t{0.f, 0.f};
+    };
+    load_x2(0);
+    load_x1(0);
+    // the K steps of every source's grad-input tiles: experts reading it (ascending), then gates — the segment order of the
+    // unfused grad-input launch
+    if (tid < ng1) {
+        const int s = tid;
+        int n = 0;
+        for (int e = 0; e < ne2; ++e)
+            if (a.e2[e].src == s)
+                for (int ks = 0; ks < H2 / 32; ++ks)
+                    if (n < MID_MAXSTEP) steps[s][n++] = MidStep{reinterpret_cast<const __bf16*>(a.e2[e].wt) + ks * 32, (int32_t)a.e2[e].ldwt,
+                                                                 e * MID_BM * Cfg::DZ_LD + ks * 32, Cfg::DZ_LD, 0};
+        for (int t = 0; t < ng2; ++t)
+            if (a.g2[t].src == s && n < MID_MAXSTEP)
+                steps[s][n++] = MidStep{reinterpret_cast<const __bf16*>(a.g2[t].wt), (int32_t)a.g2[t].ldwt, dl2_off + t * MID_BM * Cfg::DL_LD, Cfg::DL_LD, 0};
+        n_steps[s] = n;
+    }
+    mid_fill_tables(pos1, sel1, a.g1, ng1, tid);
+    mid_fill_tables(pos2, sel2, a.g2, ng2, tid);
+    const int mask1 = a.mask1, mask2 = a.mask2;
+    const float scale1 = a.scale1, scale2 = a.scale2;
+    __syncthreads();                                                   // tables, dO2 and the probabilities are in LDS
+    // B fragments of this wave's first grad-input tiles: job = wave + 16 * i -> (source s, column tile nt)
+    const int n_jobs = ng1 * Cfg::NT1;
+    auto load_w = [&](bf16x8_t (&w)[MID_MAXSTEP], int i) __attribute__((always_inline)) {
+        const int job = wave + MID_WAVES * i;
+        const bool on = job < n_jobs;
+        const int s = on ? job / Cfg::NT1 : 0, nt = on ? job % Cfg::NT1 : 0;
+        const int ns = on ? n_steps[s] : 0;
+        const int wrow = nt * 16 + frow;
+#pragma unroll
+        for (int st = 0; st < MID_MAXSTEP; ++st)
+            w[st] = st < ns ? *reinterpret_cast<const bf16x8_t*>(steps[s][st].wt + (int64_t)wrow * steps[s][st].ldwt + fk) : (bf16x8_t)(__bf16)0.f;
+    };
+    bf16x8_t wq[MID_JPW2][MID_MAXSTEP];
+#pragma unroll
+    for (int i = 0; i < MID_JPW2; ++i) load_w(wq[i], i);
+    // ---- 1: pool backward of level k+1 (lane = column).  dp_tj = <dOut_t, expert_sel(t,j)> over the row (wave reduction);
+    //         dExpert_e = sum over the gates t that select e, in gate order, of p_tj * dOut_t, then the activation mask
+    {
+        __bf16* dzg = reinterpret_cast<__bf16*>(a.dz2_h) + row * a.ld_dz2_h + lane;
+        for (int e0 = 0; e0 < ne2; e0 += MID_XCH) {
+        if (e0 > 0) load_x2(e0);
+#pragma unroll
+        for (int el = 0; el < MID_XCH; ++el) {
+            const int e = e0 + el;
+            if (e < ne2) {                                                      // uniform
+                const float x = x2r[el];
+                float d = 0.f;
+                for (int t = 0; t < ng2; ++t) {
+                    const int j = pos2[t][e];
+                    if (j >= 0) {                                               // uniform
+                        const float dO = dO2[((size_t)t * MID_BM + r) * H2 + lane];
+                        const float part = mid_wave_sum(dO * x);
+                        if (lane == 0) dp2[(t * MID_BM + r) * 16 + j] = part;
+                        d += p2[(t * MID_BM + r) * 16 + j] * dO;
+                    }
+                }
+                if (mask2) d = x > 0.f ? d * scale2 : 0.f;
+                const __bf16 h = (__bf16)d;
+                dz2[((size_t)e * MID_BM + r) * Cfg::DZ_LD + lane] = h;
+                if (live) dzg[(int64_t)e * H2] = h;
+            }
+        }
+        }
+    }
+    __syncthreads();
+    // ---- 1b: d_logit_tj = p_tj * (dp_tj - sum_k p_tk dp_tk): lane t of wave r takes (row r, gate t)
+    if (lane < ng2) {
+        const int t = lane;
+        const int ns = a.g2[t].n_sel;
+        float* dlg = a.g2[t].d_logits + row * a.g2[t].ld_dlogits;
+        __bf16* dlh = a.g2[t].d_logits_h ? reinterpret_cast<__bf16*>(a.g2[t].d_logits_h) + row * a.g2[t].ld_dlogits_h : nullptr;
+        const float* pp = p2 + (t * MID_BM + r) * 16;
+        const float* dd = dp2 + (t * MID_BM + r) * 16;
+        float dot = 0.f;
+        for (int j = 0; j < ns; ++j) dot += pp[j] * dd[j];
+        __bf16* lrow = dl2 + ((size_t)t * MID_BM + r) * Cfg::DL_LD;
+        for (int j = 0; j < 32; ++j) {
+            float dl = 0.f;
+            if (j < ns) {
+                dl = pp[j] * (dd[j] - dot);
+                if (live) {
+                    dlg[j] = dl;
+                    if (dlh) dlh[j] = (__bf16)dl;
+                }
+            }
+            lrow[j] = (__bf16)dl;
+        }
+    }
+    __syncthreads();                                                   // dz2, dl2 complete; dO2 is dead (dP1 takes its place)
+    // ---- 2: d(pooled level-k output s) [16, H1] = sum over the experts e reading s of dZ_e . W_e  +  the gates reading s
+    {
+        auto tile = [&](const bf16x8_t (&w)[MID_MAXSTEP], int i) __attribute__((always_inline)) {
+            const int job = wave + MID_WAVES * i;
+            if (job >= n_jobs) return;
+            const int s = job / Cfg::NT1, nt = job % Cfg::NT1;
+            const int ns = n_steps[s];
+            bf16x8_t af[MID_MAXSTEP];
+#pragma unroll
+            for (int st = 0; st < MID_MAXSTEP; ++st) {                 // past the source's steps: w[st] is zero, any finite A fragment will do
+                const int sc = st < ns ? st : ns - 1;
+                af[st] = *reinterpret_cast<const bf16x8_t*>(dz2 + steps[s][sc].a_off + frow * steps[s][sc].a_ld + fk);
+            }
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < MID_MAXSTEP; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[st], w[st], acc, 0, 0, 0);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                dP1[((size_t)s * MID_BM + (lane >> 4) * 4 + r4) * Cfg::DP_LD + nt * 16 + (lane & 15)] = acc[r4];
+        };
+#pragma unroll
+        for (int i = 0; i < MID_JPW2; ++i) tile(wq[i], i);
+        for (int i = MID_JPW2; wave + MID_WAVES * i < n_jobs; ++i) {
+            load_w(wq[0], i);
+            tile(wq[0], i);
+        }
+    }
+    __syncthreads();
+    // ---- 3: pool backward of level k (lane = two columns)
+    {
+        const int c1 = lane * 2;
+        __bf16* dzg = reinterpret_cast<__bf16*>(a.dz1_h) + row * a.ld_dz1_h + c1;
+        for (int e0 = 0; e0 < ne1; e0 += MID_XCH) {
+        if (e0 > 0) load_x1(e0);
+#pragma unroll
+        for (int el = 0; el < MID_XCH; ++el) {
+            const int e = e0 + el;
+            if (e < ne1) {
+                const f32x2_t x = x1r[el];
+                f32x2_t d = {0.f, 0.f};
+                for (int g = 0; g < ng1; ++g) {
+                    const int j = pos1[g][e];
+                    if (j >= 0) {
+                        const f32x2_t dO = *reinterpret_cast<const f32x2_t*>(dP1 + ((size_t)g * MID_BM + r) * Cfg::DP_LD + c1);
+                        const float part = mid_wave_sum(dO[0] * x[0] + dO[1] * x[1]);
+                        if (lane == 0) dp1[(g * MID_BM + r) * 16 + j] = part;
+                        d += p1[(g * MID_BM + r) * 16 + j] * dO;
+                    }
+                }
+                if (mask1) {
+                    d[0] = x[0] > 0.f ? d[0] * scale1 : 0.f;
+                    d[1] = x[1] > 0.f ? d[1] * scale1 : 0.f;
+                }
+                if (live) *reinterpret_cast<bf16x2_t*>(dzg + (int64_t)e * H1) = bf16x2_t{(__bf16)d[0], (__bf16)d[1]};
+            }
+        }
+        }
+    }
+    __syncthreads();
+    if (lane < ng1 && live) {
+        const int g = lane;
+        const int ns = a.g1[g].n_sel;
+        float* dlg = a.g1[g].d_logits + row * a.g1[g].ld_dlogits;
+        __bf16* dlh = a.g1[g].d_logits_h ? reinterpret_cast<__bf16*>(a.g1[g].d_logits_h) + row * a.g1[g].ld_dlogits_h : nullptr;
+        const float* pp = p1 + (g * MID_BM + r) * 16;
+        const float* dd = dp1 + (g * MID_BM + r) * 16;
+        float dot = 0.f;
+        for (int j = 0; j < ns; ++j) dot += pp[j] * dd[j];
+        for (int j = 0; j < ns; ++j) {
+            const float dl = pp[j] * (dd[j] - dot);
+            dlg[j] = dl;
+            if (dlh) dlh[j] = (__bf16)dl;
+        }
+    }
+}
+
+template <int H1, int H2>
+static size_t mid_bwd_lds(int ng1, int ng2, int ne2) {
+    typedef MidCfg<H1, H2> Cfg;
+    const size_t dp = (size_t)ng1 * MID_BM * Cfg::DP_LD * 4, dO = (size_t)ng2 * MID_BM * H2 * 4;
+    return (size_t)2 * MID_BM * ng1 * 16 * 4 + (size_t)2 * MID_BM * ng2 * 16 * 4 + (dp > dO ? dp : dO) + (size_t)ne2 * MID_BM * Cfg::DZ_LD * 2 +
+           (size_t)ng2 * MID_BM * Cfg::DL_LD * 2;
+}
+
+extern "C" int cdc_cgc_mid_bwd(const cdc_cgc_mid_bwd_args* a, void* stream) {
+    CDC_CHECK_ARG(a && a->B >= 0 && a->ex1 && a->ex2 && a->dz1_h && a->dz2_h, CDC_E_BADARG, "cgc_mid_bwd: null pointer");
+    CDC_CHECK_ARG(a->H1 == 128 && a->H2 == 64, CDC_E_BADARG, "cgc_mid_bwd: built for expert widths (128, 64), got (%d, %d)", a->H1, a->H2);
+    CDC_CHECK_ARG(a->n_exp1 > 0 && a->n_exp1 <= MID_E && a->n_exp2 > 0 && a->n_exp2 <= MID_E && a->n_gate1 > 0 && a->n_gate1 <= MID_G &&
+                      a->n_gate2 > 0 && a->n_gate2 <= MID_G, CDC_E_BADARG, "cgc_mid_bwd: bad counts");
+    CDC_CHECK_ARG((((uintptr_t)a->ex1 | (uintptr_t)a->ex2 | (uintptr_t)a->dz1_h) & 15) == 0 && (((uintptr_t)a->dz2_h) & 7) == 0 &&
+                      a->ld_ex1 % 4 == 0 && a->ld_ex2 % 4 == 0 && a->ld_dz1_h % 8 == 0 && a->ld_dz2_h % 4 == 0, CDC_E_ALIGN,
+                  "cgc_mid_bwd: misaligned expert buffers");
+    for (int g = 0; g < a->n_gate1; ++g)
+        CDC_CHECK_ARG(a->g1[g].probs && a->g1[g].d_logits && mid_check_sel(a->g1[g].sel, a->g1[g].n_sel, a->n_exp1), CDC_E_BADARG,
+                      "cgc_mid_bwd: level-k gate %d malformed", g);
+    for (int e = 0; e < a->n_exp2; ++e)
+        CDC_CHECK_ARG(a->e2[e].wt && a->e2[e].src >= 0 && a->e2[e].src < a->n_gate1 && a->e2[e].ldwt >= a->H2 && a->e2[e].ldwt % 8 == 0 &&
+                          (((uintptr_t)a->e2[e].wt) & 15) == 0, CDC_E_BADARG, "cgc_mid_bwd: expert %d malformed", e);
+    for (int g = 0; g < a->n_gate2; ++g) {
+        const cdc_mid_bgate2& G = a->g2[g];
+        CDC_CHECK_ARG(G.d_out && G.probs && G.d_logits && G.wt && G.src >= 0 && G.src < a->n_gate1 && G.ldwt >= 32 && G.ldwt % 8 == 0 &&
+                          (((uintptr_t)G.wt) & 15) == 0 && (((uintptr_t)G.d_out) & 15) == 0 && G.ld_dout % 4 == 0 &&
+                          mid_check_sel(G.sel, G.n_sel, a->n_exp2), CDC_E_BADARG, "cgc_mid_bwd: level-k+1 gate %d malformed", g);
+    }
+    for (int s = 0; s < a->n_gate1; ++s) {
+        int n = 0;
+        for (int e = 0; e < a->n_exp2; ++e) n += a->e2[e].src == s ? a->H2 / 32 : 0;
+        for (int g = 0; g < a->n_gate2; ++g) n += a->g2[g].src == s ? 1 : 0;
+        CDC_CHECK_ARG(n <= MID_MAXSTEP, CDC_E_TOOBIG, "cgc_mid_bwd: level-k output %d feeds %d K-steps of 32 (limit %d: two experts and a gate, or three experts)",
+                      s, n, MID_MAXSTEP);
+    }
+    if (a->B == 0) return 0;
+    const size_t lds = mid_bwd_lds<128, 64>(a->n_gate1, a->n_gate2, a->n_exp2);
+    CDC_CHECK_ARG(lds <= 150 * 1024, CDC_E_TOOBIG, "cgc_mid_bwd: %zu bytes of LDS needed", lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_cgc_mid_bwd<128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_cgc_mid_bwd<128, 64>), dim3((unsigned)cdc_ceil_div(a->B, MID_BM)), dim3(MID_THREADS), lds, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("cgc_mid_bwd");
+    return 0;
+}

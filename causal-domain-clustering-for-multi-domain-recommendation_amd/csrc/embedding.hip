@@ -1266,7 +1266,7 @@ extern "C" int cdc_embed_lazy_update(const float* rowgrad, const int32_t* uniq_r
 // rows -> step target = *step_dev + step_bias: all of them (period <= 1) or the slice (target mod period) of the table.
 // Rows not looked up since their last flush share one `last`, so whole waves replay the same steps.
 template <bool FAST, int VEC>
-__global__ void __launch_bounds__(256) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                     int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
                                                     const int32_t* __restrict__ step_dev, int32_t step_bias, int32_t period,
                                                     int32_t own_mod, int32_t own_rem, int32_t mark) {

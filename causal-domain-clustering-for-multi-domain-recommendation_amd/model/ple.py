@@ -100,6 +100,9 @@ class PLE(BaseModel):
         inputs = [E] * (self.n_tower + 1)
         for cgc in self.cgc_layers:
             inputs = cgc.describe(plan, inputs)
+        # a level's pooled outputs feed the next level's experts and gates and nothing else (ple.py:54-57): pooling, the next
+        # level's contractions and its pooling go out as one launch where the shapes allow (csrc/cgc.hip)
+        P.fuse_cgc_mid(plan)
         others = []                                                      # the wide term (ple.py:61) is formed inside the head launch
         if self.use_atten:
             others.append(self.describe_atten(plan, E))                  # ple.py:65-67

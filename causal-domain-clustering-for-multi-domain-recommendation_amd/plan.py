@@ -182,6 +182,7 @@ class Plan:
         self._rowdot_ws_need = 0
         self._gemm_ws = None
         self._gemm_ws_need = 0
+        self._gemm_ws_users = []          # argument blocks whose .workspace is the grad-weight split-K buffer
         self._lin_producer = {}           # linear output (root, col0, cols) -> its launch group (BatchNorm statistics fusion)
         self._last_bn_step = 0
         self._wt = {}                     # weight key -> (weight object, transposed copy [K,N]) refreshed at the start of backward
@@ -503,6 +504,8 @@ class Plan:
         dw = self._emit_deferred_dw()
         if self._gemm_ws.numel() < self._gemm_ws_need:
             self._gemm_ws = torch.empty(self._gemm_ws_need, dtype=torch.float32, device=self.device)
+        for a in self._gemm_ws_users:            # grad-weight launches built before the batched ones sized the workspace: a pointer
+            a.workspace = self._gemm_ws.data_ptr()   # taken earlier would dangle once the buffer has been re-allocated
         self.deferred_dw_steps = []          # the tail of bwd_steps nothing else in the backward depends on
         for a, fl in dw:
             a.workspace = self._gemm_ws.data_ptr()
@@ -760,7 +763,7 @@ class GLinear:
             a = L.LinBwdwArgs()
             a.n_groups = len(chunk)
             a.split_k = self.split_k[c0 // L.MAX_GROUPS]
-            a.workspace = plan._gemm_ws.data_ptr()
+            plan._gemm_ws_users.append(a)          # .workspace is set when the plan is finalised (the buffer may still grow)
             a.row_offsets = None if self.row_offsets is None else self.row_offsets.data_ptr() + 4 * c0
             for i, g in enumerate(chunk):
                 G = a.g[i]
@@ -783,6 +786,8 @@ class GLinear:
             self._keep.append(a)
             fl = sum(2.0 * self.M * g["w"].shape[0] * g["w"].shape[1] for g in chunk)
             plan.bwd_steps.append(plan.call("cdc_glinear_bwd_w", C.byref(a), plan.prec, flops=fl))
+        if getattr(self, "skip_bwd_x", False):       # the grad-input of this launch is formed elsewhere (CGCMid)
+            return
         # ---- grad-input: groups reading the same x reduce into one output
         outs = []      # list of (x Buf, [group indices]); indices run over this op's groups, then the adopted ones
         allg = self.groups + self.adopted
@@ -1004,6 +1009,199 @@ class GatePool:
                     G.sel[j] = e
             self._keep.append(a)
             plan.bwd_steps.append(plan.call("cdc_gate_pool_bwd", C.byref(a)))
+
+
+class CGCMid:
+    """The boundary between two extraction levels of PLE as ONE launch per direction (csrc/cgc.hip; model/ple.py:54-57,96-125):
+    GatePool(level k) -> GLinear(level k+1: single-layer experts + gates) -> GatePool(level k+1).  Built from the three ops the
+    model described (it takes their place in plan.ops and uses their buffers): the pooled level-k vectors exist only as bf16
+    shadows (the contraction operand and the grad-weight operand), their gradient never leaves the backward launch, and the dZ of
+    both expert levels is written as bf16 alone."""
+
+    H1, H2 = 128, 64                      # the widths csrc/cgc.hip is instantiated for (config.py:39-42: ((256,128),(64,)))
+
+    @staticmethod
+    def _same(a, b):
+        return a.root is b.root and a.col0 == b.col0 and a.cols == b.cols and a.rows == b.rows
+
+    @classmethod
+    def match(cls, plan, p1, lin, p2):
+        if not (isinstance(p1, GatePool) and isinstance(lin, GLinear) and isinstance(p2, GatePool)):
+            return None
+        if not (plan.use_g2 and lin.g2 and lin.row_offsets is None and lin.M == plan.B and not lin.adopted and lin.relu):
+            return None
+        if (p1.H, p2.H) != (cls.H1, cls.H2) or len(lin.groups) > L.G2_MAX_OUT:
+            return None
+        ne2, ng2 = p2.n_expert, len(p2.gates)
+        if (len(lin.groups) != ne2 + ng2 or p1.n_expert > L.MID_MAX_EXPERT or ne2 > L.MID_MAX_EXPERT or
+                len(p1.gates) > L.MID_MAX_GATE or ng2 > L.MID_MAX_GATE):
+            return None
+        for _, sel in list(p1.gates) + list(p2.gates):
+            if list(sel) != sorted(set(sel)):
+                return None
+
+        def src_of(x):
+            for i, o in enumerate(p1.outs):
+                if cls._same(o, x):
+                    return i
+            return None
+        srcs = []
+        for e, g in enumerate(lin.groups[:ne2]):
+            y = g["y"]
+            if not (tuple(g["w"].shape) == (cls.H2, cls.H1) and g["act_cols"] == cls.H2 and y.root is p2.experts.root and
+                    y.col0 == p2.experts.col0 + e * cls.H2 and isinstance(g["w"], torch.Tensor)):
+                return None
+            srcs.append(src_of(g["x"]))
+        for t, g in enumerate(lin.groups[ne2:]):
+            lg, sel = p2.gates[t]
+            if not (cls._same(g["y"], lg) and g["act_cols"] == 0 and g["w"].shape[0] == len(sel) and g["w"].shape[1] == cls.H1 and
+                    isinstance(g["w"], torch.Tensor)):
+                return None
+            srcs.append(src_of(g["x"]))
+        if any(s_ is None for s_ in srcs):
+            return None
+        for s_ in range(len(p1.outs)):                     # K steps of 32 per grad-input tile (csrc/cgc.hip MID_MAXSTEP)
+            if sum(cls.H2 // 32 for x in srcs[:ne2] if x == s_) + sum(1 for x in srcs[ne2:] if x == s_) > 6:
+                return None
+        if plan.is_half_only(p1.experts) or plan.is_half_only(p2.experts):
+            return None
+        return srcs
+
+    def __init__(self, plan, p1, lin, p2, srcs):
+        self.p1, self.lin, self.p2, self.srcs = p1, lin, p2, srcs
+        i = plan.ops.index(p1)
+        assert plan.ops[i + 1] is lin and plan.ops[i + 2] is p2
+        plan.ops[i:i + 3] = [self]
+        for o in p1.outs:                                  # never written as fp32: a stray reader shows up as NaN
+            plan.make_value_half_only(o)
+        # dZ of both expert levels: bf16 alone (read by the grad-weight launches and the level-k grad-input launch)
+        plan.make_grad_half_only(p1.experts)
+        plan.make_grad_half_only(p2.experts)
+        self._keep = []
+
+    def build_fwd(self, plan):
+        p1, lin, p2 = self.p1, self.lin, self.p2
+        ne2 = p2.n_expert
+        a = L.CgcMidFwdArgs()
+        a.B, a.H1, a.H2 = plan.B, self.H1, self.H2
+        a.n_exp1, a.n_gate1, a.n_exp2, a.n_gate2 = p1.n_expert, len(p1.gates), ne2, len(p2.gates)
+        a.ex1, a.ld_ex1 = p1.experts.ptr, p1.experts.ld
+        a.ex2, a.ld_ex2 = p2.experts.ptr, p2.experts.ld
+        a.relu, a.drop_p, a.seed, a.seed_offset_dev = 1 if lin.relu else 0, lin.drop_p, lin.seed & 0xFFFFFFFFFFFFFFFF, plan.step_dev.data_ptr()
+        for i, (lg, sel) in enumerate(p1.gates):
+            G = a.g1[i]
+            G.logits, G.ld_logits = lg.ptr, lg.ld
+            G.probs = p1.probs[i].data_ptr()
+            G.pooled_h, G.ld_pooled_h = plan.shadow_view(p1.outs[i])
+            plan.mark_shadow(p1.outs[i])
+            G.n_sel = len(sel)
+            for j, e in enumerate(sel):
+                G.sel[j] = e
+        for e, g in enumerate(lin.groups[:ne2]):
+            E = a.e2[e]
+            wh, _ = plan.wshadow(g["w"])
+            E.w, E.ldw = wh.data_ptr(), wh.stride(0)
+            E.bias = None if g.get("b") is None else g["b"].data_ptr()
+            E.src, E.stream_id = self.srcs[e], e           # stream_id: the group's index in the unfused launch
+        for t, g in enumerate(lin.groups[ne2:]):
+            G = a.g2[t]
+            lg, sel = p2.gates[t]
+            wh, _ = plan.wshadow(g["w"])
+            G.w, G.ldw = wh.data_ptr(), wh.stride(0)
+            G.bias = None if g.get("b") is None else g["b"].data_ptr()
+            G.probs = p2.probs[t].data_ptr()
+            o = p2.outs[t]
+            G.out, G.ld_out = o.ptr, o.ld
+            if plan.shadow_wanted(o):
+                G.out_h, G.ld_out_h = plan.shadow_view(o)
+                plan.mark_shadow(o)
+            else:
+                G.out_h = None
+            G.src, G.n_sel = self.srcs[ne2 + t], len(sel)
+            for j, e in enumerate(sel):
+                G.sel[j] = e
+        self._keep.append(a)
+        fl = sum(2.0 * plan.B * g["w"].shape[0] * g["w"].shape[1] for g in lin.groups)
+        plan.fwd_steps.append(plan.call("cdc_cgc_mid_fwd", C.byref(a), flops=fl))
+
+    def build_bwd(self, plan, gs):
+        p1, lin, p2 = self.p1, self.lin, self.p2
+        ne2 = p2.n_expert
+        if gs.claim(p1.experts) or gs.claim(p2.experts):
+            raise RuntimeError("CGCMid: an expert buffer's gradient has another writer")
+        a = L.CgcMidBwdArgs()
+        a.B, a.H1, a.H2 = plan.B, self.H1, self.H2
+        a.n_exp1, a.n_gate1, a.n_exp2, a.n_gate2 = p1.n_expert, len(p1.gates), ne2, len(p2.gates)
+        a.ex1, a.ld_ex1 = p1.experts.ptr, p1.experts.ld
+        a.ex2, a.ld_ex2 = p2.experts.ptr, p2.experts.ld
+        a.dz1_h, a.ld_dz1_h = plan.shadow_view(p1.experts.grad)
+        a.dz2_h, a.ld_dz2_h = plan.shadow_view(p2.experts.grad)
+        plan.mark_shadow(p1.experts.grad)
+        plan.mark_shadow(p2.experts.grad)
+        for ex, mk, sc in ((p1.experts, "mask1", "scale1"), (p2.experts, "mask2", "scale2")):
+            if ex.mask is not None:
+                assert ex.mask[1] >= ex.cols, "expert buffer is only partly activation-masked"
+                setattr(a, mk, 1)
+                setattr(a, sc, ex.mask[0])
+            else:
+                setattr(a, mk, 0)
+                setattr(a, sc, 1.0)
+
+        def fill_logit_grads(G, lg):
+            lgg = lg.grad
+            if gs.claim(lg):
+                raise RuntimeError("gate logits feed more than one consumer")
+            G.d_logits, G.ld_dlogits = lgg.ptr, lgg.ld
+            if plan.shadow_wanted(lgg):
+                G.d_logits_h, G.ld_dlogits_h = plan.shadow_view(lgg)
+                plan.mark_shadow(lgg)
+            else:
+                G.d_logits_h = None
+        for i, (lg, sel) in enumerate(p1.gates):
+            G = a.g1[i]
+            G.probs = p1.probs[i].data_ptr()
+            fill_logit_grads(G, lg)
+            G.n_sel = len(sel)
+            for j, e in enumerate(sel):
+                G.sel[j] = e
+        for e, g in enumerate(lin.groups[:ne2]):
+            _, wt = plan.wshadow(g["w"])
+            a.e2[e].wt, a.e2[e].ldwt, a.e2[e].src = wt.data_ptr(), wt.stride(0), self.srcs[e]
+        for t, g in enumerate(lin.groups[ne2:]):
+            G = a.g2[t]
+            lg, sel = p2.gates[t]
+            plan.ensure_grad(p2.outs[t], gs)
+            og = p2.outs[t].grad
+            G.d_out, G.ld_dout = og.ptr, og.ld
+            G.probs = p2.probs[t].data_ptr()
+            fill_logit_grads(G, lg)
+            _, wt = plan.wshadow(g["w"])
+            G.wt, G.ldwt = wt.data_ptr(), wt.stride(0)
+            G.src, G.n_sel = self.srcs[ne2 + t], len(sel)
+            for j, e in enumerate(sel):
+                G.sel[j] = e
+        self._keep.append(a)
+        fl = sum(2.0 * plan.B * g["w"].shape[0] * g["w"].shape[1] for g in lin.groups)
+        plan.bwd_steps.append(plan.call("cdc_cgc_mid_bwd", C.byref(a), flops=fl))
+        # the level-k+1 grad-weight contractions stay with the batched launches at the end of backward
+        lin.skip_bwd_x = True
+        lin.build_bwd(plan, gs)
+
+
+def fuse_cgc_mid(plan):
+    """Replaces every (GatePool, GLinear, GatePool) run of plan.ops that is a PLE level boundary of the instantiated shape by ONE
+    CGCMid op.  Called by the model that KNOWS the pooled level-k vectors have no other reader (model/ple.py: ple_inputs)."""
+    if os.environ.get("CDC_CGC_MID", "1") == "0":
+        return 0
+    n = 0
+    i = 0
+    while i + 2 < len(plan.ops):
+        srcs = CGCMid.match(plan, plan.ops[i], plan.ops[i + 1], plan.ops[i + 2])
+        if srcs is not None:
+            CGCMid(plan, plan.ops[i], plan.ops[i + 1], plan.ops[i + 2], srcs)
+            n += 1
+        i += 1
+    return n
 
 
 class BatchNorm:

@@ -419,6 +419,102 @@ typedef struct {
 int cdc_gate_pool_bwd(const cdc_pool_bwd_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The boundary between two extraction levels of PLE as ONE launch per direction (reference: model/ple.py:96-125 called twice
+ * from model/ple.py:54-57): level k's gate softmax + pooling, level k+1's single-layer experts and its gates (nn.Linear
+ * (+ReLU +dropout): model/layer.py:185-191; gates model/ple.py:89-94), and level k+1's gate softmax + pooling.  A workgroup
+ * owns 16 batch rows: the pooled level-k outputs never leave LDS as fp32 (they are the bf16 A operand of the level-k+1
+ * contractions, exactly the rounding cdc_gemm_bf16_nt applies to their shadow), the level-k+1 expert tiles are pooled
+ * straight out of LDS.  Arithmetic, rounding points and dropout stream are those of
+ *     cdc_gate_pool_fwd -> cdc_gemm_bf16_nt(mode 0) -> cdc_gate_pool_fwd        (forward: bit-identical results)
+ *     cdc_gate_pool_bwd -> cdc_gemm_bf16_nt(mode 1) -> cdc_gate_pool_bwd        (backward: same roundings; the row dot
+ *                                                                                products of the gate gradients are summed
+ *                                                                                by 16 lanes per row instead of H/4)
+ * Widths are compile-time: (H1, H2) = (128, 64), the reference's expert_dims ((256,128),(64,)) (config.py:39-42); other
+ * shapes take the three separate launches.  sel lists ascending.  What the backward needs is written: probabilities of both
+ * levels, the level-k outputs' bf16 shadows (grad-weight operand), the level-k+1 expert activations (fp32).
+ * ---------------------------------------------------------------------------------------- */
+#define CDC_MID_MAX_EXPERT 16
+#define CDC_MID_MAX_GATE 8
+typedef struct {
+    const float* logits; int64_t ld_logits;   /* [B, n_sel] fp32: this gate's logits */
+    float* probs;                             /* [B, n_sel] contiguous (saved for backward) */
+    void* pooled_h; int64_t ld_pooled_h;      /* bf16 [B, H1]: the pooled output = an input of the next level */
+    int32_t n_sel;
+    int32_t sel[CDC_MAX_SEL];
+    int32_t pad_;
+} cdc_mid_gate1;
+typedef struct {
+    const void* w; int64_t ldw;               /* bf16 [H2, >= H1] (cdc_weight_shadows' straight copy) */
+    const float* bias;                        /* [H2] or NULL */
+    int32_t src;                              /* which level-k gate's pooled output this expert reads */
+    int32_t stream_id;                        /* dropout stream of this expert (cdc_g2_out.stream_id of the unfused launch) */
+} cdc_mid_expert2;
+typedef struct {
+    const void* w; int64_t ldw;               /* bf16 [n_sel, >= H1] */
+    const float* bias;                        /* [n_sel] or NULL */
+    float* probs;                             /* [B, n_sel] contiguous */
+    float* out; int64_t ld_out;               /* fp32 [B, H2] pooled output, or NULL */
+    void* out_h; int64_t ld_out_h;            /* bf16 [B, H2] pooled output, or NULL */
+    int32_t src;                              /* which level-k pooled output the gate reads */
+    int32_t n_sel;
+    int32_t sel[CDC_MAX_SEL];
+} cdc_mid_gate2;
+typedef struct {
+    int64_t B;
+    int32_t H1, H2;
+    int32_t n_exp1, n_gate1, n_exp2, n_gate2;
+    const float* ex1; int64_t ld_ex1;         /* level-k expert activations [B, n_exp1*H1] fp32 */
+    float* ex2; int64_t ld_ex2;               /* level-k+1 expert activations [B, n_exp2*H2] fp32 (output) */
+    int32_t relu;                             /* level-k+1 experts: relu */
+    float drop_p;                             /* ... and dropout (32-bit counter stream of cdc_gemm_bf16_nt) */
+    uint64_t seed;
+    const int32_t* seed_offset_dev;
+    cdc_mid_gate1 g1[CDC_MID_MAX_GATE];
+    cdc_mid_expert2 e2[CDC_MID_MAX_EXPERT];
+    cdc_mid_gate2 g2[CDC_MID_MAX_GATE];
+} cdc_cgc_mid_fwd_args;
+int cdc_cgc_mid_fwd(const cdc_cgc_mid_fwd_args* a, void* stream);
+
+typedef struct {
+    const float* probs;                       /* [B, n_sel] */
+    float* d_logits; int64_t ld_dlogits;      /* [B, n_sel] fp32 (output) */
+    void* d_logits_h; int64_t ld_dlogits_h;   /* optional bf16 shadow of d_logits */
+    int32_t n_sel;
+    int32_t sel[CDC_MAX_SEL];
+    int32_t pad_;
+} cdc_mid_bgate1;
+typedef struct {
+    const void* wt; int64_t ldwt;             /* bf16 [H1, >= H2]: the expert's W^T (cdc_weight_shadows' transposed copy) */
+    int32_t src;
+    int32_t pad_;
+} cdc_mid_bexpert2;
+typedef struct {
+    const float* d_out; int64_t ld_dout;      /* fp32 [B, H2]: gradient of this gate's pooled output */
+    const float* probs;                       /* [B, n_sel] */
+    float* d_logits; int64_t ld_dlogits;      /* [B, n_sel] fp32 (output) */
+    void* d_logits_h; int64_t ld_dlogits_h;   /* optional bf16 shadow */
+    const void* wt; int64_t ldwt;             /* bf16 [H1, >= 32]: the gate's W^T, columns >= n_sel zero */
+    int32_t src;
+    int32_t n_sel;
+    int32_t sel[CDC_MAX_SEL];
+} cdc_mid_bgate2;
+typedef struct {
+    int64_t B;
+    int32_t H1, H2;
+    int32_t n_exp1, n_gate1, n_exp2, n_gate2;
+    const float* ex1; int64_t ld_ex1;         /* forward activations (masks and gate-gradient dot products) */
+    const float* ex2; int64_t ld_ex2;
+    void* dz1_h; int64_t ld_dz1_h;            /* bf16 [B, n_exp1*H1] (output): dZ of the level-k experts' last layer */
+    void* dz2_h; int64_t ld_dz2_h;            /* bf16 [B, n_exp2*H2] (output): dZ of the level-k+1 experts */
+    int32_t mask1, mask2;                     /* 1: d = (activation > 0) ? d * scale : 0 */
+    float scale1, scale2;
+    cdc_mid_bgate1 g1[CDC_MID_MAX_GATE];
+    cdc_mid_bexpert2 e2[CDC_MID_MAX_EXPERT];
+    cdc_mid_bgate2 g2[CDC_MID_MAX_GATE];
+} cdc_cgc_mid_bwd_args;
+int cdc_cgc_mid_bwd(const cdc_cgc_mid_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * BatchNorm1d (+ReLU, +dropout) over column segments (reference: model/layer.py:187,199-205 with the
  * batch==1 skip; model/star.py:117-181 MDR_BatchNorm with gamma_d*gamma_s / beta_d+beta_s — the caller
  * passes the combined gamma/beta).  Training: batch mean / biased variance, running stats updated with

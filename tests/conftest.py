@@ -18,3 +18,14 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _attribute_async_gpu_errors(request):
+    """Launches are asynchronous: a fault raised by one test's kernels would otherwise surface at the first host
+    synchronisation of a LATER test.  Synchronising after every GPU test pins it to the test that caused it."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()

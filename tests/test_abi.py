@@ -48,6 +48,8 @@ STRUCTS = {
     "cdc_star_fuse_args": "StarFuseArgs", "cdc_transpose_args": "TransposeArgs", "cdc_add_n_args": "AddNArgs",
     "cdc_g2_out": "G2Out", "cdc_g2_seg": "G2Seg", "cdc_g2_args": "G2Args", "cdc_wshadow_args": "WShadowArgs",
     "cdc_shadow_args": "ShadowArgs", "cdc_head_tower": "HeadTower", "cdc_head_args": "HeadArgs",
+    "cdc_mid_gate1": "MidGate1", "cdc_mid_expert2": "MidExpert2", "cdc_mid_gate2": "MidGate2", "cdc_cgc_mid_fwd_args": "CgcMidFwdArgs",
+    "cdc_mid_bgate1": "MidBGate1", "cdc_mid_bexpert2": "MidBExpert2", "cdc_mid_bgate2": "MidBGate2", "cdc_cgc_mid_bwd_args": "CgcMidBwdArgs",
     "cdc_tower_layer": "TowerLayer", "cdc_tower_desc": "TowerDesc", "cdc_tower_args": "TowerArgs",
 }
 
