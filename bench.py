@@ -290,11 +290,6 @@ def main():
     run(ts, max(args.warmup, 1))
     elapsed = timed(ts, args.steps)
     loss_val = float(ts.loss.item())
-    if os.environ.get("CDC_TOWER_MARKS") == "1" and getattr(ts.plan, "_tower_fused", None) is not None:
-        # development aid: workgroup 0's wall-clock phase marks (100 MHz) of the last fused tower launch (csrc/tower.hip TW_MARK)
-        e = ts.plan._tower_fused.err.cpu()
-        m = e[2:].view(torch.int64).tolist()
-        print("tower marks (us since kernel start):", [round((x - m[0]) / 100.0, 2) for x in m if x], "flag", int(e[0]), file=sys.stderr)
     elapsed_local = None
     if ts_local is not None:
         run(ts_local, max(args.warmup, 4))

@@ -252,27 +252,6 @@ class HeadArgs(C.Structure):
                 ("bce_inv_count", c_f), ("pad2_", c_i32), ("t", HeadTower * HEAD_MAX_TOWERS)]
 
 
-TOWER_MAX, TOWER_MAX_LAYERS, TOWER_MAX_DIM = 8, 3, 128
-
-
-class TowerLayer(C.Structure):
-    _fields_ = [("wh", c_p), ("ldwh", c_i64), ("bias", c_p), ("gamma", c_p), ("beta", c_p), ("running_mean", c_p), ("running_var", c_p),
-                ("num_batches_tracked", c_p), ("save_mean", c_p), ("save_invstd", c_p), ("z", c_p), ("ldz", c_i64),
-                ("y", c_p), ("ldy", c_i64), ("yh", c_p), ("ldyh", c_i64)]
-
-
-class TowerDesc(C.Structure):
-    _fields_ = [("xh", c_p), ("ldxh", c_i64), ("w_out", c_p), ("b_out", c_p), ("l", TowerLayer * TOWER_MAX_LAYERS)]
-
-
-class TowerArgs(C.Structure):
-    _fields_ = [("n_tower", c_i32), ("n_layer", c_i32), ("K0", c_i32), ("training", c_i32), ("H", c_i32 * TOWER_MAX_LAYERS), ("sigmoid", c_i32),
-                ("M", c_i64), ("eps", c_f), ("momentum", c_f), ("drop_p", c_f), ("pad_", c_f), ("seed", C.c_uint64), ("seed_offset_dev", c_p),
-                ("out", c_p), ("ld_out", c_i64), ("wide_x", c_p), ("ld_wide", c_i64), ("wide_w", c_p), ("wide_bias", c_p),
-                ("wide_out", c_p), ("ld_wide_out", c_i64), ("wide_K", c_i32), ("n_addend", c_i32), ("addend", c_p * 2), ("ld_addend", c_i64 * 2),
-                ("partial", c_p), ("sync", c_p), ("err", c_p), ("t", TowerDesc * TOWER_MAX)]
-
-
 class StarFuseArgs(C.Structure):
     _fields_ = [("n", c_i32), ("op", c_i32), ("size", c_i64), ("s", c_p), ("ds", c_p), ("accumulate_ds", c_i32), ("pad_", c_i32),
                 ("a", c_p * MAX_GROUPS), ("out", c_p * MAX_GROUPS), ("da", c_p * MAX_GROUPS)]
@@ -338,9 +317,6 @@ _SIGNATURES = {
     "cdc_head_fwd": (c_i32, [C.POINTER(HeadArgs), c_p]),
     "cdc_head_bwd": (c_i32, [C.POINTER(HeadArgs), c_p]),
     "cdc_head_workspace_floats": (c_i64, [C.POINTER(HeadArgs)]),
-    "cdc_tower_fwd": (c_i32, [C.POINTER(TowerArgs), c_p]),
-    "cdc_tower_fwd_workspace_doubles": (c_i64, [c_i64, c_i32, c_i32]),
-    "cdc_tower_fwd_fits": (c_i32, [c_i64, c_i32]),
     "cdc_bce_fwd_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f, c_p]),
     "cdc_attn_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),
     "cdc_attn_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),

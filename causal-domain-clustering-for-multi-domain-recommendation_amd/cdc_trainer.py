@@ -176,6 +176,9 @@ class CDCTrainer:
                     self.log(float(acc) / log_interval)
                 acc = 0.0
                 self.check_ids()
+                self.opt.refresh_table_reg()                          # lazy table: the reported loss's table term (run.py:637), exact again
+
+        self.opt.refresh_table_reg()
 
         if epoch_i == 0:                                              # warm-up on the tower mean
             for _ in range(self.warmup_step):

@@ -684,12 +684,16 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_stats_v4(const cdc_bn_bw
 #pragma unroll
         for (int k = 0; k < G::ITER; ++k) {
             const int r = r_begin + (k * WAVES_PER_BLOCK + wave) * G::RW + rs;
+            // rows past the group's extent are NOT read (a ragged group near the end of the batch: row_lo + r_begin lies beyond
+            // the buffer for the chunks the group does not have — round 2 read them and zeroed the value afterwards)
             const bool ok = r < r_end;
-            const int64_t gr = t.row_lo + (ok ? r : r_begin);
-            dv[k] = bn_ld4(S.dy, dyh, gr * S.lddy + c);
-            if (masked) yv[k] = bn_ld4(S.y, yh, gr * S.ldy + c);
-            xv[k] = bn_ld4(S.x, xh, gr * S.ldx + c);
-            if (!ok) dv[k] = bn_f4{{0.f, 0.f, 0.f, 0.f}};
+            const int64_t gr = t.row_lo + r;
+            dv[k] = yv[k] = xv[k] = bn_f4{{0.f, 0.f, 0.f, 0.f}};
+            if (ok) {
+                dv[k] = bn_ld4(S.dy, dyh, gr * S.lddy + c);
+                if (masked) yv[k] = bn_ld4(S.y, yh, gr * S.ldy + c);
+                xv[k] = bn_ld4(S.x, xh, gr * S.ldx + c);
+            }
         }
         float mean[4], invstd[4];
 #pragma unroll
@@ -730,7 +734,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply_v4(const cdc_bn_bw
     for (int k = 0; k < G::ITER; ++k) {                                  // in flight while the column sums are put together
         const int r = r_begin + (k * WAVES_PER_BLOCK + wave) * G::RW + rs;
         const bool ok = in_c && r < r_end;
-        const int64_t gr = t.row_lo + (r < r_end ? r : r_begin);
+        const int64_t gr = t.row_lo + r;
         if (ok) {
             dv[k] = bn_ld4(S.dy, dyh, gr * S.lddy + c);
             if (masked) yv[k] = bn_ld4(S.y, yh, gr * S.ldy + c);
@@ -909,10 +913,10 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_stats(const cdc_bn_bwd_a
         for (int k = 0; k < RPW; ++k) {                                  // 48 loads in flight per lane instead of 3
             const int r = r_begin + wave + k * WAVES_PER_BLOCK;
             const bool ok = r < r_end;
-            const int64_t gr = t.row_lo + (ok ? r : r_begin);
+            const int64_t gr = t.row_lo + r;                             // (only dereferenced for rows of the group: see k_bn_bwd_stats_v4)
             dv[k] = ok ? bn_ld(S.dy, dyh, gr * S.lddy + c) : 0.f;
             yv[k] = (ok && masked) ? bn_ld(S.y, yh, gr * S.ldy + c) : 1.f;
-            xv[k] = bn_ld(S.x, xh, gr * S.ldx + c);
+            xv[k] = ok ? bn_ld(S.x, xh, gr * S.ldx + c) : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {                                  // rows past r_end carry dz = 0: exact zeros in both sums
@@ -971,10 +975,10 @@ __global__ void __launch_bounds__(ROW_THREADS) k_bn_bwd_apply(const cdc_bn_bwd_a
     for (int k = 0; k < RPW; ++k) {
         const int r = r_begin + wave + k * WAVES_PER_BLOCK;
         const bool ok = r < r_end;
-        const int64_t gr = t.row_lo + (ok ? r : r_begin);
+        const int64_t gr = t.row_lo + r;
         dv[k] = ok ? bn_ld(S.dy, dyh, gr * S.lddy + c) : 0.f;
         yv[k] = (ok && masked) ? bn_ld(S.y, yh, gr * S.ldy + c) : 1.f;
-        xv[k] = need_x ? bn_ld(S.x, xh, gr * S.ldx + c) : 0.f;
+        xv[k] = (ok && need_x) ? bn_ld(S.x, xh, gr * S.ldx + c) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {

@@ -151,6 +151,7 @@ def train_epoch(step, loader, log_interval=None, log=None):
         log_interval = max(1, 204800 // step.B)
     acc = torch.zeros((), dtype=torch.float64, device=step.device)
     done = skipped = 0
+    step.refresh_table_reg()                     # lazy table: the first logging window reports the table's L2 term too
     for batch in loader:
         X = batch[0]
         ts = step

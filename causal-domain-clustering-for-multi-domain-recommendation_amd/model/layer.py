@@ -182,12 +182,6 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
     cur = list(inputs)
     extra_outs = []
     depth = len(mlps[0].hidden)
-    # tower stacks (BatchNorm layers + output layer + head): their forward launches can be taken over by ONE launch
-    fuse = (mlps[0].use_bn and mlps[0].out_linear is not None and head_out is not None and not extra_groups and last_outs is None and
-            depth > 0 and P.TowerStackFused.eligible(plan, n, cur[0].cols, [h[0].out_features for h in mlps[0].hidden], head_out,
-                                                     len(final_addends)))
-    marker = P.FwdMarker(plan) if fuse else None
-    fused_layers = []
     if depth == 0 and extra_groups:
         op = P.GLinear(plan, [dict(g) for g in extra_groups])
         extra_outs = op.outs
@@ -226,8 +220,7 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
             if j < depth - 1 and width % 8 == 0 and post is not None:
                 for sg in segs:                       # read by the next layer's contractions only (see the BatchNorm-free case below)
                     sg["half_only"] = True
-            bn_op = P.BatchNorm(plan, segs, relu=True, dropout=True)
-            fused_layers.append((op, bn_op))
+            P.BatchNorm(plan, segs, relu=True, dropout=True)
             cur = dst
         else:
             # hidden activations of a BatchNorm-free stack are read by the next layer's contractions only (forward, grad-weight,
@@ -246,9 +239,7 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
     if mlps[0].out_linear is not None and head_out is not None:
         # the output layers of all towers, the wide term and the sigmoid in one launch per direction (csrc/head.hip)
         towers = [{"x": cur[i], "w": m.out_linear.weight, "b": m.out_linear.bias} for i, m in enumerate(mlps)]
-        head = P.TowerHead(plan, towers, head_out, wide=head_wide, addends=final_addends, sigmoid=final_sigmoid)
-        if fuse:
-            P.TowerStackFused(plan, marker, fused_layers, head)
+        P.TowerHead(plan, towers, head_out, wide=head_wide, addends=final_addends, sigmoid=final_sigmoid)
         return [head_out.slice(i, i + 1) for i in range(n)], extra_outs
     if mlps[0].out_linear is not None:
         groups = []
@@ -468,7 +459,11 @@ class BaseModel(HipModule):
         fused head launch (csrc/head.hip) together with the towers' output layers; other_outs are the further logits."""
         import os
         n = len(self.towers)
-        fused = (wide_in is not None and n <= P.L.HEAD_MAX_TOWERS and len(other_outs) <= 2 and
+        # the fused head's backward keeps one weight-gradient column per tower input, bias and wide input in LDS: 8 waves x width
+        # floats in 64 KB (csrc/head.hip: head_width) — wider models (e.g. 39 fields x emb_dim 64) take the row-dot launches
+        head_cols = sum(t.out_linear.weight.numel() + 1 for t in self.towers if t.out_linear is not None)
+        head_cols += 0 if wide_in is None else wide_in.cols + 1
+        fused = (wide_in is not None and n <= P.L.HEAD_MAX_TOWERS and len(other_outs) <= 2 and head_cols <= 2048 and
                  all(t.out_linear is not None for t in self.towers) and os.environ.get("CDC_FUSED_HEAD", "1") != "0")
         if wide_in is not None and not fused:
             other_outs = [self.linear.describe(plan, wide_in)] + list(other_outs)

@@ -64,6 +64,7 @@ class FusedAdam:
         self.flush_every = int(flush_every) if table_mode == "lazy" else 0
         self.reg_sum = torch.zeros(2, dtype=torch.float64, device=dev)       # [0] dense params (l2 applied), [1] table sum(w^2)
         self.table_reg = torch.zeros((), dtype=torch.float64, device=dev)    # lazy table: l2 * sum(w^2) at the last refresh
+        self.table_reg_ready = False          # False until refresh_table_reg() has run for the current weights (build / load)
         f32 = lambda v: float(torch.tensor(v, dtype=torch.float64).to(torch.float32))  # noqa: E731
         self._lerp_w = f32(1.0 - betas[0])
         self._beta2 = f32(betas[1])
@@ -322,9 +323,35 @@ class FusedAdam:
         part only covers rows replayed this step; call flush_table() + table_reg_loss() for the exact figure."""
         return self.reg_sum[0] + self.l2_table * self.reg_sum[1]
 
-    def table_reg_loss(self):
+    def table_reg_loss(self, owned_only=False):
+        """l2 * sum(w^2) over the table after bringing its rows to the current step (model/layer.py:31,96-112).  owned_only (the
+        row-sharded table under data parallelism): only the rows this rank maintains (r % own_mod == own_rem) — the others are
+        stale here; the caller adds the ranks' figures up.  Summed in double over row blocks (no table-sized temporary)."""
         self.flush_table()
-        return self.l2_table * torch.sum(torch.square(self.table.data.double()))
+        w = self.table.data
+        if owned_only and self.own_mod > 1:
+            w = w[self.own_rem::self.own_mod]
+        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        step = 1 << 22
+        for r0 in range(0, w.shape[0], step):
+            total += torch.sum(torch.square(w[r0:r0 + step].double()))
+        return self.l2_table * total
+
+    def refresh_table_reg(self, dist=None):
+        """Lazy table: re-evaluates the table's share of the reference's reported loss (run.py:489) for the weights the next
+        forward sees and caches it in `table_reg`, which every step adds to its `reg` figure until the next refresh.  dist: the
+        data-parallel group when the table is row-sharded (owned rows summed per rank, then added up across ranks)."""
+        if self.table_mode != "lazy":
+            return self.table_reg
+        sharded = dist is not None and self.own_mod > 1
+        val = self.table_reg_loss(owned_only=sharded)
+        if sharded:
+            val = val.reshape(1).clone()
+            dist.all_reduce_sum(val)
+            val = val[0]
+        self.table_reg.copy_(val)
+        self.table_reg_ready = True
+        return self.table_reg
 
     # ---- checkpointing (run.py:447: 'optimizer': optimizer.state_dict()) -------------------------------------
     def state_dict(self):
@@ -355,3 +382,4 @@ class FusedAdam:
                     self._dense_sig = None
         if self.table_last is not None:
             self.table_last.fill_(int(sd["step"]))
+        self.table_reg_ready = False

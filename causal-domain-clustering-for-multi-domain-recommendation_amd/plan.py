@@ -147,7 +147,7 @@ class _GradState:
 
 
 class Plan:
-    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0, step_dev=None, grad_arena=None, dist=None):
+    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0, step_dev=None, grad_arena=None, dist=None, g2=True):
         assert precision in ("bf16", "f32")
         self.lib = L.load()
         self.device = torch.device(device)
@@ -190,7 +190,9 @@ class Plan:
         self.finalized = False
         self.loss_inputs = None
         # bf16 contraction path with operands that are bf16 in memory (csrc/gemm2.hip): shadows of activations, gradients, weights
-        self.use_g2 = self.prec == L.PREC_BF16 and os.environ.get("CDC_GEMM2", "1") != "0"
+        # g2=False (tests only): every bf16 contraction through csrc/gemm.hip's register-staged path — the one ragged launches
+        # (STAR's per-domain groups) take — so that the two paths can be held against each other
+        self.use_g2 = self.prec == L.PREC_BF16 and bool(g2)
         self._shadows = {}                # id(fp32 root) -> (root, bf16 tensor [rows64, cols64 + 64], zero padded)
         self._sh_have = {}                # id(root) -> [(c0, c1)] columns whose shadow is current at this point of the sequence
         self._sh_wanted = {}              # id(root) -> [(c0, c1)] columns some contraction reads through the shadow
@@ -1641,125 +1643,6 @@ class TowerHead:
         self._keep.append(a)
         self.bwd_args = [a]                      # (trainer: the fused BCE is switched on in this launch)
         plan.bwd_steps.append(plan.call("cdc_head_bwd", C.byref(a)))
-
-
-class FwdMarker:
-    """remembers where the forward launch list stood when the ops after it were built"""
-
-    def __init__(self, plan):
-        self.pos = None
-        plan.add(self)
-
-    def build_fwd(self, plan):
-        self.pos = len(plan.fwd_steps)
-
-    def build_bwd(self, plan, gs):
-        pass
-
-
-class TowerStackFused:
-    """The FORWARD launches of a tower stack — per hidden layer one grouped linear + one BatchNorm launch, then the head — replaced
-    by ONE launch (csrc/tower.hip: cdc_tower_fwd).  The ops it stands for are built as usual (their backward launches, buffers,
-    shadow bookkeeping and saved statistics are what the backward reads); this op, added after them, takes their forward
-    launches back out of the plan and puts its own there.
-
-    layers: [(GLinear, BatchNorm)] per depth (group / segment i = tower i), head: TowerHead."""
-
-    @staticmethod
-    def eligible(plan, n, in_cols, widths, head_out, n_addends):
-        # Off unless CDC_FUSED_TOWER=1.  Measured at C2 (profiles/round2/README.md): 40.7 us against 46.8 us for the five launches it
-        # replaces — the launch is a chain of ~10 dependent memory round trips either way (a grid barrier + the gather of the
-        # partial sums costs 5-6 us, about what a launch boundary costs inside a replayed graph), so the step gains 1 %, which
-        # does not pay for a launch that needs every workgroup resident at once.
-        if os.environ.get("CDC_FUSED_TOWER", "0") != "1" or not plan.use_g2 or plan.dist is not None or head_out is None:
-            return False
-        if not (0 < n <= L.TOWER_MAX and 0 < len(widths) <= L.TOWER_MAX_LAYERS and n_addends <= 2):
-            return False
-        if any(w % 16 or w > L.TOWER_MAX_DIM for w in list(widths) + [in_cols]):
-            return False
-        return L.load().cdc_tower_fwd_fits(plan.B, n) == 1
-
-    def __init__(self, plan, marker, layers, head):
-        self.marker, self.layers, self.head = marker, layers, head
-        self.ok = all(lin.g2 and lin.row_offsets is None and bn.row_offsets is None for lin, bn in layers)
-        if self.ok:
-            n, depth = len(head.towers), len(layers)
-            need = L.load().cdc_tower_fwd_workspace_doubles(plan.B, n, depth)
-            self.partial = torch.zeros(max(int(need), 1), dtype=torch.float64, device=plan.device)
-            self.sync = torch.zeros(L.TOWER_MAX_LAYERS + 1, dtype=torch.int32, device=plan.device)
-            self.err = torch.zeros(2 + 2 * 12, dtype=torch.int32, device=plan.device)      # [flag, pad | 12 int64 phase marks]
-            plan._tower_fused = self
-            plan.add(self)
-
-    def build_fwd(self, plan):
-        head, layers = self.head, self.layers
-        n, depth = len(head.towers), len(layers)
-        a = L.TowerArgs()
-        a.n_tower, a.n_layer, a.training, a.M = n, depth, 1 if plan.training else 0, plan.B
-        a.K0 = layers[0][0].groups[0]["x"].cols
-        for l, (lin, bn) in enumerate(layers):
-            a.H[l] = lin.groups[0]["w"].shape[0]
-        a.sigmoid = 1 if head.sigmoid else 0
-        bn0 = layers[0][1]
-        a.eps, a.momentum, a.drop_p = bn0.eps, bn0.momentum, bn0.drop_p
-        a.seed, a.seed_offset_dev = bn0.seed & 0xFFFFFFFFFFFFFFFF, plan.step_dev.data_ptr()
-        a.out, a.ld_out = head.out.ptr, head.out.ld
-        if head.wide is not None:
-            w = head.wide
-            a.wide_x, a.ld_wide, a.wide_w = w["x"].ptr, w["x"].ld, w["w"].data_ptr()
-            a.wide_bias = None if w.get("b") is None else w["b"].data_ptr()
-            a.wide_K = w["w"].numel()
-            self.wide_scratch = torch.zeros(plan.B, dtype=torch.float32, device=plan.device)
-            a.wide_out, a.ld_wide_out = self.wide_scratch.data_ptr(), 1
-        a.n_addend = len(head.addends)
-        for i, ad in enumerate(head.addends):
-            a.addend[i], a.ld_addend[i] = ad.ptr, ad.ld
-        a.partial, a.sync, a.err = self.partial.data_ptr(), self.sync.data_ptr(), self.err.data_ptr()
-        for i in range(n):
-            T = a.t[i]
-            x = layers[0][0].groups[i]["x"]
-            if not plan.has_shadow(x):
-                raise RuntimeError("the fused tower launch reads its input through the bf16 shadow, which nobody wrote")
-            T.xh, T.ldxh = plan.shadow_view(x)
-            T.w_out = head.towers[i]["w"].data_ptr()
-            T.b_out = None if head.towers[i].get("b") is None else head.towers[i]["b"].data_ptr()
-            for l, (lin, bn) in enumerate(layers):
-                g, sg = lin.groups[i], bn.segs[i]
-                Lr = T.l[l]
-                wh, _ = plan.wshadow(g["w"])
-                Lr.wh, Lr.ldwh = wh.data_ptr(), wh.stride(0)
-                Lr.bias = None if g.get("b") is None else g["b"].data_ptr()
-                Lr.gamma, Lr.beta = sg["gamma"].data_ptr(), sg["beta"].data_ptr()
-                Lr.running_mean, Lr.running_var = sg["running_mean"].data_ptr(), sg["running_var"].data_ptr()
-                nbt = sg.get("num_batches_tracked")
-                Lr.num_batches_tracked = None if nbt is None else nbt.data_ptr()
-                Lr.save_mean, Lr.save_invstd = sg["save_mean"].data_ptr(), sg["save_invstd"].data_ptr()
-                Lr.z, Lr.ldz = g["y"].ptr, g["y"].ld
-                y = sg["y"]
-                if plan.is_half_only(y):
-                    Lr.y = None
-                else:
-                    Lr.y, Lr.ldy = y.ptr, y.ld
-                if plan.has_shadow(y):
-                    Lr.yh, Lr.ldyh = plan.shadow_view(y)
-                else:
-                    Lr.yh = None
-        self._keep = [a]
-        # the launches this one stands for: the linears', the BatchNorms' and the head's forward (anything else that was queued in
-        # between — a shadow conversion of an input — stays)
-        mine = set()
-        for lin, bn in layers:
-            mine.update(id(s_) for s_ in getattr(lin, "_fwd_calls", []))
-            mine.update(id(s_) for s_ in getattr(bn, "_fwd_calls", []))
-        mine.update(id(s_) for s_ in getattr(head, "_fwd_calls", []))
-        before = len(plan.fwd_steps)
-        plan.fwd_steps[self.marker.pos:] = [s_ for s_ in plan.fwd_steps[self.marker.pos:] if id(s_) not in mine]
-        if before - len(plan.fwd_steps) != 2 * len(layers) + 1:
-            raise RuntimeError("fused tower launch: the launches it replaces were not found in the plan")
-        plan.fwd_steps.append(plan.call("cdc_tower_fwd", C.byref(a)))
-
-    def build_bwd(self, plan, gs):
-        pass
 
 
 class CrossLayer:

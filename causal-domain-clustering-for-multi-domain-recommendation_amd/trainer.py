@@ -67,6 +67,7 @@ class TrainStep:
         self._stage_graphs = {}
         self._dp_seq = None
         self._warm = 0
+        self._reg_checked = False
         if table_dist is None:
             table_dist = "sharded" if optimizer.table_mode == "lazy" else "replicated"
         assert table_dist in ("sharded", "replicated")
@@ -211,10 +212,11 @@ class TrainStep:
         (run.py:489: `loss += get_regularization_loss()`, i.e. l2 * sum(w^2) over the WHOLE table, model/layer.py:31,96-112).  The
         value is exact for the weights the NEXT step's forward sees, and is what `step()` adds to its reg figure until the next
         refresh (per step it changes by ~lr * 2 * l2 * sum|w|: 2e-8 relative at the reference's settings).  One pass over
-        the table: call it where the reference's value is looked at (the logging steps of train_epoch), not every step."""
-        if self.opt.table_mode == "lazy":
-            self.opt.table_reg.copy_(self.opt.table_reg_loss())
-        return self.opt.table_reg
+        the table: called when the step is built, at the start of an epoch and where the reference's value is looked at (the
+        logging steps of train_epoch / CDCTrainer), not every step.  Row-sharded table: every rank sums the rows it owns and the
+        figures are added up across ranks (a collective: call it on every rank)."""
+        sharded = self.dp_on and self.table_dist == "sharded"
+        return self.opt.refresh_table_reg(self.dist if sharded else None)
 
     def _launch_all(self):
         """single GPU: the whole step is one launch sequence (one hipGraph when use_graph)."""
@@ -468,6 +470,12 @@ class TrainStep:
             self.y.copy_(yf)
             if gdst is not None:
                 gdst.copy_(gf)
+        if not self._reg_checked:
+            # the first reported loss of a lazy run carries the table's L2 term like every later one (a freshly built or loaded
+            # optimiser has not evaluated it yet)
+            self._reg_checked = True
+            if self.opt.table_mode == "lazy" and not self.opt.table_reg_ready:
+                self.refresh_table_reg()
         if self.dp_on:
             self._step_dp()
         elif self.use_graph and self._warm >= 2:

@@ -698,60 +698,6 @@ int cdc_head_bwd(const cdc_head_args* a, void* stream);
 int64_t cdc_head_workspace_floats(const cdc_head_args* a);
 
 /* ------------------------------------------------------------------------------------------
- * Tower stacks in ONE forward launch (bf16 contractions): for every tower its hidden layers
- * [Linear -> BatchNorm1d -> ReLU -> Dropout] x n_layer (reference: MultiLayerPerceptron, model/layer.py:178-206, as built by
- * BaseModel.build_tower_output model/layer.py:37-46), the output Linear(->1), `y_logits += other` (wide term and further
- * addends, model/layer.py:50-55) and the Sigmoid.  A tower's layers are a few MFLOP: as separate launches (two grouped
- * linears, two BatchNorm, one head) they cost five launch latencies (47 us of the C2 step).  Here a workgroup owns 64 rows
- * of one tower; the batch statistics of a layer are exchanged through `partial` between two grid-wide barriers (`sync`
- * counters; every workgroup of the launch must be resident at once — the entry point checks that against the device's
- * occupancy and refuses otherwise), everything else stays in registers / LDS.  Writes what the (unfused) backward launches
- * read: every layer's pre-norm output z (fp32), its post-activation output (fp32 and/or bf16), the saved batch statistics,
- * the running statistics, and out[M, n_tower].  training == 0: running statistics, no barriers.
- * Sizes: K0 and every H a multiple of 16, at most CDC_TOWER_MAX_DIM; bf16 operands readable up to the next multiple of 32
- * columns (the zero-padded copies of this library are).
- * ---------------------------------------------------------------------------------------- */
-#define CDC_TOWER_MAX 8
-#define CDC_TOWER_MAX_LAYERS 3
-#define CDC_TOWER_MAX_DIM 128
-typedef struct {
-    const void* wh; int64_t ldwh;         /* bf16 [H, >= K rounded up to 32] copy of the weight */
-    const float* bias;                    /* [H] or NULL */
-    const float* gamma; const float* beta;
-    float* running_mean; float* running_var; int64_t* num_batches_tracked;
-    float* save_mean; float* save_invstd; /* [H] (training) */
-    float* z; int64_t ldz;                /* [M,H] pre-norm output, fp32 */
-    float* y; int64_t ldy;                /* [M,H] post-activation output fp32, or NULL */
-    void* yh; int64_t ldyh;               /* [M,H] post-activation output bf16, or NULL */
-} cdc_tower_layer;
-typedef struct {
-    const void* xh; int64_t ldxh;         /* [M,K0] input, bf16 */
-    const float* w_out; const float* b_out;   /* output layer [H_last], [1] or NULL */
-    cdc_tower_layer l[CDC_TOWER_MAX_LAYERS];
-} cdc_tower_desc;
-typedef struct {
-    int32_t n_tower, n_layer, K0, training;
-    int32_t H[CDC_TOWER_MAX_LAYERS]; int32_t sigmoid;
-    int64_t M;
-    float eps, momentum, drop_p, pad_;
-    uint64_t seed; const int32_t* seed_offset_dev;
-    float* out; int64_t ld_out;           /* [M, n_tower] */
-    const float* wide_x; int64_t ld_wide; /* [M, wide_K] or NULL (the wide term's input) */
-    const float* wide_w; const float* wide_bias;
-    float* wide_out; int64_t ld_wide_out; /* optional [M,1] copy of the wide logit */
-    int32_t wide_K, n_addend;
-    const float* addend[2]; int64_t ld_addend[2];
-    double* partial;                      /* >= cdc_tower_fwd_workspace_doubles() */
-    int32_t* sync;                        /* CDC_TOWER_MAX_LAYERS + 1 counters, zero before the first launch (left zero by every launch) */
-    int32_t* err;                         /* set to 1 when a barrier gave up waiting (results are then undefined) */
-    cdc_tower_desc t[CDC_TOWER_MAX];
-} cdc_tower_args;
-int cdc_tower_fwd(const cdc_tower_args* a, void* stream);
-int64_t cdc_tower_fwd_workspace_doubles(int64_t M, int32_t n_tower, int32_t n_layer);
-/* 1 if a launch of this shape can run (every workgroup resident at once on the current device), 0 if not, <0 on error */
-int cdc_tower_fwd_fits(int64_t M, int32_t n_tower);
-
-/* ------------------------------------------------------------------------------------------
  * Loss (reference: run.py:484,723 — BCELoss(mean) on probabilities gathered by group column,
  * log clamped at -100; backward as aten::binary_cross_entropy_backward with eps 1e-12)
  *   p [B, n_col]; group [B] int64 column per row (NULL => column 0); y int16/float labels.

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+# a kernel fault should end the test run, not spend minutes writing a GPU core dump first (must be set before the runtime starts)
+os.environ.setdefault("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

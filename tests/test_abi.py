@@ -50,7 +50,6 @@ STRUCTS = {
     "cdc_shadow_args": "ShadowArgs", "cdc_head_tower": "HeadTower", "cdc_head_args": "HeadArgs",
     "cdc_mid_gate1": "MidGate1", "cdc_mid_expert2": "MidExpert2", "cdc_mid_gate2": "MidGate2", "cdc_cgc_mid_fwd_args": "CgcMidFwdArgs",
     "cdc_mid_bgate1": "MidBGate1", "cdc_mid_bexpert2": "MidBExpert2", "cdc_mid_bgate2": "MidBGate2", "cdc_cgc_mid_bwd_args": "CgcMidBwdArgs",
-    "cdc_tower_layer": "TowerLayer", "cdc_tower_desc": "TowerDesc", "cdc_tower_args": "TowerArgs",
 }
 
 
@@ -84,7 +83,7 @@ def test_limits_match_the_header():
                        ("CDC_MAX_SEL", _lib.MAX_SEL), ("CDC_MAX_BN_SEGS", _lib.MAX_BN_SEGS), ("CDC_SORT_MAX_B", _lib.SORT_MAX_B), ("CDC_SORT_MAX_ROWS", _lib.SORT_MAX_ROWS),
                        ("CDC_BN_ROWS_PER_BLOCK", _lib.BN_ROWS_PER_BLOCK), ("CDC_ROWDOT_PARTS", _lib.ROWDOT_PARTS),
                        ("CDC_G2_MAX_OUT", _lib.G2_MAX_OUT), ("CDC_G2_MAX_SEG", _lib.G2_MAX_SEG), ("CDC_HEAD_MAX_TOWERS", _lib.HEAD_MAX_TOWERS),
-                       ("CDC_TOWER_MAX", _lib.TOWER_MAX), ("CDC_TOWER_MAX_LAYERS", _lib.TOWER_MAX_LAYERS), ("CDC_TOWER_MAX_DIM", _lib.TOWER_MAX_DIM)]:
+                       ]:
         m = re.search(rf"#define\s+{macro}\s+(\d+)", src)
         assert m and int(m.group(1)) == val, macro
 

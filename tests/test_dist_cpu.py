@@ -1,4 +1,4 @@
-"""The N>1 exchange pattern of the training step rehearsed on CPU: world_size 2, gloo backend, the package's own
+"""The N>1 exchange pattern of the training step rehearsed on CPU: world sizes 2, 3 and 8, gloo backend, the package's own
 DataParallel helper, the CPU oracle standing in for the kernels (the HIP path cannot run without a GPU).
 
 Checked: sharded step == single step on the concatenated batch — (1) ONE sum all-reduce of the flat dense-gradient
@@ -98,8 +98,8 @@ def _worker(rank, world, port, out_dir):
     dp.close()
 
 
-def test_two_rank_exchange_equals_single_process(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_n_rank_exchange_equals_single_process(tmp_path, world):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
@@ -119,8 +119,9 @@ def test_two_rank_exchange_equals_single_process(tmp_path):
         got_table = _table_grad(o["idx_all"], o["dE_all"], R, D)
         assert torch.allclose(got_table, want_table, rtol=1e-5, atol=1e-7)
         assert abs(float(o["loss"]) - float(loss)) < 1e-6
-    # both ranks hold identical exchanged data -> identical table update on every replica
-    assert torch.equal(outs[0]["dE_all"], outs[1]["dE_all"]) and torch.equal(outs[0]["arena"], outs[1]["arena"])
+    # every rank holds identical exchanged data -> identical table update on every replica
+    for o in outs[1:]:
+        assert torch.equal(outs[0]["dE_all"], o["dE_all"]) and torch.equal(outs[0]["arena"], o["arena"])
 
 
 # ---- the row-sharded table protocol (trainer._dp_sequence_sharded) rehearsed with numpy standing in for the kernels -------
@@ -189,10 +190,11 @@ def _worker_sharded(rank, world, port, out_dir):
     dp.close()
 
 
-def test_two_rank_row_sharded_table_exchange(tmp_path):
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_n_rank_row_sharded_table_exchange(tmp_path, world):
     """ids -> owners, rows -> requesters, row gradients -> owners (three equal-split all-to-alls): every rank sees exactly
-    the rows a plain gather gives, and the owners' gradients together are the single-process table gradient."""
-    world = 2
+    the rows a plain gather gives, and the owners' gradients together are the single-process table gradient.  World sizes 2, 3
+    (uneven ownership) and 8 (the target node)."""
     mp.spawn(_worker_sharded, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from oracle import cdc_oracle as O

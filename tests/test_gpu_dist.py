@@ -33,11 +33,20 @@ def _data(world):
     X = np.stack([rng.integers(0, d, size=n) for d in FD], axis=1).astype(np.int32)
     y = rng.integers(0, 2, size=n).astype(np.int16)
     g = X[:, 4].astype(np.int64)
+    if os.environ.get("CDC_TEST_GROUPS") == "cdc":                # C4: the tower of a row is the CLUSTER of its domain (30 -> 4)
+        g = np.array([(3 * d + 1) % 4 for d in range(30)], dtype=np.int64)[X[:, 0]]
     return X, y, g
 
 
 def _build(kind, dev):
     D = int(os.environ.get("CDC_TEST_EMB_DIM", "8"))            # (spawned workers inherit the environment)
+    if kind == "cdcple":
+        # BASELINE config C4 in small: CDC(base='ple'), 30 domains (field 0) -> 4 clusters, emb_dim 32, nested expert dims
+        import types
+        from cdcmdr_amd.model.cdc import CDC
+        cfg = types.SimpleNamespace(ple_n_expert_specific=2, ple_n_expert_shared=2, dataset_name="t", use_atten=False, use_dcn=False)
+        cdc = CDC(FD, 32, 4, 30, "ple", ((32, 16), (8,)), (8, 4), 0, n_causal_mask=2, device=dev, dropout=0.0, config=cfg)
+        return cdc.base_model_instance.to(dev).set_precision("f32"), "multi"
     if kind == "star":
         from cdcmdr_amd.model.star import STAR
         return STAR(FD, D, 3, (32, 16), domain_idx=4, dropout=0.0).to(dev).set_precision("f32"), "star"
@@ -140,6 +149,34 @@ def test_two_ranks_stay_identical(cuda, tmp_path, table_mode, use_graph, table_d
     moved = (w - w0).abs()
     big = w0.abs() > 0.1
     assert float(moved[big].min()) > 0.9e-3 * STEPS and float(moved[big].max()) < 1.1e-3 * STEPS
+
+
+def test_two_ranks_cdc_ple_row_sharded_equals_one_rank(cuda, tmp_path, monkeypatch):
+    """BASELINE config C4's composition — CDC(base='ple') with 30 domains grouped into 4 cluster towers, emb_dim 32, trained in
+    split mode on the lazy table, the table row-sharded over the ranks (ids / rows / row gradients by all-to-all): two ranks on
+    shards == one rank on the concatenated batches, replicas identical after gather_table()."""
+    monkeypatch.setenv("CDC_TEST_GROUPS", "cdc")
+    monkeypatch.chdir(tmp_path)
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "lazy", False, "sharded", True, "cdcple"), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
+    assert r0["losses"] == r1["losses"] and all(np.isfinite(r0["losses"]))
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), f"replicas diverged in {k}"
+    from helpers import assert_close, is_pre_bn_bias
+    ref_sd, ref_losses = _single_process_reference("lazy", kind="cdcple")
+    for a, b in zip(r0["losses"], ref_losses):
+        assert abs(a - b) < 2e-5, (r0["losses"], ref_losses)
+    names = set(ref_sd)
+    for k, v in ref_sd.items():
+        if is_pre_bn_bias(k, names) or "num_batches" in k:
+            continue
+        # a running mean contains the (noise-driven, +-lr per step) bias of the Linear in front of it: 0.1 * sum over STEPS steps
+        atol = 3e-3 if k.endswith("running_mean") else 2e-5
+        assert_close(r0["sd"][k], v, 5e-4, atol, f"2-rank vs 1-rank: {k}")
+    g = _data(world)[2]
+    assert sorted(set(g.tolist())) == [0, 1, 2, 3]
 
 
 def test_two_ranks_with_per_rank_batchnorm_statistics(cuda, tmp_path):

@@ -1,7 +1,7 @@
 """The bf16-operands-from-memory contraction path (csrc/gemm2.hip) through the C-ABI.
 
 Checked (a) against the same arithmetic restated on the CPU in double on the bf16-rounded operands, and (b) bit for bit against
-the register-staged bf16 path of csrc/gemm.hip (CDC_GEMM2=0), which rounds the same fp32 values to the same bf16 operands and
+the register-staged bf16 path of csrc/gemm.hip (Plan(g2=False): what ragged launches take), which rounds the same fp32 values to the same bf16 operands and
 accumulates the same K-slabs in the same order."""
 import ctypes as C
 
@@ -95,8 +95,7 @@ def test_grad_input_segments_mask_and_accumulate(cuda):
 
 def _run_plan(cuda, monkeypatch, g2, M, K, Ns, seed):
     from cdcmdr_amd import plan as P
-    monkeypatch.setenv("CDC_GEMM2", "1" if g2 else "0")
-    plan = P.Plan(cuda, M, precision="bf16", training=True, dropout=0.0)
+    plan = P.Plan(cuda, M, precision="bf16", training=True, dropout=0.0, g2=g2)
     assert plan.use_g2 == g2
     gen = torch.Generator().manual_seed(seed)
     xb = plan.new(K)

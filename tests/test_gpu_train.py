@@ -257,6 +257,44 @@ def test_train_epoch_over_a_device_loader_with_a_ragged_last_batch(cuda):
         assert_close(got[k], s2[k].detach(), 5e-4, atol, f"epoch: {k}")
 
 
+def test_first_logged_loss_of_a_lazy_run_carries_the_tables_l2_term(cuda):
+    """run.py:489 adds l2 * sum(w^2) over the WHOLE table to every reported loss.  The lazy table caches that term
+    (TrainStep.refresh_table_reg); a freshly built step must have it from the very first logging window: the values
+    train_epoch logs on the lazy table equal the dense-mode values, where the term is summed every step."""
+    from cdcmdr_amd.data import make_loader, train_epoch
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = FD_SPARSE
+    rng = np.random.default_rng(8)
+    n = 96
+    X = torch.from_numpy(make_ids(rng, n, fd))
+    X[:, 2] = torch.from_numpy(rng.integers(0, 3, size=n).astype(np.int32))
+    y = torch.from_numpy(rng.integers(0, 2, size=(n, 1)).astype(np.int16))
+    logged = {}
+    for table_mode in ("dense", "lazy"):
+        torch.manual_seed(21)
+        model = PLE(fd, 4, 3, 2, 2, ((32, 16), (8,)), (8, 4), dropout=0.0).to(cuda).set_precision("f32")
+        loader, _ = make_loader(X, y, 32, cuda, domain_idx=2, domain2group={0: 0, 1: 1, 2: 2}, shuffle=False)
+        opt = FusedAdam(model, table_mode=table_mode, fast_replay=False)
+        ts = TrainStep(model, opt, 32)
+        out = []
+        train_epoch(ts, loader, log_interval=1, log=out.append)
+        logged[table_mode] = out
+        # and without train_epoch: the very first step() of a new TrainStep reports the term as well
+        torch.manual_seed(21)
+        model2 = PLE(fd, 4, 3, 2, 2, ((32, 16), (8,)), (8, 4), dropout=0.0).to(cuda).set_precision("f32")
+        ts2 = TrainStep(model2, FusedAdam(model2, table_mode=table_mode, fast_replay=False), 32)
+        bce, reg = ts2.step(X[:32].to(cuda), y[:32, 0].to(cuda), X[:32, 2].to(torch.int64).to(cuda))
+        logged[table_mode + "_first"] = float(bce.item()) + float(reg.item())
+    table_term = 1e-5 * float((model.embedding.embedding_dict.weight.detach().double() ** 2).sum())
+    assert table_term > 1e-3                                        # a term that would be missed, not a rounding matter
+    for a, b in zip(logged["dense"], logged["lazy"]):
+        assert abs(a - b) < 1e-6 * max(1.0, abs(a)), (logged["dense"], logged["lazy"])
+    assert abs(logged["dense_first"] - logged["lazy_first"]) < 1e-6 * max(1.0, abs(logged["dense_first"]))
+    assert abs(logged["dense"][0] - logged["dense_first"]) < 1e-9
+
+
 def test_star_fast_path_matches_the_oracle(cuda):
     """TrainStep(mode="star"): rows partitioned by domain, every partition through its own tower + the shared one
     (star.py:109-181), BCE on the group-ordered targets (run.py:476-479) — two steps against the oracle's grouped forward

@@ -15,6 +15,9 @@ Sides (each trains from the same state on the same batches in the same order, th
     ref_perm<k>  the same with the rows of every batch in a seeded random order (k = 1, 2, ...): further samples of that
                  floor, so that the band the HIP sides are held to is a distribution and not one pair.
     oracle       oracle/cdc_oracle.py (the CPU restatement) with the same loop.
+    oracle_bf16[_perm<k>]  the restatement with the operands of every contraction rounded to bf16 where the kernels round them
+                 (fp32 accumulate): the CPU statement of the bf16 path's arithmetic, plain and with reordered batches — the
+                 spread the bf16 HIP side is entitled to on top of the reference's own.
     hip_f32 / hip_bf16   the HIP path (TrainStep, lazy table, hipGraph) with exact-fp32 / bf16 contractions.  Needs a GPU.
 
 Every side writes <out>/<side>.npy (float32 predictions of the evaluation rows' own tower); `--summarise` turns whatever
@@ -52,6 +55,7 @@ def parse():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--id-dist", default="uniform")
     ap.add_argument("--teacher-std", type=float, default=0.3)
+    ap.add_argument("--fixture", default="", help="with --summarise: also write the CPU sides as a test fixture (tests/golden/auc_parity_*.json)")
     return ap.parse_args()
 
 
@@ -127,9 +131,12 @@ def side_ref(args, fd, sd0, train, ev, reverse, perm_seed=None):
     return np.concatenate(out).astype(np.float32)
 
 
-def side_oracle(args, fd, sd0, train, ev):
+def side_oracle(args, fd, sd0, train, ev, bf16=False, perm_seed=None):
+    """bf16: the restatement rounds the operands of every contraction to bf16 where the kernels do (fp32 accumulate) — the CPU
+    statement of the arithmetic the bf16 HIP path runs; perm_seed: rows of every batch in a seeded random order."""
     import torch
     from oracle import cdc_oracle as O
+    O.MATMUL_BF16 = bool(bf16)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd0.items() if v.dtype.is_floating_point and "running_" not in k}
     sd = dict(sd0)
     sd.update(leaves)
@@ -139,10 +146,14 @@ def side_oracle(args, fd, sd0, train, ev):
     t0 = time.time()
     for s in range(args.steps):
         sl = slice(s * B, (s + 1) * B)
+        xs, ys, gs = Xtr[sl], ytr[sl], gtr[sl]
+        if perm_seed is not None:
+            pi = np.random.Generator(np.random.PCG64(1_000_003 * perm_seed + s)).permutation(B)
+            xs, ys, gs = xs[pi].copy(), ys[pi].copy(), gs[pi].copy()
         stats = {}
-        p = O.ple_forward(sd, Xtr[sl], fd, N_DOMAIN, training=True, stats_out=stats)
-        p = p.gather(1, torch.from_numpy(gtr[sl]).reshape(-1, 1)).squeeze(1)
-        loss = O.bce_mean(p, torch.from_numpy(ytr[sl].astype(np.float32))) + O.reg_loss(sd, l2).sum()
+        p = O.ple_forward(sd, xs, fd, N_DOMAIN, training=True, stats_out=stats)
+        p = p.gather(1, torch.from_numpy(gs).reshape(-1, 1)).squeeze(1)
+        loss = O.bce_mean(p, torch.from_numpy(ys.astype(np.float32))) + O.reg_loss(sd, l2).sum()
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -156,6 +167,7 @@ def side_oracle(args, fd, sd0, train, ev):
         for i in range(0, len(Xev), 16384):
             p = O.ple_forward(sde, Xev[i:i + 16384], fd, N_DOMAIN, training=False)
             out.append(p.gather(1, torch.from_numpy(gev[i:i + 16384]).reshape(-1, 1)).squeeze(1).numpy())
+    O.MATMUL_BF16 = False
     return np.concatenate(out).astype(np.float32)
 
 
@@ -194,6 +206,7 @@ def summarise(args, ev, init_hash=None):
            "sides": {}}
     preds = {}
     names = ["ref", "ref_rev"] + sorted(f[:-4] for f in os.listdir(args.out) if f.startswith("ref_perm") and f.endswith(".npy"))
+    names += sorted(f[:-4] for f in os.listdir(args.out) if f.startswith("oracle_bf16") and f.endswith(".npy"))
     for name in names + ["oracle", "hip_f32", "hip_bf16"]:
         path = os.path.join(args.out, name + ".npy")
         if os.path.exists(path):
@@ -228,6 +241,17 @@ def summarise(args, ev, init_hash=None):
     path = os.path.join(args.out, "summary.json")
     json.dump(res, open(path, "w"), indent=1)
     print(json.dumps(res, indent=1))
+    if getattr(args, "fixture", ""):
+        cpu = {k: {f: v[f] for f in ("auc", "logloss", "domain_auc")} for k, v in res["sides"].items() if not k.startswith("hip_")}
+        any_side = next(iter(res["sides"].values()))
+        fx = {"config": dict(res["config"], teacher_std=float(getattr(args, "teacher_std", 0.3))),
+              "init_sha": any_side.get("init_sha"), "torch": any_side.get("torch"), "cpu_sides": cpu,
+              "cpu_vs_cpu_floor": res.get("cpu_vs_cpu_floor"), "ref_reorderings": res.get("ref_reorderings"),
+              "bf16_restatement_runs": sorted(k for k in cpu if k.startswith("oracle_bf16")),
+              "made_by": "tools/auc_parity.py --sides ref,ref_rev,ref_perm1..5,oracle (build container, imports /root/reference/model/ple.py) "
+                         "+ --summarise --fixture"}
+        json.dump(fx, open(args.fixture, "w"), indent=1)
+        print("wrote", args.fixture)
     return res
 
 
@@ -256,6 +280,9 @@ def main():
             p = side_ref(args, fd, sd0, train, ev, reverse=False, perm_seed=int(side[len("ref_perm"):]))
         elif side == "oracle":
             p = side_oracle(args, fd, sd0, train, ev)
+        elif side.startswith("oracle_bf16"):
+            tail = side[len("oracle_bf16"):]
+            p = side_oracle(args, fd, sd0, train, ev, bf16=True, perm_seed=int(tail[5:]) if tail.startswith("_perm") else None)
         elif side in ("hip_f32", "hip_bf16"):
             p = side_hip(args, fd, model, sd0, train, ev, side[4:])
         else:

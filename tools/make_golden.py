@@ -268,6 +268,46 @@ def main():
         arrays["reg"] = _np(cdc.get_regularization_loss(device="cpu"))
         _save(f"g5_cdc_{base}", **arrays)
 
+    # ---------------------------------------------------------------- G5b CDC(base='ple') TRAINED in split mode: the shape of
+    # BASELINE config C4 (30 domains -> 4 clusters, emb_dim 32, nested expert dims: cdc.py:32-42) driven like run.py:635-640 —
+    # two single-domain batches (mode='split', domain_i=d) and one mixed batch (domain_i=None), Adam on every parameter
+    n_dom4, n_clu4, dom_idx4, D4, B4 = 30, 4, 2, 32, 48
+    fd_c4 = [40, 900, n_dom4, 300, 9]
+    d2g4 = np.array([(3 * d + 1) % n_clu4 for d in range(n_dom4)], dtype=np.int64)
+    torch.manual_seed(SEED)
+    cdc = CDC(fd_c4, D4, n_clu4, n_dom4, "ple", ((32, 16), (8,)), (8, 4), dom_idx4,
+              domain_cnt_weight=np.full(n_dom4, 1.0 / n_dom4), n_causal_mask=4, dropout=0.0, config=cdc_config())
+    cdc.domain2group = torch.from_numpy(d2g4)
+    cdc.domain2group_list = d2g4.tolist()
+    opt = torch.optim.Adam(params=cdc.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8)
+    arrays = {"domain2group": d2g4, "domain_idx": np.array(dom_idx4), "field_dims": np.array(fd_c4)}
+    arrays.update(_pack_sd("sd0", cdc.state_dict()))
+    cdc.train()
+    for s_, dom in enumerate([7, 22, None]):
+        xx = _ids(rng, B4, fd_c4)
+        xx[:, 1] = np.minimum(xx[:, 1], 700)               # rows 701..899 of field 1 are never looked up (F3)
+        if dom is not None:
+            xx[:, dom_idx4] = dom                          # run.py:631: a batch of ONE domain
+        yy = rng.integers(0, 2, size=(B4, 1)).astype(np.int16)
+        pred = cdc(torch.from_numpy(xx), mode="split", domain_i=dom)
+        loss = crit(pred.squeeze(), torch.from_numpy(yy).squeeze().float())
+        bce = loss.detach().clone()
+        reg = cdc.get_regularization_loss(device="cpu")
+        loss = loss + reg
+        cdc.zero_grad()
+        loss.backward()
+        opt.step()
+        arrays[f"x{s_}"], arrays[f"y{s_}"] = xx, yy
+        arrays[f"domain{s_}"] = np.array(-1 if dom is None else dom)
+        arrays[f"bce{s_}"], arrays[f"reg{s_}"] = _np(bce), _np(reg)
+        arrays.update(_pack_sd(f"sd{s_ + 1}", cdc.state_dict()))
+    st = opt.state_dict()["state"]
+    for i, (k, _) in enumerate(cdc.named_parameters()):
+        if i in st:
+            arrays[f"m3/{k}"] = _np(st[i]["exp_avg"])
+            arrays[f"v3/{k}"] = _np(st[i]["exp_avg_sq"])
+    _save("g5_cdc_ple_adam", **arrays)
+
     # ---------------------------------------------------------------- G6 batch of one
     x1 = x[:1].copy()
     arrays = {"x": x1, "x13": x13[:1].copy()}
