@@ -1067,13 +1067,15 @@ extern "C" int cdc_embed_lazy_catchup(const int32_t* uniq_row, const int32_t* un
 // write its positions side by side — the hot row is read from HBM once per step, however many samples carry it.
 // Ids outside the table (row -1 in the sorted lists) yield zero rows, like cdc_embed_gather_fwd.
 // ------------------------------------------------------------------------------------------------
+#define CG_HOT 32                       /* a row looked up by more than this many samples of the batch is a HOT row */
 template <bool FAST>
 __global__ void __launch_bounds__(256) k_lazy_catchup_gather(const int32_t* __restrict__ uniq_row, const int32_t* __restrict__ uniq_cnt,
                                                              const int32_t* __restrict__ seg_start, const int32_t* __restrict__ perm,
                                                              float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                              int32_t* __restrict__ last, cdc_adam_hp hp,
                                                              const int32_t* __restrict__ step_dev, float* __restrict__ out,
-                                                             __bf16* __restrict__ out_h, int64_t ld_out_h, int32_t B, int32_t F, int32_t D) {
+                                                             __bf16* __restrict__ out_h, int64_t ld_out_h, int32_t B, int32_t F, int32_t D,
+                                                             int32_t n_short_blocks, int32_t hot_cap) {
     typedef __bf16 h4_t __attribute__((ext_vector_type(4)));
     const AdamConsts c = make_consts(hp);
     const int target = *step_dev - 1;
@@ -1088,8 +1090,70 @@ __global__ void __launch_bounds__(256) k_lazy_catchup_gather(const int32_t* __re
             *reinterpret_cast<h4_t*>(out_h + (int64_t)b * ld_out_h + (int64_t)f * D + ch * 4) = h;
         }
     };
+    if ((int)blockIdx.x >= n_short_blocks) {
+        // ---- HOT rows of one field (a domain column: three rows with ~B/3 positions each; the head of a Zipf distribution): the
+        //      workgroup lists them, brings all of them up to date in one pass (a thread per (row, 16-byte chunk)), keeps the
+        //      current rows in LDS and writes every position that looks one of them up with all 256 threads — a hot row is read
+        //      from HBM once per step however many samples carry it.  The other workgroups skip these rows.
+        extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
+        __shared__ int n_hot;
+        // hot_cap = B / CG_HOT + 1 rounded up to 4: no more than that many rows can each hold more than CG_HOT of a field's B lookups
+        int32_t* hot_j = reinterpret_cast<int32_t*>(cg_smem);                      // [hot_cap] unique-row slots of the hot rows
+        float4* stage = reinterpret_cast<float4*>(hot_j + hot_cap);                // [hot_cap][chunks] the rows as the forward sees them
+        const int f = (int)blockIdx.x - n_short_blocks;
+        const int cnt = uniq_cnt[f];
+        const int32_t* ss = seg_start + (int64_t)f * (B + 1);
+        if (threadIdx.x == 0) n_hot = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += blockDim.x)
+            if (ss[j + 1] - ss[j] > CG_HOT) {
+                const int slot = atomicAdd(&n_hot, 1);                             // (the order of the list changes no result)
+                if (slot < hot_cap) hot_j[slot] = j;
+            }
+        __syncthreads();
+        const int nh = n_hot < hot_cap ? n_hot : hot_cap;                          // (n_hot <= B / CG_HOT < hot_cap by counting)
+        const int n_item = nh * chunks;
+        // uniform trip count: every lane of a wave reaches the replay
+        for (int base = 0; base < n_item; base += blockDim.x) {
+            const int i = base + threadIdx.x;
+            const bool has = i < n_item;
+            const int hs = has ? i / chunks : 0, ch = has ? i % chunks : 0;
+            const int64_t row = has ? uniq_row[(int64_t)f * B + hot_j[hs]] : -1;
+            const bool real = has && row >= 0;
+            int from = real ? last[row] : target;
+            const bool act = real && from < target;
+            if (!act) from = target;
+            const int64_t e0 = real ? row * D + ch * 4 : 0;
+            float wv[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {1.f, 1.f, 1.f, 1.f};
+            if (real) { const float4 a4 = *reinterpret_cast<const float4*>(w + e0); wv[0] = a4.x; wv[1] = a4.y; wv[2] = a4.z; wv[3] = a4.w; }
+            if (act) {
+                const float4 b4 = *reinterpret_cast<const float4*>(m + e0), c4 = *reinterpret_cast<const float4*>(v + e0);
+                mv[0] = b4.x; mv[1] = b4.y; mv[2] = b4.z; mv[3] = b4.w;
+                vv[0] = c4.x; vv[1] = c4.y; vv[2] = c4.z; vv[3] = c4.w;
+            }
+            adam_replay_wave<FAST, 4>(wv, mv, vv, from, target, c, hp);
+            if (act) {
+                *reinterpret_cast<float4*>(w + e0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+                *reinterpret_cast<float4*>(m + e0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+                *reinterpret_cast<float4*>(v + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                if (ch == 0) last[row] = target;
+            }
+            if (has) stage[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);            // (ids outside the table: a zero row)
+        }
+        __syncthreads();
+        for (int hs = 0; hs < nh; ++hs) {
+            const int j = hot_j[hs];
+            const int p0 = ss[j], n = ss[j + 1] - p0;
+            for (int q = threadIdx.x; q < n * chunks; q += blockDim.x) {
+                const int b = perm[(int64_t)f * B + p0 + q / chunks], ch = q % chunks;
+                const float4 x = stage[hs * chunks + ch];
+                put(b, f, ch, x.x, x.y, x.z, x.w);
+            }
+        }
+        return;
+    }
     // uniform trip count and no early exits: every lane of a wave reaches the replay and the wave-cooperative part
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)n_short_blocks * blockDim.x) {
         const int64_t i = base + threadIdx.x;
         bool has = i < total;                                           // this lane belongs to a unique row of the batch
         int ch = 0, f = 0, j = 0, from = target;
@@ -1106,6 +1170,7 @@ __global__ void __launch_bounds__(256) k_lazy_catchup_gather(const int32_t* __re
             row = uniq_row[(int64_t)f * B + j];
             p0 = seg_start[(int64_t)f * (B + 1) + j];
             n = seg_start[(int64_t)f * (B + 1) + j + 1] - p0;
+            has = n <= CG_HOT;                                          // hot rows belong to their field's workgroup (above)
         }
         const bool real = has && row >= 0;                              // < 0: ids outside the table (zero rows)
         if (real) from = last[row];
@@ -1184,14 +1249,19 @@ extern "C" int cdc_embed_lazy_catchup_gather(const int32_t* uniq_row, const int3
     CDC_CHECK_ARG(!out_h || (ld_out_h >= (int64_t)F * D && ld_out_h % 4 == 0 && (((uintptr_t)out_h) & 7) == 0), CDC_E_BADARG,
                   "embed_lazy_catchup_gather: malformed bf16 shadow");
     CDC_CHECK_ARG(!hp.fast_replay || hp.inv_bc2, CDC_E_BADARG, "embed_lazy_catchup_gather: fast_replay needs the inv_bc2 table");
+    const int32_t hot_cap = (int32_t)((B / CG_HOT + 1 + 3) / 4 * 4);
     const int64_t total = (int64_t)F * B * (D / 4);
-    int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    const int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 256), 256 * 16);
+    // the F hot-row workgroups go FIRST in dispatch order is not needed: they are short (a few hundred positions per thread at
+    // most) and run beside the others; they sit behind the short blocks in the grid
+    const size_t lds = (size_t)hot_cap * 4 + (size_t)hot_cap * (D / 4) * 16;
+    CDC_CHECK_ARG(lds <= 64 * 1024, CDC_E_TOOBIG, "embed_lazy_catchup_gather: batch too large for the hot-row staging area");
     if (hp.fast_replay)
-        hipLaunchKernelGGL((k_lazy_catchup_gather<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, seg_start, perm,
-                           w, m, v, last, hp, step_dev, out, reinterpret_cast<__bf16*>(out_h), ld_out_h, (int32_t)B, F, D);
+        hipLaunchKernelGGL((k_lazy_catchup_gather<true>), dim3(blocks + F), dim3(256), lds, (hipStream_t)stream, uniq_row, uniq_cnt, seg_start, perm,
+                           w, m, v, last, hp, step_dev, out, reinterpret_cast<__bf16*>(out_h), ld_out_h, (int32_t)B, F, D, blocks, hot_cap);
     else
-        hipLaunchKernelGGL((k_lazy_catchup_gather<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, uniq_row, uniq_cnt, seg_start, perm,
-                           w, m, v, last, hp, step_dev, out, reinterpret_cast<__bf16*>(out_h), ld_out_h, (int32_t)B, F, D);
+        hipLaunchKernelGGL((k_lazy_catchup_gather<false>), dim3(blocks + F), dim3(256), lds, (hipStream_t)stream, uniq_row, uniq_cnt, seg_start, perm,
+                           w, m, v, last, hp, step_dev, out, reinterpret_cast<__bf16*>(out_h), ld_out_h, (int32_t)B, F, D, blocks, hot_cap);
     CDC_LAUNCH_CHECK("embed_lazy_catchup_gather");
     return 0;
 }

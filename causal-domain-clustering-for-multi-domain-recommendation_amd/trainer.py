@@ -222,42 +222,44 @@ class TrainStep:
         """single GPU: the whole step is one launch sequence (one hipGraph when use_graph)."""
         opt, plan, emb = self.opt, self.plan, self.emb
         B, F, D = self.B, emb.F, emb.D
-        if opt.table_mode == "lazy" and self._fuse_gather():
-            # sort -> catch-up of the batch's rows, which also writes the gathered embeddings (+ shadow) -> slice of the whole-table
-            # replay; the plan's own gather launch is skipped
-            oh, ldh = (plan.shadow_view(emb.out) if (plan.use_g2 and plan.has_shadow(emb.out)) else (None, 0))
-            opt.begin_step_catchup_gather(emb.ids, emb.offsets, emb.out.ptr, oh, ldh, B, F, D, err=emb.err)
-            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            for fn in self._fwd_after_gather:
-                fn(st)
-        elif opt.table_mode == "lazy" and self._overlap():
-            # Two chains on two hardware queues (two HIP streams; two branches of the hipGraph when captured):
-            #   main:  sort, catch-up | gather, forward, BCE, backward, grad-weight launches, dense Adam | per-row sums + Adam on the
-            #   side:                 | this step's slice of the whole-table replay                      |   step's rows, reg
-            # The replay slice is VALU-only and touches no row of the batch (those are at step t-1 after the catch-up and are
-            # skipped); it goes out in its background form (a capped grid of two waves per SIMD at the lowest issue priority,
-            # cdc_embed_lazy_flush_bg) and the chain's kernels raise their priority (CDC_PRIO_MAIN), so the slice takes the issue
-            # cycles the chain leaves idle while it waits on L2 / LDS / MFMA results.  The table update needs the slice finished:
-            # it goes last on the main chain, behind the one join.
-            main, side = torch.cuda.current_stream(), self._side_stream()
-            opt.begin_step_catchup(emb.ids, emb.offsets, B, F, D, flush=False)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                opt.flush_slice(background_waves=self._overlap_waves)
-            plan.forward()
+        if opt.table_mode == "lazy":
+            # sort -> catch-up of the batch's rows [which also writes the gathered embeddings (+ shadow): hot rows staged in LDS and
+            # written by a whole workgroup, the plan's own gather launch skipped] -> this step's slice of the whole-table replay.
+            # With the slice in the BACKGROUND, two chains on two hardware queues (two branches of the hipGraph when captured):
+            #   main:  sort, catch-up(+gather) | forward, BCE, backward, grad-weight launches, dense Adam | per-row sums + Adam on the
+            #   side:                          | the slice                                                |   step's rows, reg
+            # The slice is VALU-only and touches no row of the batch (those are at step t-1 after the catch-up and are skipped); it
+            # goes out capped (two waves per SIMD) at the lowest issue priority (cdc_embed_lazy_flush_bg) while the chain's kernels
+            # raise theirs (CDC_PRIO_MAIN): it takes the issue cycles the chain leaves idle while waiting on L2 / LDS / MFMA results.
+            # The table update needs the slice finished: it goes last on the main chain, behind the one join.
+            fused, bg = self._fuse_gather(), self._overlap()
+            if fused:
+                oh, ldh = (plan.shadow_view(emb.out) if (plan.use_g2 and plan.has_shadow(emb.out)) else (None, 0))
+                opt.begin_step_catchup_gather(emb.ids, emb.offsets, emb.out.ptr, oh, ldh, B, F, D, err=emb.err, flush=not bg)
+            else:
+                opt.begin_step_catchup(emb.ids, emb.offsets, B, F, D, flush=not bg)
+            main = torch.cuda.current_stream()
+            if bg:
+                side = self._side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    opt.flush_slice(background_waves=self._overlap_waves)
+            if fused:
+                st = C.c_void_p(main.cuda_stream)
+                for fn in self._fwd_after_gather:
+                    fn(st)
+            else:
+                plan.forward()
             self._bce()
             plan.backward()
             opt.dense_step(plan.param_grads, plan._param_refs)
-            main.wait_stream(side)
+            if bg:
+                main.wait_stream(side)
             opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
             self._reg()
             return
-        elif opt.table_mode == "lazy":
-            opt.begin_step_catchup(emb.ids, emb.offsets, B, F, D)         # + this step's slice of the whole-table replay
-            plan.forward()
-        else:
-            opt.begin_step()
-            plan.forward()
+        opt.begin_step()
+        plan.forward()
         self._bce()
         plan.backward()
         opt.table_step(emb.idx, emb.out.grad.root, B, F, D)

@@ -42,6 +42,12 @@ def assert_close(a, b, rtol, atol, what=""):
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     err = (a - b).abs()
     tol = atol + rtol * b.abs()
+    rec = os.environ.get("CDC_RECORD_MARGINS")
+    if rec and a.numel():
+        # development aid: how much of the stated tolerance each comparison used (profiles/round3/parity_margins.txt)
+        with open(rec, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]}\t{what}\t{float(err.max()):.3e}\t"
+                    f"{float((err / tol).max()):.3e}\t{rtol}\t{atol}\n")
     bad = err > tol
     if bad.any():
         i = int(torch.argmax(err - tol))
@@ -65,10 +71,14 @@ def is_pre_bn_bias(k, names):
     return False
 
 
-BF16_GRAD_MAX, BF16_GRAD_P90, BF16_GRAD_MEDIAN = 2.5e-1, 5e-2, 2.5e-2            # see compare_param_grads
+# bf16 gradient bounds (relative L2 per tensor against the exact-accumulation bf16 restatement), see compare_param_grads:
+# 5e-2 for a tensor, 2.5e-1 only for the SMALL ones a single flipped row dominates (a gate bias of four elements, one of 30 small
+# towers: at most BF16_GRAD_SMALL elements), nine tensors in ten within 5e-2, the median within 2.5e-2
+BF16_GRAD_MAX, BF16_GRAD_MAX_SMALL, BF16_GRAD_SMALL, BF16_GRAD_P90, BF16_GRAD_MEDIAN = 5e-2, 2.5e-1, 2048, 5e-2, 2.5e-2
 
 
-def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=None, bn_active=True, max_rel=None, median_rel=None):
+def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=None, bn_active=True, max_rel=None, median_rel=None,
+                        p90_rel=None):
     """Gradient check per parameter (pre-BatchNorm biases only have to be negligible)."""
     names = set(all_names) if all_names is not None else set(want)
     rels = []
@@ -97,15 +107,17 @@ def compare_param_grads(named_params, want, rtol, atol, bf16=False, all_names=No
             #     HIP bf16 vs the exact restatement:                 MMoE-8 1.8e-2 / 8.5e-3   PLE-3 8.5e-3 / 3.3e-3   STAR-30 1.1e-1 / 4.3e-3
             # (vs the fp32 oracle 1.8e-1 / 1.2e-1: bf16 operand rounding flips ~1e-3 of the units).  So: the MEDIAN over tensors — what a
             # systematic error (a missed term, a wrong rounding point) moves — is held to 3x the worst measured median, nine tensors in
-            # ten to 5e-2, and a single tensor (a gate bias of four elements downstream of a flipped row; one of 30 small towers) to
-            # 2.5e-1.  A model small enough to have no flips is held to 5e-4 in tests/test_gpu_gaps.py.
+            # ten to 5e-2, a single tensor to 5e-2 as well unless it is SMALL (a gate bias of four elements downstream of a flipped row;
+            # one of 30 small towers: <= 2048 elements), which may reach 2.5e-1.  A model small enough to have no flips is held to
+            # 5e-4 in tests/test_gpu_gaps.py, PLE-3's rows without a flip to 5e-4 in tests/test_gpu_cgc_mid.py.
             gd, wd = got.detach().cpu().double(), g.double()
             rel = float((gd - wd).norm() / max(float(wd.norm()), 1e-12))
             rels.append(rel)
-            assert rel < (max_rel or BF16_GRAD_MAX) or float((gd - wd).abs().max()) < 1e-5, f"grad {k}: relative L2 error {rel:.3e} vs bf16 restatement"
+            bound = max_rel or (BF16_GRAD_MAX_SMALL if gd.numel() <= BF16_GRAD_SMALL else BF16_GRAD_MAX)
+            assert rel < bound or float((gd - wd).abs().max()) < 1e-5, f"grad {k} ({gd.numel()} elements): relative L2 error {rel:.3e} vs bf16 restatement (bound {bound})"
         else:
             assert_close(got, g, rtol, atol * max(scale, 1.0), f"grad {k}")
     if bf16 and len(rels) >= 8:
         med, p90 = float(np.median(rels)), float(np.quantile(rels, 0.9))
         assert med < (median_rel or BF16_GRAD_MEDIAN), f"median relative L2 error of the gradient tensors {med:.3e}"
-        assert p90 < (max_rel or BF16_GRAD_P90), f"90th percentile of the gradient tensors' relative L2 errors {p90:.3e}"
+        assert p90 < (p90_rel or BF16_GRAD_P90), f"90th percentile of the gradient tensors' relative L2 errors {p90:.3e}"

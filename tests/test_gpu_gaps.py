@@ -69,7 +69,7 @@ def test_step_with_emb_dim_32_matches_the_oracle(cuda):
     assert_close(opt.table_m.cpu(), ref_opt.state[leaves["embedding.embedding_dict.weight"]]["exp_avg"], 1e-3, 1e-7, "table exp_avg")
 
 
-def _bf16_vs_restatement(cuda, model, forward, B, field_dims, seed, max_rel=None, median_rel=None, mean_prob=2e-4):
+def _bf16_vs_restatement(cuda, model, forward, B, field_dims, seed, max_rel=None, median_rel=None, mean_prob=2e-4, p90_rel=None):
     """forward + every parameter gradient of a bf16 model against the oracle's bf16 restatement (identical rounded operands, exact
     accumulation).  Probabilities: a handful of rows carry a bf16 rounding-boundary flip (max |d| ~1e-3), the rest agree to
     accumulation noise, so the MEAN |d| is bounded as well (measured 4e-5 MMoE-8, 4e-6 STAR-30)."""
@@ -89,7 +89,7 @@ def _bf16_vs_restatement(cuda, model, forward, B, field_dims, seed, max_rel=None
     assert_close(out, ref, 5e-3, 2e-3, "probabilities")
     assert float((out.detach().cpu() - ref).abs().mean()) < mean_prob
     compare_param_grads(dict(model.named_parameters()), grads, 5e-3, 2e-3, bf16=True, all_names=list(sd), bn_active=True,
-                        max_rel=max_rel, median_rel=median_rel)
+                        max_rel=max_rel, median_rel=median_rel, p90_rel=p90_rel or max_rel)
     new_sd = sd_cpu(model)
     for k, v in stats.items():
         assert_close(new_sd[k], v, 5e-3, 2e-3, f"stat {k}")
@@ -126,8 +126,10 @@ def test_star30_bf16_against_the_bf16_restatement(cuda):
     m = STAR(fd, 16, 30, (256, 128, 64, 32), dropout=0.0).to(cuda).set_precision("bf16")
     # 30 towers of 256 rows: a tower with one flipped unit in its 32-wide last layer is ~1e-1 off in all its tensors (measured worst
     # 1.06e-1, tower 13; two CPU restatements against each other: 6.8e-2, tower 6); the median over the 400 tensors is the check
+    # (so the per-tensor bound stays at 2.5e-1 for this model whatever the tensor's size: every tensor of a tower inherits the flip;
+    # nine in ten stay within 5e-2)
     _bf16_vs_restatement(cuda, m, lambda s, x, st: O.star_forward(s, x, fd, 30, training=True, stats_out=st), 256, fd, 8,
-                         median_rel=1.3e-2)
+                         max_rel=2.5e-1, median_rel=1.3e-2, p90_rel=5e-2)
 
 
 @pytest.mark.parametrize("name", ["g2_ple3", "g2_mmoe8", "g2_star30_all", "g2_dcnv2_mix", "g2_dcn13"])

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FD = [7, 100, 3, 50, 11, 29]
 FD13 = [11, 50, 7, 100, 3, 29, 64, 5, 17, 200, 9, 31, 13]
-RTOL, ATOL = 2e-4, 2e-5
+RTOL, ATOL = 2e-5, 2e-6        # 3.6x the worst share measured over 2 239 comparisons (profiles/round3/parity_margins.txt); SURVEY 8c proposed 1e-5 / 1e-6
 
 
 def load(name):

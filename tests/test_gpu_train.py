@@ -253,7 +253,9 @@ def test_train_epoch_over_a_device_loader_with_a_ragged_last_batch(cuda):
     for k in names:
         if is_pre_bn_bias(k, names) or "num_batches" in k:
             continue
-        atol = 5e-4 if k.endswith("running_mean") else 2e-5
+        # a running mean contains the (rounding-noise driven, +-lr per step) bias of the Linear in front of it: up to
+        # momentum * sum over the steps of the difference — 1e-3 after three steps (measured 4.9e-4)
+        atol = 1.5e-3 if k.endswith("running_mean") else 2e-5
         assert_close(got[k], s2[k].detach(), 5e-4, atol, f"epoch: {k}")
 
 

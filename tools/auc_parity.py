@@ -171,7 +171,7 @@ def side_oracle(args, fd, sd0, train, ev, bf16=False, perm_seed=None):
     return np.concatenate(out).astype(np.float32)
 
 
-def side_hip(args, fd, model, sd0, train, ev, precision):
+def side_hip(args, fd, model, sd0, train, ev, precision, perm_seed=None):
     import torch
     from cdcmdr_amd.optim import FusedAdam
     from cdcmdr_amd.trainer import TrainStep
@@ -184,7 +184,11 @@ def side_hip(args, fd, model, sd0, train, ev, precision):
     Xtr, ytr, gtr = (torch.from_numpy(a).to(dev) for a in train)
     for s in range(args.steps):
         sl = slice(s * B, (s + 1) * B)
-        ts.step(Xtr[sl], ytr[sl], gtr[sl])
+        if perm_seed is None:
+            ts.step(Xtr[sl], ytr[sl], gtr[sl])
+        else:                                                                # same rows, another order inside the batch (as ref_perm<k>)
+            pi = torch.from_numpy(np.random.Generator(np.random.PCG64(1_000_003 * perm_seed + s)).permutation(B)).to(dev)
+            ts.step(Xtr[sl][pi].contiguous(), ytr[sl][pi].contiguous(), gtr[sl][pi].contiguous())
     ts.check_ids()
     opt.flush_table()
     model.eval()
@@ -207,7 +211,8 @@ def summarise(args, ev, init_hash=None):
     preds = {}
     names = ["ref", "ref_rev"] + sorted(f[:-4] for f in os.listdir(args.out) if f.startswith("ref_perm") and f.endswith(".npy"))
     names += sorted(f[:-4] for f in os.listdir(args.out) if f.startswith("oracle_bf16") and f.endswith(".npy"))
-    for name in names + ["oracle", "hip_f32", "hip_bf16"]:
+    hips = sorted(f[:-4] for f in os.listdir(args.out) if f.startswith("hip_") and f.endswith(".npy"))
+    for name in names + ["oracle"] + hips:
         path = os.path.join(args.out, name + ".npy")
         if os.path.exists(path):
             preds[name] = np.load(path)
@@ -283,8 +288,9 @@ def main():
         elif side.startswith("oracle_bf16"):
             tail = side[len("oracle_bf16"):]
             p = side_oracle(args, fd, sd0, train, ev, bf16=True, perm_seed=int(tail[5:]) if tail.startswith("_perm") else None)
-        elif side in ("hip_f32", "hip_bf16"):
-            p = side_hip(args, fd, model, sd0, train, ev, side[4:])
+        elif side.startswith("hip_f32") or side.startswith("hip_bf16"):
+            prec, _, tail = side[4:].partition("_perm")
+            p = side_hip(args, fd, model, sd0, train, ev, prec, perm_seed=int(tail) if tail else None)
         else:
             raise SystemExit(f"unknown side {side}")
         np.save(os.path.join(args.out, side + ".npy"), p)
