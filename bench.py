@@ -343,7 +343,7 @@ def main():
 
 # C-ABI call -> kernel name in the rocprofv3 summaries
 _KERNEL_OF = {"cdc_embed_lazy_flush(slice)": "k_lazy_flush", "cdc_embed_adam_dense_pass": "k_adam_dense_pass",
-              "cdc_glinear_fwd": "k_glinear_fwd", "cdc_glinear_bwd_x": "k_glinear_bwd_x", "cdc_embed_gather_fwd": "k_gather_fwd"}
+              "cdc_glinear_fwd": "k_g2_nt", "cdc_glinear_bwd_x": "k_g2_nt", "cdc_embed_gather_fwd": "k_gather_fwd"}
 
 
 def profiled_traffic(call_name):
@@ -394,61 +394,79 @@ def event_pair_floor_ms(ts, n=64):
 
 
 def measure_roofline(args, ts, opt, Xd, yd, gd):
-    """Per-launch HIP-event timing of instrumented eager steps (same launches as the timed region, which may be
-    replayed as a graph where events cannot be placed).  The roofline object is for the step's dominant kernel."""
+    """Per-launch HIP-event timing of instrumented eager steps, every launch with the chip to itself (the timed region replays the
+    same launches as a graph, where events cannot be placed, with the replay slice in the background; the rocprofv3 tables under
+    profiles/ give the in-step durations).  `roofline` is for the step's dominant kernel; the north-star figures (contractions
+    against the bf16 MFMA peak, gather against the HBM peak) ride along, with the event pair's own latency subtracted."""
     batches = [(Xd[i], yd[i], gd[i]) for i in range(len(Xd))]
-    prof = ts.profile(batches, n_steps=2 + 64, skip=2)      # 64 steps: exactly one period of the lazy table's whole-table flush
+    prof = ts.profile(batches, n_steps=2 + 64, skip=2, overlap=False)      # 64 steps: exactly one period of the lazy table's whole-table flush
+    floor_ms = event_pair_floor_ms(ts)
+    floor_net = max(floor_ms - 0.002, 0.0)                                  # the fill launch inside the pair is ~2 us of kernel itself
+
+    def net_ms(v):                                                          # a launch family's ms/step without the event pairs' latency
+        return max(v["ms_per_step"] - floor_net * v["launches_per_step"], 1e-9)
+
     total = sum(v["ms_per_step"] for v in prof.values())
     top = sorted(prof.items(), key=lambda kv: -kv[1]["ms_per_step"])
     name, d = top[0]
     breakdown = {k: round(v["ms_per_step"], 4) for k, v in top[:8]}
     breakdown_all = {k: round(v["ms_per_step"], 4) for k, v in top}
     per_launch_ms = d["ms_per_step"] / max(d["launches_per_step"], 1e-9)
+    traffic, traffic_src = profiled_traffic(name)
     if d["flops_per_step"] > 0:
-        achieved = d["flops_per_step"] / (d["ms_per_step"] * 1e-3) / 1e12
+        achieved = d["flops_per_step"] / (net_ms(d) * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_step": d["flops_per_step"]}
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_step": d["flops_per_step"], "traffic": traffic}
+    elif "lazy_flush" in name:
+        # The replay slice reads and writes each of its elements once and advances it flush_every Adam steps in between (64 replayed
+        # steps per 24 bytes moved): its bound is VALU ISSUE, not HBM.  Per element and step the scaled replay (csrc/common.h
+        # adam_scaled_step_pk) issues 5 plain fp32 operations + v_sqrt_f32 + v_rcp_f32; a wave instruction occupies its SIMD for
+        # 4 cycles (plain) / 8 cycles (transcendental) per 64 lanes (MI355X_MICROARCH.md, instruction issue costs): 36 cycles per 64
+        # element-steps.  peak = 256 CUs x 4 SIMDs x 2.4 GHz x 64 / 36.
+        es = opt.table.numel() * 1.0 / max(opt.own_mod, 1)                  # element-steps per training step (every owned element, one step)
+        peak = 256 * 4 * 2.4e9 * 64 / 36.0 / 1e9
+        achieved = es / (net_ms(d) * 1e-3) / 1e9
+        nbytes = d["bytes_per_step"]
+        hbm = nbytes / (net_ms(d) * 1e-3) / 1e9 if nbytes else None
+        roof = {"bound": "valu", "kernel": name, "achieved": achieved, "peak": peak, "unit": "G element-steps/s", "frac": achieved / peak,
+                "algorithmic_element_steps_per_step": es, "valu_cycles_per_64_element_steps": 36,
+                "hbm": {"achieved_GBps": hbm, "peak_GBps": HBM_PEAK_GBPS, "frac": None if hbm is None else hbm / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_step": nbytes, "traffic": traffic, "traffic_source": traffic_src,
+                        "measured_in_run": False if traffic is not None else None},
+                "traffic": traffic,
+                "note": "VALU-issue bound: element_steps is the nominal R*D per step (rows looked up since their slice's last flush replay "
+                        "fewer); in the timed region this launch runs in the background beside the forward/backward (two waves per SIMD, "
+                        "lowest issue priority) and lasts ~1.8x as long while costing the step ~0.6x of its stand-alone time "
+                        "(profiles/round3/README.md)"}
     else:
         nbytes = d["bytes_per_step"]
-        achieved = nbytes / (d["ms_per_step"] * 1e-3) / 1e9 if nbytes else None
+        achieved = nbytes / (net_ms(d) * 1e-3) / 1e9 if nbytes else None
         roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": nbytes}
-    if "lazy_flush" in name:
-        # the slice launch reads and writes each of its elements once but advances it flush_every Adam steps in between:
-        # its own floor is VALU issue (13 issue cycles per element-step with packed fp32 + two quarter-rate transcendentals)
-        es = opt.table.numel() * 1.0                       # element-steps per training step (every element, one step)
-        lane_rate = 256 * 64 * 2.4e9                       # fp32 lanes x clock
-        roof["valu"] = {"element_steps_per_step": es, "element_steps_per_s": es / (d["ms_per_step"] * 1e-3),
-                        "lane_cycles_per_element_step": lane_rate * d["ms_per_step"] * 1e-3 / es,
-                        "instruction_estimate_lane_cycles": 9.4,
-                        "note": "VALU-issue bound, not HBM bound: 64 replayed steps per byte moved.  The scaled replay (csrc/common.h "
-                                "adam_scaled_step_pk) issues 10 VALU instructions per element PAIR and step (6 packed fp32 + 2 v_sqrt_f32 + "
-                                "2 v_rcp_f32); SQ counters put the launch at 7.5 issue cycles per instruction and wave, and a variant that "
-                                "traded 3 transcendentals for 5 multiplies per 4 elements was 9.7% slower, i.e. every instruction costs the "
-                                "same and the count is the floor: 5 instructions x 7.5 cycles / 4 SIMD-lane-groups = 9.4 lane-cycles per "
-                                "element-step (profiles/round2/pmc_sq_wait_valu.txt, DESIGN.md section 3).  element_steps is the nominal "
-                                "R*D per step (rows looked up since their last flush replay fewer); the time is the live HIP-event figure, "
-                                "which includes the event pair's latency (rocprofv3: 98 us per launch = 9.3 lane-cycles)"}
-    traffic, traffic_src = profiled_traffic(name)
-    floor_ms = event_pair_floor_ms(ts)
-    roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"], "traffic": traffic,
-                 "traffic_source": traffic_src,
+                "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": nbytes, "traffic": traffic}
+    roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"],
+                 "traffic_source": traffic_src, "traffic_measured_in_run": False if traffic is not None else None,
                  # what the same event pair reads around a one-element fill launch (~2 us of kernel): the part of avg_launch_ms that is
                  # the events' own dispatch latency, not the kernel — rocprofv3's per-kernel average has no such term
-                 "event_pair_floor_ms": floor_ms, "avg_launch_ms_less_event_floor": max(per_launch_ms - max(floor_ms - 0.002, 0.0), 0.0),
-                 "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown, "breakdown_all": breakdown_all})
-    # all MFMA launches together (north-star figure: expert GEMMs vs bf16 peak)
-    gm = [v for k, v in prof.items() if "glinear" in k]
+                 "event_pair_floor_ms": floor_ms, "avg_launch_ms_less_event_floor": max(per_launch_ms - floor_net, 0.0),
+                 "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown, "breakdown_all": breakdown_all,
+                 "timing": "HIP events around every launch of 64 eager steps, each launch alone on the chip"})
+    # the north star's two figures: all contraction launches against the dense bf16 MFMA peak, the gather against the HBM peak
+    gm = [v for k, v in prof.items() if "glinear" in k or "cgc_mid" in k]
     if gm:
         fl = sum(v["flops_per_step"] for v in gm)
-        ms = sum(v["ms_per_step"] for v in gm)
+        ms = sum(net_ms(v) for v in gm)
         roof["all_gemm_tflops"] = fl / (ms * 1e-3) / 1e12
         roof["all_gemm_ms_per_step"] = ms
+        roof["gemm_frac_of_mfma_peak"] = roof["all_gemm_tflops"] / MFMA_BF16_PEAK_TFLOPS
+        big = [v for k, v in prof.items() if "glinear" in k]
+        if big:
+            roof["grouped_linear_tflops"] = sum(v["flops_per_step"] for v in big) / (sum(net_ms(v) for v in big) * 1e-3) / 1e12
     g = prof.get("cdc_embed_gather_fwd")
     if g:
         B, F, D = ts.B, ts.emb.F, ts.emb.D
-        gb = B * F * (D * 4 + 4 + D * 4)
-        roof["gather_GBps"] = gb / (g["ms_per_step"] * 1e-3) / 1e9
+        gb = B * F * (D * 4 + 4 + D * 4)                                    # SURVEY 8d: row read + id + fp32 row written (the bf16 shadow not counted)
+        roof["gather_GBps"] = gb / (net_ms(g) * 1e-3) / 1e9
+        roof["gather_frac_of_hbm_peak"] = roof["gather_GBps"] / HBM_PEAK_GBPS
     return roof
 
 

@@ -177,21 +177,24 @@ __device__ __forceinline__ void adam_replay(float (&w)[N], float (&m)[N], float 
 // slice were looked up since its last flush).
 // The fast replay in SCALED state: with c = 2*l2 + wd the L2-only step is g = c*w, so M = m / ((1-beta1) c) and
 // V = v / ((1-beta2) c^2) obey  M <- beta1*M + w,  V <- beta2*V + w^2,  w <- w - A_t * M / (sqrt(V) + E_t)  with the per-step
-// scalars A_t = step_size_t * (1-beta1) c * bc2_t / sqrt((1-beta2) c^2),  E_t = eps * bc2_t / sqrt((1-beta2) c^2)  (host table,
-// formed in double).  Six packed fp32 operations + sqrt + rcp per element pair and step instead of nine: the replay is
+// scalars A_t = step_size_t * (1-beta1) c * bc2_t / sqrt((1-beta2) c^2),  E_t = eps * bc2_t / sqrt((1-beta2) c^2)  (formed in double on
+// the host; the table holds C1_t = -1/A_t and C2_t = -E_t/A_t, see adam_scaled_step_pk).  Six packed fp32 operations + sqrt + rcp per element pair and step instead of nine: the replay is
 // VALU-issue bound (profiles/round2), so the slice launch shrinks with the instruction count.  Same mathematics as
 // adam_elem_fast_pk; roundings differ in the last bit per step (the fast replay is 1-ulp arithmetic already).
-__device__ __forceinline__ void adam_scaled_step_pk(cdc_f2& w, cdc_f2& M, cdc_f2& V, float beta1, float beta2, float A, float E) {
+__device__ __forceinline__ void adam_scaled_step_pk(cdc_f2& w, cdc_f2& M, cdc_f2& V, float beta1, float beta2, float C1, float C2) {
+    // round 3: the step scalars travel as C1 = -1/A_t and C2 = -E_t/A_t, so that -A_t / (sqrt(V) + E_t) = 1 / fma(sqrt(V), C1, C2):
+    // the scaling by A_t rides in the FMA that formed the denominator anyway — one multiply less per element and step
+    // (5 plain + 2 transcendental instead of 6 + 2; the replay is bound by its instruction count)
     M = __builtin_elementwise_fma((cdc_f2){beta1, beta1}, M, w);
     V = __builtin_elementwise_fma((cdc_f2){beta2, beta2}, V, w * w);
     cdc_f2 sq;
     sq.x = __builtin_amdgcn_sqrtf(V.x);
     sq.y = __builtin_amdgcn_sqrtf(V.y);
-    const cdc_f2 d = sq + (cdc_f2){E, E};
+    const cdc_f2 d = __builtin_elementwise_fma(sq, (cdc_f2){C1, C1}, (cdc_f2){C2, C2});
     cdc_f2 r;
     r.x = __builtin_amdgcn_rcpf(d.x);
     r.y = __builtin_amdgcn_rcpf(d.y);
-    w = __builtin_elementwise_fma(M * (-A), r, w);
+    w = __builtin_elementwise_fma(M, r, w);
 }
 // (Tried: ONE v_rcp_f32 for four denominators, 1/(d0 d1 d2 d3) times the complementary products — 5 instead of 8 transcendentals
 // per four element-steps for 5 more multiplies.  9.7 % SLOWER (107.5 vs 98 us per slice launch): a transcendental costs about

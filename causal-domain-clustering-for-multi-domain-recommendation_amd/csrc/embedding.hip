@@ -1360,53 +1360,60 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     const int chunks = D / VEC;
     const int64_t total = n_rows * chunks;
     // software pipeline: the loads of the NEXT item are in flight under the replay of this one (the background form of this
-    // launch runs with one or two waves per SIMD, too few to hide a ~2 us load behind other waves)
-    struct Item { bool act; int from; int64_t row, e0, i; float wv[VEC], mv[VEC], vv[VEC]; };
-    auto fetch = [&](int64_t base, Item& it) {
-        it.i = base + threadIdx.x;
-        it.act = base < total && it.i < total;
-        it.row = it.act ? first + (it.i / chunks) * stride : first;
-        it.e0 = it.row * D + (it.act ? (it.i % chunks) * VEC : 0);
-        it.from = it.act ? last[it.row] : target;
-        it.act = it.act && it.from < target;
-        if (!it.act) it.from = target;
+    // launch runs with one or two waves per SIMD, too few to hide a ~2 us load behind other waves).  Only the item's VALUES and
+    // its start step are carried across the iteration; its row and element offset are recomputed from the index where they
+    // are needed (register budget: 64 VGPRs, so that two background waves sit beside four waves of a 96-VGPR kernel on a SIMD)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int32_t itotal = (int32_t)total;                              // (R * chunks < 2^31: checked by the launcher)
+    auto row_of = [&](int32_t i) -> int64_t { return first + (int64_t)(i / chunks) * stride; };
+    auto fetch = [&](int32_t i, int& from, float (&wv)[VEC], float (&mv)[VEC], float (&vv)[VEC]) __attribute__((always_inline)) {
+        const bool in = i < itotal;
+        const int64_t row = in ? row_of(i) : first;
+        from = in ? last[row] : target;
+        const bool act = in && from < target;
+        if (!act) from = target;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) { it.wv[k] = 0.f; it.mv[k] = 0.f; it.vv[k] = 1.f; }
-        if (it.act) {
+        for (int k = 0; k < VEC; ++k) { wv[k] = 0.f; mv[k] = 0.f; vv[k] = 1.f; }
+        if (act) {
+            const int64_t e0 = row * D + (i % chunks) * VEC;
             if (VEC == 4) {
                 // streamed once per flush period: non-temporal, so that the slice does not push the contractions' operands out of L2
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                const f4v a4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(w + it.e0)),
-                          b4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m + it.e0)),
-                          c4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v + it.e0));
-                it.wv[0] = a4.x; it.wv[1] = a4.y; it.wv[2] = a4.z; it.wv[3] = a4.w;
-                it.mv[0] = b4.x; it.mv[1] = b4.y; it.mv[2] = b4.z; it.mv[3] = b4.w;
-                it.vv[0] = c4.x; it.vv[1] = c4.y; it.vv[2] = c4.z; it.vv[3] = c4.w;
+                const f4v a4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(w + e0)),
+                          b4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m + e0)),
+                          c4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v + e0));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { wv[k] = a4[k]; mv[k] = b4[k]; vv[k] = c4[k]; }
             } else {
-                it.wv[0] = w[it.e0]; it.mv[0] = m[it.e0]; it.vv[0] = v[it.e0];
+                wv[0] = w[e0]; mv[0] = m[e0]; vv[0] = v[e0];
             }
         }
     };
-    const int64_t gstride = (int64_t)gridDim.x * blockDim.x;
-    Item cur, nxt;
-    fetch((int64_t)blockIdx.x * blockDim.x, cur);
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += gstride) {
-        fetch(base + gstride, nxt);                              // (past the end: an inactive item, no loads)
-        if (__any(cur.act)) {                                    // wave-uniform
-            adam_replay_wave<FAST, VEC>(cur.wv, cur.mv, cur.vv, cur.from, target, c, hp);
-            if (cur.act) {
+    const int32_t gstride = (int32_t)(gridDim.x * blockDim.x);
+    int cfrom, nfrom;
+    float cw[VEC], cm[VEC], cv[VEC], nw[VEC], nm[VEC], nv[VEC];
+    int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    fetch(i, cfrom, cw, cm, cv);
+    for (int32_t base = (int32_t)(blockIdx.x * blockDim.x); base < itotal; base += gstride, i += gstride) {
+        fetch(base + gstride < itotal ? i + gstride : itotal, nfrom, nw, nm, nv);     // (past the end: an inactive item, no loads)
+        const bool act = cfrom < target;
+        if (__any(act)) {                                        // wave-uniform
+            adam_replay_wave<FAST, VEC>(cw, cm, cv, cfrom, target, c, hp);
+            if (act) {
+                const int64_t row = row_of(i);
+                const int64_t e0 = row * D + (i % chunks) * VEC;
                 if (VEC == 4) {
-                    typedef float f4v __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store((f4v){cur.wv[0], cur.wv[1], cur.wv[2], cur.wv[3]}, reinterpret_cast<f4v*>(w + cur.e0));
-                    __builtin_nontemporal_store((f4v){cur.mv[0], cur.mv[1], cur.mv[2], cur.mv[3]}, reinterpret_cast<f4v*>(m + cur.e0));
-                    __builtin_nontemporal_store((f4v){cur.vv[0], cur.vv[1], cur.vv[2], cur.vv[3]}, reinterpret_cast<f4v*>(v + cur.e0));
+                    __builtin_nontemporal_store((f4v){cw[0], cw[1], cw[2], cw[3]}, reinterpret_cast<f4v*>(w + e0));
+                    __builtin_nontemporal_store((f4v){cm[0], cm[1], cm[2], cm[3]}, reinterpret_cast<f4v*>(m + e0));
+                    __builtin_nontemporal_store((f4v){cv[0], cv[1], cv[2], cv[3]}, reinterpret_cast<f4v*>(v + e0));
                 } else {
-                    w[cur.e0] = cur.wv[0]; m[cur.e0] = cur.mv[0]; v[cur.e0] = cur.vv[0];
+                    w[e0] = cw[0]; m[e0] = cm[0]; v[e0] = cv[0];
                 }
-                if (mark && (cur.i % chunks) == 0) last[cur.row] = target;   // the row's lanes share one wave (see k_lazy_catchup)
+                if (mark && (i % chunks) == 0) last[row] = target;   // the row's lanes share one wave (see k_lazy_catchup)
             }
         }
-        cur = nxt;
+        cfrom = nfrom;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { cw[k] = nw[k]; cm[k] = nm[k]; cv[k] = nv[k]; }
     }
 }
 __global__ void __launch_bounds__(256) k_lazy_set_last(int32_t* __restrict__ last, int64_t R, const int32_t* __restrict__ step_dev,

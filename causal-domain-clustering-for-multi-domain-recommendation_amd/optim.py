@@ -87,7 +87,10 @@ class FusedAdam:
             self._k1, self._k2 = f32(self._lerp_w * c), f32(self._omb2 * c * c)
             if self._k1 > 0.0 and self._k2 > 0.0:
                 t64 = tab.double()
-                rt = torch.stack([t64[:, 0] * self._k1 * t64[:, 1] / math.sqrt(self._k2), self._eps * t64[:, 1] / math.sqrt(self._k2)], dim=1)
+                A = t64[:, 0] * self._k1 * t64[:, 1] / math.sqrt(self._k2)
+                E = self._eps * t64[:, 1] / math.sqrt(self._k2)
+                A[0] = A[1]                                           # (row 0 = "step 0" is never replayed; keep it finite)
+                rt = torch.stack([-1.0 / A, -E / A], dim=1)           # C1 = -1/A_t, C2 = -E_t/A_t (csrc/common.h adam_scaled_step_pk)
                 self.replay_tab = rt.to(torch.float32).to(dev).contiguous()
         self.state = {}                                                       # id(param) -> (m, v)
         self.table_m = torch.zeros_like(self.table.data)
