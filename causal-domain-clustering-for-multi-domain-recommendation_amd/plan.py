@@ -1021,6 +1021,7 @@ class CGCMid:
     both expert levels is written as bf16 alone."""
 
     H1, H2 = 128, 64                      # the widths csrc/cgc.hip is instantiated for (config.py:39-42: ((256,128),(64,)))
+    MAX_B = 8192                          # batch rows up to which the fused boundary beats the three launches (see match)
 
     @staticmethod
     def _same(a, b):
@@ -1033,6 +1034,11 @@ class CGCMid:
         if not (plan.use_g2 and lin.g2 and lin.row_offsets is None and lin.M == plan.B and not lin.adopted and lin.relu):
             return None
         if (p1.H, p2.H) != (cls.H1, cls.H2) or len(lin.groups) > L.G2_MAX_OUT:
+            return None
+        # one workgroup (16 rows) per CU at a time: the fused launches scale linearly with the batch from B = 4096 on, the three
+        # launches they replace are still latency-bound there.  Measured stand-alone, fused vs unfused, forward + backward: 56 vs 80 us
+        # at B = 4096, 200 vs 188 at 16384, 396 vs 385 at 32768 (profiles/round3/asymptote.txt): fused up to 8192 rows per GPU
+        if plan.B > cls.MAX_B:
             return None
         ne2, ng2 = p2.n_expert, len(p2.gates)
         if (len(lin.groups) != ne2 + ng2 or p1.n_expert > L.MID_MAX_EXPERT or ne2 > L.MID_MAX_EXPERT or

@@ -44,7 +44,7 @@ for B in (4096, 16384, 32768):
             if not rec:
                 continue
             name, _, _, flops, nbytes = rec[0]
-            if not ("glinear" in name or "gather" in name or "cgc_mid" in name):
+            if not ("glinear" in name or "gather" in name or "cgc_mid" in name or "gate_pool" in name):
                 continue
             reps = 50
             for _ in range(5):
