@@ -110,8 +110,8 @@ class BwdwGroup(C.Structure):
 
 
 class LinBwdwArgs(C.Structure):
-    _fields_ = [("n_groups", c_i32), ("split_k", c_i32), ("workspace", c_p), ("row_offsets", c_p),
-                ("g", BwdwGroup * MAX_GROUPS)]
+    _fields_ = [("n_groups", c_i32), ("split_k", c_i32), ("workspace", c_p), ("row_offsets", c_p), ("defer_reduce", c_i32),
+                ("pad_", c_i32), ("g", BwdwGroup * MAX_GROUPS)]
 
 
 class PoolFwdGate(C.Structure):
@@ -150,6 +150,22 @@ class MidExpert2(C.Structure):
 class MidGate2(C.Structure):
     _fields_ = [("w", c_p), ("ldw", c_i64), ("bias", c_p), ("probs", c_p), ("out", c_p), ("ld_out", c_i64),
                 ("out_h", c_p), ("ld_out_h", c_i64), ("src", c_i32), ("n_sel", c_i32), ("sel", c_i32 * MAX_SEL)]
+
+
+PAIR_MAX_EXPERT = 16
+
+
+class PairExpert(C.Structure):
+    _fields_ = [("x", c_p), ("ldx", c_i64), ("w1", c_p), ("ldw1", c_i64), ("b1", c_p), ("w2", c_p), ("ldw2", c_i64), ("b2", c_p),
+                ("h", c_p), ("ldh", c_i64), ("y", c_p), ("ldy", c_i64), ("yh", c_p), ("ldyh", c_i64),
+                ("ws", c_p), ("ldws", c_i64), ("bs", c_p), ("ys", c_p), ("ldys", c_i64), ("ns", c_i32),
+                ("stream1", c_i32), ("stream2", c_i32), ("pad_", c_i32)]
+
+
+class ExpertPairArgs(C.Structure):
+    _fields_ = [("n_expert", c_i32), ("M", c_i32), ("K1r", c_i32), ("H1", c_i32), ("H2", c_i32), ("relu", c_i32), ("drop_p", c_f),
+                ("pad_", c_i32), ("seed1", C.c_uint64), ("seed2", C.c_uint64), ("seed_offset_dev", c_p),
+                ("e", PairExpert * PAIR_MAX_EXPERT)]
 
 
 class CgcMidFwdArgs(C.Structure):
@@ -258,7 +274,8 @@ class StarFuseArgs(C.Structure):
 
 
 class AdamTensor(C.Structure):
-    _fields_ = [("w", c_p), ("g", c_p), ("m", c_p), ("v", c_p), ("n", c_i64), ("l2", c_f)]
+    _fields_ = [("w", c_p), ("g", c_p), ("m", c_p), ("v", c_p), ("n", c_i64), ("l2", c_f), ("n_slabs", c_i32), ("slabs", c_p),
+                ("slab_stride", c_i64)]
 
 
 class AddNArgs(C.Structure):
@@ -269,7 +286,7 @@ class AddNArgs(C.Structure):
 class AdamArgs(C.Structure):
     _fields_ = [("n_tensors", c_i32), ("lerp_w", c_f), ("beta2", c_f), ("one_minus_beta2", c_f), ("eps", c_f),
                 ("weight_decay", c_f), ("step_scalars", c_p), ("n_scalars", c_i32), ("grad_scale", c_f),
-                ("step_dev", c_p), ("reg_sum", c_p), ("t", AdamTensor * MAX_TENSORS)]
+                ("step_dev", c_p), ("reg_sum", c_p), ("reg_seed", c_p), ("t", AdamTensor * MAX_TENSORS)]
 
 
 # name -> (restype, argtypes); every symbol include/cdcmdr.h declares
@@ -309,6 +326,7 @@ _SIGNATURES = {
     "cdc_gate_pool_fwd": (c_i32, [C.POINTER(PoolFwdArgs), c_p]),
     "cdc_cgc_mid_fwd": (c_i32, [C.POINTER(CgcMidFwdArgs), c_p]),
     "cdc_cgc_mid_bwd": (c_i32, [C.POINTER(CgcMidBwdArgs), c_p]),
+    "cdc_expert_pair_fwd": (c_i32, [C.POINTER(ExpertPairArgs), c_p]),
     "cdc_gate_pool_bwd": (c_i32, [C.POINTER(PoolBwdArgs), c_p]),
     "cdc_bn_fwd": (c_i32, [C.POINTER(BnFwdArgs), c_p]),
     "cdc_bn_bwd": (c_i32, [C.POINTER(BnBwdArgs), c_p]),

@@ -1150,6 +1150,7 @@ extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void*
         const cdc_bwdw_group& G = a->g[g];
         CDC_CHECK_ARG(G.dz && G.x && G.dw && G.M >= 0 && G.N > 0 && G.K > 0 && G.lddz >= G.N && G.ldx >= G.K && G.lddw >= G.K,
                       CDC_E_BADARG, "glinear_bwd_w: group %d malformed", g);
+        CDC_CHECK_ARG(!(a->defer_reduce && G.accumulate), CDC_E_BADARG, "glinear_bwd_w: group %d accumulates, its slabs cannot be left to the consumer", g);
         t64 += cdc_ceil_div(G.N, 64) * cdc_ceil_div(G.K, 64);
         slab += (int64_t)G.N * G.K + G.N;
     }
@@ -1167,7 +1168,7 @@ extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void*
     else
         hipLaunchKernelGGL((k_glinear_bwd_w<false, 64, 64>), dim3(grid), dim3(GEMM_THREADS), (lds_bytes<false, 64, 64>()), st, *a, slab);
     CDC_LAUNCH_CHECK("glinear_bwd_w");
-    if (S > 1) {
+    if (S > 1 && !a->defer_reduce) {
         int64_t total = 0;
         for (int g = 0; g < a->n_groups; ++g) total += (int64_t)a->g[g].N * a->g[g].K + a->g[g].N;
         int blocks = (int)std::min<int64_t>(cdc_ceil_div(total, 1024), 4096);       // four floats per thread (one 16-byte piece when aligned)

@@ -1630,7 +1630,13 @@ __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args 
     // One workgroup covers ADAM_CHUNK elements so that the launch ends in a few hundred (not thousands of) same-address
     // double atomics for the regularisation sum; with so few workgroups the launch lives on memory-level parallelism, so
     // every thread issues ALL its loads (16 elements x 4 arrays, as 16-byte loads when the tensors allow) before it computes.
-    const bool vec = ((((uintptr_t)T.w | (uintptr_t)T.m | (uintptr_t)T.v | (uintptr_t)T.g) & 15) == 0);
+    // gradient: the tensor T.g, or the sum of the split-K slabs of the grad-weight launch that left its reduction to us
+    // (same adds in the same order as k_bwd_w_reduce: 0 + slab 0 + slab 1 + ...)
+    const int n_slabs = T.n_slabs;
+    const float* const slabs = T.slabs;
+    const int64_t sstride = T.slab_stride;
+    const bool vec = ((((uintptr_t)T.w | (uintptr_t)T.m | (uintptr_t)T.v | (uintptr_t)(n_slabs > 0 ? slabs : T.g)) & 15) == 0) &&
+                     (n_slabs <= 0 || sstride % 4 == 0);
     if (vec && begin + ADAM_CHUNK <= T.n) {
         constexpr int R = ADAM_CHUNK / (4 * ROW_THREADS);
         adam_f4 w[R], m[R], v[R], g[R];
@@ -1640,7 +1646,28 @@ __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args 
             w[q] = *reinterpret_cast<const adam_f4*>(T.w + i);
             m[q] = *reinterpret_cast<const adam_f4*>(T.m + i);
             v[q] = *reinterpret_cast<const adam_f4*>(T.v + i);
-            g[q] = T.g ? *reinterpret_cast<const adam_f4*>(T.g + i) : adam_f4{0.f, 0.f, 0.f, 0.f};
+            g[q] = (T.g && n_slabs <= 0) ? *reinterpret_cast<const adam_f4*>(T.g + i) : adam_f4{0.f, 0.f, 0.f, 0.f};
+        }
+        // slabs in rounds of eight, every load of a round in flight before the first add (a round per slab was one memory latency
+        // per slab: 70 us for the two launches of C2 instead of 16); the adds stay in slab order
+        constexpr int SB = 8;
+        for (int s0 = 0; s0 < n_slabs; s0 += SB) {
+            adam_f4 t[SB][R];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                if (s0 + j < n_slabs) {                              // uniform
+                    const float* sp = slabs + (int64_t)(s0 + j) * sstride + begin + (int64_t)threadIdx.x * 4;
+#pragma unroll
+                    for (int q = 0; q < R; ++q) t[j][q] = *reinterpret_cast<const adam_f4*>(sp + (int64_t)q * ROW_THREADS * 4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                if (s0 + j < n_slabs) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) g[q] += t[j][q];
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -1665,7 +1692,27 @@ __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args 
                 const int64_t i = i0 + (int64_t)q * ROW_THREADS;
                 const bool ok = i < end;
                 w[q] = ok ? T.w[i] : 0.f; m[q] = ok ? T.m[i] : 0.f; v[q] = ok ? T.v[i] : 0.f;
-                g[q] = (ok && T.g) ? T.g[i] : 0.f;
+                g[q] = (ok && T.g && n_slabs <= 0) ? T.g[i] : 0.f;
+            }
+            for (int s0 = 0; s0 < n_slabs; s0 += 8) {                // rounds of eight slabs, loads first (see the vector path)
+                float t[8][4];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (s0 + j < n_slabs) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int64_t i = i0 + (int64_t)q * ROW_THREADS;
+                            t[j][q] = i < end ? slabs[(int64_t)(s0 + j) * sstride + i] : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (s0 + j < n_slabs) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) g[q] += t[j][q];
+                    }
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1678,6 +1725,7 @@ __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args 
             }
         }
     }
+    if (a.reg_sum && a.reg_seed && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.reg_sum, *a.reg_seed);
     if (a.reg_sum && T.l2 != 0.f) {
         __shared__ double part[WAVES_PER_BLOCK];
         sq = wave_sum_d(sq);
@@ -1693,6 +1741,8 @@ extern "C" int cdc_adam_multi(const cdc_adam_args* a, void* stream) {
     int64_t chunks = 0;
     for (int i = 0; i < a->n_tensors; ++i) {
         CDC_CHECK_ARG(a->t[i].w && a->t[i].m && a->t[i].v && a->t[i].n > 0, CDC_E_BADARG, "adam_multi: tensor %d malformed", i);
+        CDC_CHECK_ARG(a->t[i].n_slabs <= 0 || (a->t[i].slabs && a->t[i].n_slabs <= 256 && a->t[i].slab_stride >= a->t[i].n), CDC_E_BADARG,
+                      "adam_multi: tensor %d: gradient slabs malformed", i);
         chunks += cdc_ceil_div(a->t[i].n, ADAM_CHUNK);
     }
     CDC_CHECK_ARG(chunks < (1ll << 31), CDC_E_TOOBIG, "adam_multi: too many chunks");

@@ -103,6 +103,8 @@ class PLE(BaseModel):
         # a level's pooled outputs feed the next level's experts and gates and nothing else (ple.py:54-57): pooling, the next
         # level's contractions and its pooling go out as one launch where the shapes allow (csrc/cgc.hip)
         P.fuse_cgc_mid(plan)
+        # the two layers of a level's experts (no BatchNorm between them, ple.py:84-87) as one forward launch (csrc/pair.hip)
+        P.fuse_expert_pair(plan)
         others = []                                                      # the wide term (ple.py:61) is formed inside the head launch
         if self.use_atten:
             others.append(self.describe_atten(plan, E))                  # ple.py:65-67

@@ -286,10 +286,12 @@ class FusedAdam:
                  self._stream(), nbytes=24.0 * self.table.numel())
 
     # ------------------------------------------------------------------------------------------
-    def dense_step(self, param_grads, param_refs):
+    def dense_step(self, param_grads, param_refs, slabs=None):
         """Adam step t on every dense parameter that has a gradient in the plan (params without one are skipped,
-        as torch.optim.Adam skips `grad is None`)."""
-        sig = tuple((k, g.data_ptr()) for k, g in param_grads.items())
+        as torch.optim.Adam skips `grad is None`).  slabs (plan.grad_slabs): gradients whose split-K slabs the grad-weight launches
+        left unreduced — the launch adds them while it reads (address of the gradient tensor -> (first slab, stride, count))."""
+        slabs = slabs or {}
+        sig = tuple((k, g.data_ptr(), slabs.get(g.data_ptr())) for k, g in param_grads.items())
         if self._dense_sig != sig:
             items = []
             for k, g in param_grads.items():
@@ -311,10 +313,17 @@ class FusedAdam:
                 a.grad_scale = self.grad_scale
                 a.step_dev = self.step_dev.data_ptr()
                 a.reg_sum = self.reg_sum.data_ptr()
+                # lazy table: the step's reg figure = dense parameters' sum + the table term cached by refresh_table_reg()
+                a.reg_seed = self.table_reg.data_ptr() if (self.table_mode == "lazy" and c0 == 0) else 0
                 for i, (p, g, st) in enumerate(chunk):
                     T = a.t[i]
                     T.w, T.g, T.m, T.v, T.n = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel()
                     T.l2 = float(torch.tensor(self._l2_of.get(id(p), 0.0), dtype=torch.float64).to(torch.float32))
+                    sl = slabs.get(g.data_ptr())
+                    if sl is not None:
+                        T.slabs, T.slab_stride, T.n_slabs = sl
+                    else:
+                        T.slabs, T.slab_stride, T.n_slabs = None, 0, 0
                 args.append(a)
             self._dense_args, self._dense_sig = args, sig
         s = self._stream()
@@ -322,8 +331,10 @@ class FusedAdam:
             L.launch("cdc_adam_multi", self.lib.cdc_adam_multi, (C.byref(a),), s)
 
     def reg_loss(self):
-        """device double: the step's regularisation term sum(l2*w^2) (dense params + table). In lazy mode the table
-        part only covers rows replayed this step; call flush_table() + table_reg_loss() for the exact figure."""
+        """device double: the step's regularisation term sum(l2*w^2) (dense params + table).  Lazy mode: the table's part is the
+        value cached by refresh_table_reg(), already added by the dense step (cdc_adam_args.reg_seed)."""
+        if self.table_mode == "lazy":
+            return self.reg_sum[0]
         return self.reg_sum[0] + self.l2_table * self.reg_sum[1]
 
     def table_reg_loss(self, owned_only=False):

@@ -147,7 +147,8 @@ class _GradState:
 
 
 class Plan:
-    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0, step_dev=None, grad_arena=None, dist=None, g2=True):
+    def __init__(self, device, B, precision="bf16", training=True, dropout=0.0, seed=0, step_dev=None, grad_arena=None, dist=None, g2=True,
+                 defer_dw_reduce=False):
         assert precision in ("bf16", "f32")
         self.lib = L.load()
         self.device = torch.device(device)
@@ -187,6 +188,12 @@ class Plan:
         self._last_bn_step = 0
         self._wt = {}                     # weight key -> (weight object, transposed copy [K,N]) refreshed at the start of backward
         self._deferred_dw = []            # grad-weight groups of every layer, launched together at the end of backward
+        # defer_dw_reduce (the single-GPU training step): the batched grad-weight launches leave their split-K slabs unreduced and
+        # the dense Adam launch adds them while it reads the gradient (cdc_adam_tensor.slabs): two launches and a round trip of
+        # the gradients through memory less per step.  grad_slabs: address of a parameter gradient -> (first slab, stride, count);
+        # the gradient tensors of those parameters are NOT written by backward()
+        self.defer_dw_reduce = bool(defer_dw_reduce) and os.environ.get("CDC_DW_DEFER", "1") != "0"
+        self.grad_slabs = {}
         self.finalized = False
         self.loss_inputs = None
         # bf16 contraction path with operands that are bf16 in memory (csrc/gemm2.hip): shadows of activations, gradients, weights
@@ -320,6 +327,8 @@ class Plan:
                 T = 64 if all(g["N"] <= 64 for g in chunk) else 128
                 tiles = sum(math.ceil(g["N"] / T) * math.ceil(g["K"] / T) for g in chunk)
                 S = max(1, min(int(os.environ.get("CDC_DW_BLOCKS", "512")) // max(tiles, 1), max(Mmax // 256, 1), 32))
+                if self.defer_dw_reduce:                   # the Adam launch reads the slabs in rounds of eight (csrc/rowops.hip)
+                    S = min(S, 8)
             else:
                 tiles = sum(math.ceil(g["N"] / 64) * math.ceil(g["K"] / 64) for g in chunk)
                 S = max(1, min(1024 // max(tiles, 1), max(Mmax // 128, 1), 64))       # 1024: measured best of 384…2560 at C2
@@ -509,8 +518,33 @@ class Plan:
         for a in self._gemm_ws_users:            # grad-weight launches built before the batched ones sized the workspace: a pointer
             a.workspace = self._gemm_ws.data_ptr()   # taken earlier would dangle once the buffer has been re-allocated
         self.deferred_dw_steps = []          # the tail of bwd_steps nothing else in the backward depends on
+        # launches that leave the slab reduction to the optimiser get a workspace region of their own behind the shared one
+        # (their slabs must survive until the dense Adam launch)
+        own, extra = {}, 0
+        if self.defer_dw_reduce:
+            for a, fl in dw:
+                if a.split_k > 1 and not any(a.g[i].accumulate for i in range(a.n_groups)):
+                    slab = sum(a.g[i].N * a.g[i].K + a.g[i].N for i in range(a.n_groups))
+                    own[id(a)] = (extra, slab)
+                    extra += (a.split_k * slab + 3) // 4 * 4
+        if extra:
+            shared = (self._gemm_ws_need + 3) // 4 * 4
+            self._gemm_ws = torch.empty(shared + extra, dtype=torch.float32, device=self.device)
+            for a in self._gemm_ws_users:
+                a.workspace = self._gemm_ws.data_ptr()
         for a, fl in dw:
             a.workspace = self._gemm_ws.data_ptr()
+            if id(a) in own:
+                off, slab = own[id(a)]
+                a.workspace = self._gemm_ws.data_ptr() + 4 * (shared + off)
+                a.defer_reduce = 1
+                pos = 0
+                for i in range(a.n_groups):
+                    G = a.g[i]
+                    self.grad_slabs[G.dw] = (a.workspace + 4 * pos, slab, a.split_k)
+                    if G.db:
+                        self.grad_slabs[G.db] = (a.workspace + 4 * (pos + G.N * G.K), slab, a.split_k)
+                    pos += G.N * G.K + G.N
             step = self.call("cdc_glinear_bwd_w", C.byref(a), self.prec, flops=fl)
             self.bwd_steps.append(step)
             self.deferred_dw_steps.append(step)
@@ -1207,6 +1241,112 @@ def fuse_cgc_mid(plan):
         srcs = CGCMid.match(plan, plan.ops[i], plan.ops[i + 1], plan.ops[i + 2])
         if srcs is not None:
             CGCMid(plan, plan.ops[i], plan.ops[i + 1], plan.ops[i + 2], srcs)
+            n += 1
+        i += 1
+    return n
+
+
+class ExpertPair:
+    """Two consecutive BatchNorm-free expert layers — GLinear(x -> H1, ReLU, dropout; hidden kept as a bf16 shadow only) and
+    GLinear(H1 -> H2, ReLU, dropout [+ gate projections of x riding along]) — as ONE forward launch (csrc/pair.hip; model/ple.py:83-94,
+    model/layer.py:185-196).  Built from the two ops the model described (it takes their place in plan.ops and uses their buffers);
+    the forward is bit-identical to their two launches, the backward IS theirs."""
+
+    H1, H2 = 256, 128                     # the widths csrc/pair.hip is instantiated for (config.py:39-42: ((256,128),(64,)))
+
+    @classmethod
+    def match(cls, plan, la, lb):
+        if not (isinstance(la, GLinear) and isinstance(lb, GLinear) and plan.use_g2 and la.g2 and lb.g2):
+            return False
+        if not (la.row_offsets is None and lb.row_offsets is None and la.M == plan.B and lb.M == plan.B and la.relu and lb.relu and
+                la.drop_p == lb.drop_p and plan.B < (1 << 31)):
+            return False
+        n = len(la.groups)
+        if not (0 < n <= L.PAIR_MAX_EXPERT and n <= len(lb.groups) <= 2 * n and len(lb.groups) <= L.G2_MAX_OUT):
+            return False
+        K = la.groups[0]["w"].shape[1]
+        for i in range(n):
+            ga, gb = la.groups[i], lb.groups[i]
+            if not (isinstance(ga["w"], torch.Tensor) and isinstance(gb["w"], torch.Tensor) and tuple(ga["w"].shape) == (cls.H1, K) and
+                    tuple(gb["w"].shape) == (cls.H2, cls.H1) and ga["act_cols"] == cls.H1 and gb["act_cols"] == cls.H2):
+                return False
+            if not (CGCMid._same(ga["y"], gb["x"]) and plan.is_half_only(ga["y"]) and not plan.is_half_only(ga["x"])):
+                return False
+        for j, g in enumerate(lb.groups[n:]):                 # the riders: narrow, no activation, reading what expert j reads
+            if not (isinstance(g["w"], torch.Tensor) and g["w"].shape[0] <= 16 and g["w"].shape[1] == K and g["act_cols"] == 0 and
+                    CGCMid._same(g["x"], la.groups[j]["x"]) and not plan.is_half_only(g["y"])):
+                return False
+        return True
+
+    def __init__(self, plan, la, lb):
+        self.la, self.lb = la, lb
+        i = plan.ops.index(la)
+        assert plan.ops[i + 1] is lb
+        plan.ops[i:i + 2] = [self]
+        self._keep = []
+        for op in (la, lb):                                    # (their backward builders append argument blocks here)
+            op._keep = getattr(op, "_keep", [])
+
+    def build_fwd(self, plan):
+        la, lb = self.la, self.lb
+        n = len(la.groups)
+        plan.ensure_shadows([g["x"] for g in la.groups], plan.fwd_steps)
+        a = L.ExpertPairArgs()
+        K = la.groups[0]["w"].shape[1]
+        a.n_expert, a.M, a.K1r, a.H1, a.H2 = n, plan.B, (K + 63) // 64 * 64, self.H1, self.H2
+        a.relu, a.drop_p = 1, la.drop_p
+        a.seed1, a.seed2 = la.seed & 0xFFFFFFFFFFFFFFFF, lb.seed & 0xFFFFFFFFFFFFFFFF
+        a.seed_offset_dev = plan.step_dev.data_ptr()
+        for i in range(n):
+            ga, gb, E = la.groups[i], lb.groups[i], a.e[i]
+            E.x, E.ldx = plan.shadow_view(ga["x"])
+            w1, _ = plan.wshadow(ga["w"])
+            w2, _ = plan.wshadow(gb["w"])
+            E.w1, E.ldw1 = w1.data_ptr(), w1.stride(0)
+            E.w2, E.ldw2 = w2.data_ptr(), w2.stride(0)
+            E.b1 = None if ga.get("b") is None else ga["b"].data_ptr()
+            E.b2 = None if gb.get("b") is None else gb["b"].data_ptr()
+            E.h, E.ldh = plan.shadow_view(ga["y"])
+            plan.mark_shadow(ga["y"])
+            y = gb["y"]
+            if plan.is_half_only(y):
+                E.y = None
+            else:
+                E.y, E.ldy = y.ptr, y.ld
+            if plan.shadow_wanted(y):
+                E.yh, E.ldyh = plan.shadow_view(y)
+                plan.mark_shadow(y)
+            else:
+                E.yh = None
+            E.stream1, E.stream2 = i, i                        # the group's index in each of the two launches
+            E.ws, E.ns = None, 0
+        for j, g in enumerate(lb.groups[n:]):
+            E = a.e[j]
+            ws, _ = plan.wshadow(g["w"])
+            E.ws, E.ldws = ws.data_ptr(), ws.stride(0)
+            E.bs = None if g.get("b") is None else g["b"].data_ptr()
+            E.ys, E.ldys, E.ns = g["y"].ptr, g["y"].ld, g["w"].shape[0]
+            if plan.shadow_wanted(g["y"]):
+                raise RuntimeError("ExpertPair: a rider's output is read by a bf16 contraction (no shadow is written for it)")
+        self._keep.append(a)
+        fl = sum(2.0 * plan.B * g["w"].shape[0] * g["w"].shape[1] for g in la.groups + lb.groups)
+        plan.fwd_steps.append(plan.call("cdc_expert_pair_fwd", C.byref(a), what="cdc_glinear_pair_fwd", flops=fl))
+
+    def build_bwd(self, plan, gs):
+        self.lb.build_bwd(plan, gs)
+        self.la.build_bwd(plan, gs)
+
+
+def fuse_expert_pair(plan):
+    """Replaces every (GLinear, GLinear) run of plan.ops that is the two layers of a level's experts in the instantiated shape by ONE
+    ExpertPair op (env CDC_PAIR=0: leave the two launches)."""
+    if os.environ.get("CDC_PAIR", "1") == "0":
+        return 0
+    n = 0
+    i = 0
+    while i + 1 < len(plan.ops):
+        if ExpertPair.match(plan, plan.ops[i], plan.ops[i + 1]):
+            ExpertPair(plan, plan.ops[i], plan.ops[i + 1])
             n += 1
         i += 1
     return n

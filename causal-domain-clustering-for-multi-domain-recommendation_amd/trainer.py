@@ -61,7 +61,8 @@ class TrainStep:
             self.order = self.holder.extra_outputs[0]             # row order after the partition (ascending group)
             self.y_perm = torch.zeros(self.B, dtype=torch.int16, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.reg = torch.zeros((), dtype=torch.float64, device=dev)        # the step's sum(l2*w^2), formed inside the launch sequence
+        # the step's sum(l2*w^2), formed inside the launch sequence; lazy table: the optimiser's accumulator itself (see _reg)
+        self.reg = self.opt.reg_sum[0] if self.opt.table_mode == "lazy" else torch.zeros((), dtype=torch.float64, device=dev)
         self.use_graph = use_graph
         self.graph = None
         self._stage_graphs = {}
@@ -117,7 +118,7 @@ class TrainStep:
             plan = P.Plan(dev, B, precision=model.precision, training=self.train_mode,
                           dropout=float(getattr(model, "dropout_p", 0.0)) if self.train_mode else 0.0,
                           seed=int(getattr(model, "seed", 0)), step_dev=opt.step_dev, grad_arena=opt.grad_arena,
-                          dist=self.dist if self.sync_bn else None)
+                          dist=self.dist if self.sync_bn else None, defer_dw_reduce=not self.dp_on)
             emb = model.embedding.describe(plan)
             outs, ins, extra = model.describe(plan, emb, grouped=True) if self.mode == "star" else model.describe(plan, emb)
             plan.finalize(outs)
@@ -127,7 +128,7 @@ class TrainStep:
         model.train(self.train_mode)                 # the ops read module.training while describing themselves
         try:
             return model._cache().get(model, ("train_step", id(opt), self.train_mode, self.mode == "star",
-                                               bool(self.sync_bn and self.dp_on)), B, build)
+                                               bool(self.sync_bn and self.dp_on), bool(self.dp_on)), B, build)
         finally:
             model.train(was)
 
@@ -201,10 +202,9 @@ class TrainStep:
     def _reg(self):
         # part of the (graph-replayed) launch sequence, so that step() issues nothing else per call.  Dense table mode: the
         # streaming pass sums w^2 of the whole table every step (reg_sum[1]).  Lazy table: nobody walks the table in a step;
-        # the table's term is the value of the last refresh_table_reg() (flush + exact sum), see there.
-        if self.opt.table_mode == "lazy":
-            torch.add(self.opt.reg_sum[0], self.opt.table_reg, out=self.reg)
-        else:
+        # the table's term is the value of the last refresh_table_reg() (flush + exact sum), see there; the first dense Adam launch
+        # of the step adds it to the dense parameters' sum, so `reg` IS the optimiser's accumulator and no launch is issued here.
+        if self.opt.table_mode != "lazy":
             torch.add(self.opt.reg_sum[0], self.opt.reg_sum[1], alpha=self.opt.l2_table, out=self.reg)
 
     def refresh_table_reg(self):
@@ -252,7 +252,7 @@ class TrainStep:
                 plan.forward()
             self._bce()
             plan.backward()
-            opt.dense_step(plan.param_grads, plan._param_refs)
+            opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
             if bg:
                 main.wait_stream(side)
             opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
@@ -263,7 +263,7 @@ class TrainStep:
         self._bce()
         plan.backward()
         opt.table_step(emb.idx, emb.out.grad.root, B, F, D)
-        opt.dense_step(plan.param_grads, plan._param_refs)
+        opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
         self._reg()
 
     def _overlap(self):
@@ -303,7 +303,7 @@ class TrainStep:
 
         def update():
             opt.table_step(self.idx_all, self.dE_all, self.global_B, F, D)
-            opt.dense_step(plan.param_grads, plan._param_refs)
+            opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
             self._reg()
 
         def run_steps(steps):
@@ -382,7 +382,7 @@ class TrainStep:
         def update():
             opt.table_step(self.recv_ids, self.grads_recv, Bv, F, D, "owner", short_segments=True)
             opt.flush_slice()                           # off the rows-exchange critical path: after the owner's update
-            opt.dense_step(plan.param_grads, plan._param_refs)
+            opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
             self._reg()
 
         def run_steps(steps):

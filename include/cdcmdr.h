@@ -372,6 +372,10 @@ typedef struct {
                                         (deterministic; no float atomics) */
     float* workspace;                /* split_k > 1: >= split_k * sum_g (N_g*K_g + N_g) floats */
     const int32_t* row_offsets;      /* ragged rows (device [n_groups+1]) or NULL */
+    int32_t defer_reduce;            /* split_k > 1 only: 1 = the slab-adding launch is left out — dw / db are NOT written, the consumer
+                                        (cdc_adam_tensor.slabs) adds the slabs [dW_0 | db_0 | dW_1 | db_1 | ...] itself; no group may
+                                        accumulate */
+    int32_t pad_;
     cdc_bwdw_group g[CDC_MAX_GROUPS];
 } cdc_lin_bwdw_args;
 int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void* stream);
@@ -513,6 +517,43 @@ typedef struct {
     cdc_mid_bgate2 g2[CDC_MID_MAX_GATE];
 } cdc_cgc_mid_bwd_args;
 int cdc_cgc_mid_bwd(const cdc_cgc_mid_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Two consecutive BatchNorm-free expert layers as ONE forward launch (csrc/pair.hip; reference: the experts'
+ * MultiLayerPerceptron(in, (H1, H2), dropout, output_layer=False, bn=False), model/ple.py:83-88, model/layer.py:185-196:
+ * Linear, ReLU, Dropout, Linear, ReLU, Dropout).  For every expert e and its M rows:
+ *   h_e = drop(relu(x_e . W1_e^T + b1_e))  -> bf16 [M, H1]  (the second layer's operand; kept for the backward launches)
+ *   y_e = drop(relu(h_e . W2_e^T + b2_e))  -> fp32 [M, H2] and / or its bf16 copy
+ * and optionally a side output of ns <= 16 columns from the same x_e (a gate's logits, model/ple.py:89-94):
+ *   ys_e = x_e . WS_e^T + bs_e             -> fp32 [M, ns]
+ * Arithmetic (bf16 operands, fp32 accumulate, K walked in 64-wide slabs), rounding of h and the dropout streams (seed1 / seed2 +
+ * stream ids) are those of two cdc_gemm_bf16_nt forward launches with the same arguments: results are bit-identical.
+ * Operands as for cdc_gemm_bf16_nt: bf16, 16-byte aligned, rows readable to K1r (a multiple of 64) with zero padding in at
+ * least one operand of each product.  Instantiated for (H1, H2) = (256, 128); anything else: CDC_E_BADARG.
+ * ---------------------------------------------------------------------------------------- */
+#define CDC_PAIR_MAX_EXPERT 16
+typedef struct {
+    const void* x; int64_t ldx;                        /* bf16 [M, >= K1r] */
+    const void* w1; int64_t ldw1; const float* b1;     /* bf16 [H1, >= K1r]; bias fp32 [H1] or NULL */
+    const void* w2; int64_t ldw2; const float* b2;     /* bf16 [H2, >= H1];  bias fp32 [H2] or NULL */
+    void* h; int64_t ldh;                              /* out bf16 [M, H1] (may be NULL: not kept) */
+    float* y; int64_t ldy;                             /* out fp32 [M, H2] (may be NULL if yh) */
+    void* yh; int64_t ldyh;                            /* out bf16 [M, H2] (may be NULL) */
+    const void* ws; int64_t ldws; const float* bs;     /* side output: bf16 [ns, >= K1r] weight rows (NULL: none), bias or NULL */
+    float* ys; int64_t ldys;                           /* out fp32 [M, ns] */
+    int32_t ns;
+    int32_t stream1, stream2;                          /* dropout stream ids of the two layers (the group's index in the unfused launch) */
+    int32_t pad_;
+} cdc_pair_expert;
+typedef struct {
+    int32_t n_expert, M, K1r, H1, H2, relu;
+    float drop_p;
+    int32_t pad_;
+    uint64_t seed1, seed2;
+    const int32_t* seed_offset_dev;
+    cdc_pair_expert e[CDC_PAIR_MAX_EXPERT];
+} cdc_expert_pair_args;
+int cdc_expert_pair_fwd(const cdc_expert_pair_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm1d (+ReLU, +dropout) over column segments (reference: model/layer.py:187,199-205 with the
@@ -774,12 +815,15 @@ int cdc_copy_or_add(float* dst, int64_t ldd, const float* src, int64_t lds, int6
 /* ------------------------------------------------------------------------------------------
  * Dense-parameter Adam, multi-tensor (reference: run.py:720-721 torch.optim.Adam(lr, betas=(0.9,0.99),
  * eps=1e-8, weight_decay=wd) + the L2 term of model/layer.py:96-112 whose gradient is 2*l2*w):
- *   g = grad + 2*l2_i*w + wd*w ; Adam step t ; reg_sum += l2_i * sum(w_old^2) (device double).
+ *   g = grad + 2*l2_i*w + wd*w ; Adam step t ; reg_sum += l2_i * sum(w_old^2) (device double; + *reg_seed once).
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     float* w; const float* g; float* m; float* v;
     int64_t n;
     float l2;
+    int32_t n_slabs;                  /* > 0: the gradient is the sum of n_slabs split-K slabs of a grad-weight launch whose second */
+    const float* slabs;               /* launch was deferred (cdc_lin_bwdw_args.defer_reduce): g[i] = ((0 + slabs[i]) + slabs[stride+i]) */
+    int64_t slab_stride;              /* + ... in slab order — the sums k_bwd_w_reduce forms, bit for bit; `g` is not read */
 } cdc_adam_tensor;
 typedef struct {
     int32_t n_tensors;
@@ -788,6 +832,7 @@ typedef struct {
     float grad_scale;                 /* g is multiplied by this first (1/world_size after a sum all-reduce) */
     const int32_t* step_dev;
     double* reg_sum;                  /* may be NULL */
+    const double* reg_seed;           /* may be NULL: *reg_sum += *reg_seed, once per launch (the lazy table's cached l2*sum(w^2)) */
     cdc_adam_tensor t[CDC_MAX_TENSORS];
 } cdc_adam_args;
 int cdc_adam_multi(const cdc_adam_args* a, void* stream);

@@ -161,6 +161,45 @@ def test_graph_replay_equals_eager(cuda, table_mode):
         assert torch.equal(res[False][1][k], res[True][1][k]), k
 
 
+@pytest.mark.parametrize("precision,B", [("bf16", 1024), ("f32", 512)])
+def test_split_k_slabs_summed_by_the_adam_launch_train_bit_identically(cuda, monkeypatch, precision, B):
+    """Single GPU: the batched grad-weight launches leave their split-K slabs unreduced and the dense Adam launch adds them in the
+    order the reduce launch would (cdc_lin_bwdw_args.defer_reduce, cdc_adam_tensor.slabs).  Same sums in the same order: weights,
+    moments and losses after six steps are bit-identical to the run with the reduce launches."""
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    from cdcmdr_amd.model.ple import PLE
+    fd = [50, 3, 500, 7, 90, 4, 1000, 30]
+    res = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("CDC_DW_DEFER", defer)
+        torch.manual_seed(4)
+        model = PLE(fd, 16, 3, 2, 2, ((256, 128), (64,)), (64, 32), dropout=0.2).to(cuda).set_precision(precision)
+        model.seed = 77
+        opt = FusedAdam(model, table_mode="lazy")
+        ts = TrainStep(model, opt, B, use_graph=(defer == "1"))
+        assert bool(ts.plan.grad_slabs) == (defer == "1"), "split-K launches expected at this batch size"
+        r = np.random.default_rng(8)
+        losses = []
+        for _ in range(6):
+            X = torch.from_numpy(make_ids(r, B, fd)).to(cuda)
+            y = torch.from_numpy(r.integers(0, 2, size=B).astype(np.int16)).to(cuda)
+            g = torch.from_numpy(r.integers(0, 3, size=B).astype(np.int64)).to(cuda)
+            bce, reg = ts.step(X, y, g)
+            losses.append((float(bce.item()), float(reg.item())))
+        opt.flush_table()
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        mom = {k: (v["exp_avg"].cpu(), v["exp_avg_sq"].cpu()) for k, v in opt.state_dict()["state"].items()}
+        res[defer] = (losses, sd, mom)
+    assert [b for b, _ in res["0"][0]] == [b for b, _ in res["1"][0]]
+    # (the reg figure is a sum of per-workgroup double partials added by atomics: equal to the last bits, not bit for bit)
+    assert np.allclose([r_ for _, r_ in res["0"][0]], [r_ for _, r_ in res["1"][0]], rtol=1e-12, atol=0)
+    for k in res["0"][1]:
+        assert torch.equal(res["0"][1][k], res["1"][1][k]), k
+    for k in res["0"][2]:
+        assert torch.equal(res["0"][2][k][0], res["1"][2][k][0]) and torch.equal(res["0"][2][k][1], res["1"][2][k][1]), k
+
+
 def test_table_adam_kernels_bits_equal_the_c_restatement(cuda):
     """The dense streaming pass (untouched rows: L2-only gradient) and the touched-row kernel against
     oracle/adam_elem_ref.c, which tests/test_host_logic.py pins bit-for-bit to torch's CPU Adam."""
