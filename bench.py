@@ -267,7 +267,9 @@ def main():
         for _ in range(n):
             j = cursor[0] % args.pool
             cursor[0] += 1
-            step_obj.step(Xd[j], yd[j], gd[j])
+            # the next batch is named like a data loader with one batch of look-ahead does (data.train_epoch): on one GPU its row
+            # sort runs beside this step's forward/backward — every step still sorts exactly one batch
+            step_obj.step(Xd[j], yd[j], gd[j], next_X=Xd[cursor[0] % args.pool])
 
     def timed(step_obj, n):
         if dp:
@@ -325,7 +327,7 @@ def main():
             "config": {"workload": "PLE 3-domain full training step (fwd + BCE + whole-table L2 + bwd + Adam), "
                                    f"{args.fields} fields x vocab {args.vocab}, emb_dim={args.embed_dim}, batch {B}/GPU",
                        "global_batch": B * world, "dropout": args.dropout, "table_mode": table_mode,
-                       "hip_graph": use_graph, "id_dist": args.id_dist, "parallelism": f"dp{world}", "attention_branch": bool(args.atten),
+                       "hip_graph": use_graph, "row_sort_one_batch_ahead": bool(getattr(ts, "_ahead_ok", False)), "id_dist": args.id_dist, "parallelism": f"dp{world}", "attention_branch": bool(args.atten),
                        "table_dist": ts.table_dist if world > 1 else None,
                        "bn_stats": None if world == 1 else ("global batch (sync)" if args.sync_bn else "per rank"),
                        "steady_state": bool(steady), "preroll_steps": args.preroll,

@@ -152,15 +152,21 @@ def train_epoch(step, loader, log_interval=None, log=None):
     acc = torch.zeros((), dtype=torch.float64, device=step.device)
     done = skipped = 0
     step.refresh_table_reg()                     # lazy table: the first logging window reports the table's L2 term too
-    for batch in loader:
+    it = iter(loader)
+    batch = next(it, None)
+    while batch is not None:
+        nxt = next(it, None)                     # one batch of look-ahead: its rows are sorted beside this batch's step
         X = batch[0]
         ts = step
         if X.shape[0] != step.B:
             if step.world > 1 or X.shape[0] == 0:
                 skipped += 1
+                batch = nxt
                 continue
             ts = step.sibling(X.shape[0])
-        bce, reg = ts.step(*batch)
+        ahead = nxt[0] if (nxt is not None and ts is step and nxt[0].shape[0] == step.B and step.world == 1) else None
+        bce, reg = ts.step(*batch, next_X=ahead) if ahead is not None else ts.step(*batch)
+        batch = nxt
         acc += bce.double().sum() + reg
         done += 1
         if done % log_interval == 0:

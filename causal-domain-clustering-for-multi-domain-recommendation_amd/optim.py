@@ -193,16 +193,27 @@ class FusedAdam:
         if flush:
             self.flush_slice()
 
-    def begin_step_sort(self, ids, offsets, B, F, D, tag="", err=None):
+    def begin_step_sort(self, ids, offsets, B, F, D, tag="", err=None, begin=True):
         """begin_step() + table_index() + sort_rows() in the sort's launches: the sort reads the raw ids (row = id + field
-        offset, out-of-range -> -1 and `err`), and its first launch also advances the step counter and clears the accumulators."""
+        offset, out-of-range -> -1 and `err`), and its first launch also advances the step counter and clears the accumulators.
+        begin=False: the sort alone (a batch sorted one step ahead: the step counter is not its business)."""
         ws = self._workspace(B, F, D, tag)
         L.launch("cdc_embed_sort_dedupe", self.lib.cdc_embed_sort_dedupe_ids,
-                 (ids.data_ptr(), offsets.data_ptr(), self.table.shape[0], self.step_dev.data_ptr(), self.reg_sum.data_ptr(), 2,
+                 (ids.data_ptr(), offsets.data_ptr(), self.table.shape[0], self.step_dev.data_ptr() if begin else None,
+                  self.reg_sum.data_ptr() if begin else None, 2 if begin else 0,
                   None if err is None else err.data_ptr(),
                   ws["uniq"].data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(),
                   None if ws["scratch"] is None else ws["scratch"].data_ptr(), B, F), self._stream())
         return ws
+
+    def catchup_sorted(self, B, F, D, tag=""):
+        """lazy mode: the catch-up of the rows whose sorted list is in workspace `tag` (begin_step_sort(..., tag) of this or the
+        previous step), without the slice (the caller issues flush_slice())."""
+        assert self.table_mode == "lazy"
+        ws = self._workspace(B, F, D, tag)
+        L.launch("cdc_embed_lazy_catchup", self.lib.cdc_embed_lazy_catchup,
+                 (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.table.data_ptr(), self.table_m.data_ptr(),
+                  self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(), self.step_dev.data_ptr(), None, 0, B, F, D), self._stream())
 
     def begin_step_catchup(self, ids, offsets, B, F, D, flush=True):
         """begin_step() + table_catchup() of a single-GPU lazy step with two launches less (begin_step_sort)."""

@@ -266,6 +266,67 @@ class TrainStep:
         opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
         self._reg()
 
+    def _sort_ahead(self):
+        """Single GPU, lazy table, slice in the background: the sort + dedupe of batch t+1's rows (30 us of three dependent launches
+        that read nothing but the ids) goes out on the side chain of step t, behind the slice, when the caller names the next batch
+        (step(..., next_X=)); step t+1 then starts at the catch-up.  CDC_SORT_AHEAD=0: every step sorts its own batch first."""
+        if getattr(self, "_ahead_ok", None) is None:
+            self._ahead_ok = (not self.dp_on and self.opt.table_mode == "lazy" and self._overlap() and not self._fuse_gather() and
+                              os.environ.get("CDC_SORT_AHEAD", "1") != "0")
+            if self._ahead_ok:
+                self.ids_next = torch.zeros_like(self.emb.ids)
+                self._parity, self._sorted_for, self._graphs = 0, None, {}
+        return self._ahead_ok
+
+    def _launch_ahead(self, have, prefetch, p):
+        """_launch_all's lazy branch with the row sort taken out of the chain: have = this batch's sorted rows are in workspace a<p>
+        (sorted by the previous step), prefetch = sort the batch in ids_next into workspace a<1-p> on the side chain.  begin_step's
+        work was done by the staging launch (cdc_stage_batch_next)."""
+        opt, plan, emb = self.opt, self.plan, self.emb
+        B, F, D = self.B, emb.F, emb.D
+        cur, nxt = f"a{p}", f"a{1 - p}"
+        if not have:
+            opt.begin_step_sort(emb.ids, emb.offsets, B, F, D, tag=cur, begin=False)
+        opt.catchup_sorted(B, F, D, tag=cur)
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            opt.flush_slice(background_waves=self._overlap_waves)
+            if prefetch:
+                opt.begin_step_sort(self.ids_next, emb.offsets, B, F, D, tag=nxt, begin=False)
+        plan.forward()
+        self._bce()
+        plan.backward()
+        opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
+        main.wait_stream(side)
+        opt.table_step(emb.idx, emb.out.grad.root, B, F, D, tag=cur)
+        self._reg()
+
+    def _step_ahead(self, X, nx):
+        # the remembered tensor is kept alive (its storage cannot be handed to another batch) and its version pins its contents
+        key = (X.data_ptr(), X._version) if torch.is_tensor(X) else None
+        have = self._sorted_for is not None and self._sorted_for[:2] == key
+        prefetch = nx is not None
+        p = self._parity
+        if self.use_graph and self._warm >= 2:
+            g = self._graphs.get((have, prefetch, p))
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch_ahead(have, prefetch, p)
+                self._graphs[(have, prefetch, p)] = g
+                self.graph = g
+            g.replay()
+        else:
+            self._launch_ahead(have, prefetch, p)
+            self._warm += 1
+        if prefetch:
+            self._parity = 1 - p
+            self._sorted_for = (nx.data_ptr(), nx._version, nx)
+        else:
+            self._sorted_for = None
+
     def _overlap(self):
         """The replay slice of the lazy table on a second stream beside the forward/backward (single GPU).  CDC_OVERLAP=0 puts it
         back on the main chain, CDC_OVERLAP_WAVES sets the slice's waves per SIMD.  Measured at C2 (profiles/round3/README.md):
@@ -454,16 +515,38 @@ class TrainStep:
             g.replay()
         self._warm += 1
 
-    def step(self, X, y, group=None):
+    def step(self, X, y, group=None, next_X=None):
         """One training step. X int32 [B,F]; y int16/float [B] or [B,1]; group int64 [B] or [B,1] (multi mode).
-        Returns (bce_loss, reg_loss) as device tensors (no host synchronisation)."""
+        next_X (optional, single GPU): the ids of the batch the NEXT call will be given (device int32 [B,F], not modified until
+        then) — its rows are sorted beside this step's forward/backward (_sort_ahead); a next call with another tensor simply sorts
+        its own.  Returns (bce_loss, reg_loss) as device tensors (no host synchronisation)."""
         gdst = self.group if self.group is not None else (self.group_in if self.mode == "single_group" else None)
         yf = y.reshape(-1)
         gf = None if (group is None or gdst is None) else group.reshape(-1)
         fast = (X.is_cuda and X.dtype == torch.int32 and X.is_contiguous() and tuple(X.shape) == (self.B, self.emb.F) and
                 yf.is_cuda and yf.dtype == torch.int16 and yf.is_contiguous() and yf.numel() == self.B and
                 (gdst is None or (gf is not None and gf.is_cuda and gf.dtype == torch.int64 and gf.is_contiguous() and gf.numel() == self.B)))
-        if fast:                                                  # one launch instead of three copies
+        if not self._reg_checked:
+            # the first reported loss of a lazy run carries the table's L2 term like every later one (a freshly built or loaded
+            # optimiser has not evaluated it yet).  Before the staging launch: with the look-ahead sort that launch advances the step
+            # counter, and the refresh brings the table to the counter's step
+            self._reg_checked = True
+            if self.opt.table_mode == "lazy" and not self.opt.table_reg_ready:
+                self.refresh_table_reg()
+        ahead = (not self.dp_on) and self._sort_ahead() and self._overlap()      # (profile(overlap=False) switches the side chain off)
+        if not ahead and getattr(self, "_ahead_ok", False):
+            self._sorted_for = None
+        nx = None
+        if fast and ahead:                                        # + the next batch's ids for the look-ahead sort, + begin_step
+            if (next_X is not None and next_X.is_cuda and next_X.dtype == torch.int32 and next_X.is_contiguous() and
+                    tuple(next_X.shape) == (self.B, self.emb.F)):
+                nx = next_X
+            L.launch("cdc_stage_batch", self.lib.cdc_stage_batch_next,
+                     (X.data_ptr(), yf.data_ptr(), None if gdst is None else gf.data_ptr(), self.emb.ids.data_ptr(), self.y.data_ptr(),
+                      None if gdst is None else gdst.data_ptr(), self.B, self.emb.F, None if nx is None else nx.data_ptr(),
+                      self.ids_next.data_ptr(), self.opt.step_dev.data_ptr(), self.opt.reg_sum.data_ptr(), 2),
+                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        elif fast:                                                # one launch instead of three copies
             L.launch("cdc_stage_batch", self.lib.cdc_stage_batch,
                      (X.data_ptr(), yf.data_ptr(), None if gdst is None else gf.data_ptr(), self.emb.ids.data_ptr(), self.y.data_ptr(),
                       None if gdst is None else gdst.data_ptr(), self.B, self.emb.F), C.c_void_p(torch.cuda.current_stream().cuda_stream))
@@ -472,14 +555,12 @@ class TrainStep:
             self.y.copy_(yf)
             if gdst is not None:
                 gdst.copy_(gf)
-        if not self._reg_checked:
-            # the first reported loss of a lazy run carries the table's L2 term like every later one (a freshly built or loaded
-            # optimiser has not evaluated it yet)
-            self._reg_checked = True
-            if self.opt.table_mode == "lazy" and not self.opt.table_reg_ready:
-                self.refresh_table_reg()
+            if ahead:
+                self.opt.begin_step()
         if self.dp_on:
             self._step_dp()
+        elif ahead:
+            self._step_ahead(X if fast else None, nx)
         elif self.use_graph and self._warm >= 2:
             if self.graph is None:
                 g = torch.cuda.CUDAGraph()

@@ -867,7 +867,13 @@ int cdc_begin_step(int32_t* step_dev, double* accumulators, int32_t n_acc, void*
 /* one batch into the static buffers of a replayed launch sequence: ids int32 [B,F], labels int16 [B], tower index int64 [B]
  * (group / group_dst may be NULL) — the three tensors run.py:476-479 hands to a step; one launch instead of three copies */
 int cdc_stage_batch(const int32_t* ids, const int16_t* y, const int64_t* group, int32_t* ids_dst, int16_t* y_dst,
-                    int64_t* group_dst, int64_t B, int32_t F, void* stream);   /* ++*step_dev and zero n_acc doubles */
+                    int64_t* group_dst, int64_t B, int32_t F, void* stream);
+/* the same for a step whose row sort runs one step AHEAD (the sort of batch t+1 beside the forward/backward of batch t): this batch as
+ * above, the next batch's ids (next_ids, may be NULL) into next_dst — the buffer the look-ahead sort reads — and, with step_dev,
+ * cdc_begin_step's work (++*step_dev, accumulators[0..n_acc) = 0), which the sort's first launch does otherwise */
+int cdc_stage_batch_next(const int32_t* ids, const int16_t* y, const int64_t* group, int32_t* ids_dst, int16_t* y_dst,
+                         int64_t* group_dst, int64_t B, int32_t F, const int32_t* next_ids, int32_t* next_dst,
+                         int32_t* step_dev, double* accumulators, int32_t n_acc, void* stream);
 int cdc_fill_f32(float* p, float value, int64_t n, void* stream);
 int cdc_fill_f64(double* p, double value, int64_t n, void* stream);
 /* dst[r*ld_dst + c] += src[r*ld_src + c]  (gradient fan-in where a kernel cannot accumulate itself) */

@@ -200,6 +200,52 @@ def test_split_k_slabs_summed_by_the_adam_launch_train_bit_identically(cuda, mon
         assert torch.equal(res["0"][2][k][0], res["1"][2][k][0]) and torch.equal(res["0"][2][k][1], res["1"][2][k][1]), k
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_row_sort_one_batch_ahead_trains_bit_identically(cuda, monkeypatch, use_graph):
+    """Single GPU, lazy table: step(..., next_X=) sorts the NEXT batch's rows on the side chain of this step (trainer._sort_ahead).
+    The sort reads nothing but ids, so the trajectory is bit-identical to steps that sort their own batch first — also when the
+    announced batch is not the one that comes (the step then sorts its own), when no batch is announced, and across a ragged
+    announcement (wrong shape: ignored)."""
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    from cdcmdr_amd.model.ple import PLE
+    fd = [50, 3, 500, 7, 90, 4, 1000, 30]
+    B, n = 256, 10
+    r = np.random.default_rng(8)
+    Xs = [torch.from_numpy(make_ids(r, B, fd)).to(cuda) for _ in range(n + 1)]
+    ys = [torch.from_numpy(r.integers(0, 2, size=B).astype(np.int16)).to(cuda) for _ in range(n)]
+    gs = [torch.from_numpy(r.integers(0, 3, size=B).astype(np.int64)).to(cuda) for _ in range(n)]
+    decoy = torch.from_numpy(make_ids(r, B, fd)).to(cuda)
+    res = {}
+    for ahead in ("0", "1"):
+        monkeypatch.setenv("CDC_SORT_AHEAD", ahead)
+        torch.manual_seed(4)
+        model = PLE(fd, 8, 3, 2, 2, ((32, 16), (8,)), (8, 4), dropout=0.2).to(cuda).set_precision("f32")
+        model.seed = 5
+        opt = FusedAdam(model, table_mode="lazy", flush_every=4)
+        ts = TrainStep(model, opt, B, use_graph=use_graph)
+        losses = []
+        for i in range(n):
+            nxt = Xs[i + 1]
+            if i == 4:
+                nxt = decoy                              # announced, never comes: step 5 sorts its own batch
+            if i == 6:
+                nxt = None                               # nothing announced
+            if i == 7:
+                nxt = Xs[i + 1][:B // 2]                 # wrong shape: ignored
+            bce, _ = ts.step(Xs[i], ys[i], gs[i], next_X=nxt)
+            losses.append(float(bce.item()))
+        assert bool(getattr(ts, "_ahead_ok", False)) == (ahead == "1")
+        opt.flush_table()
+        res[ahead] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                      {k: (v["exp_avg"].cpu(), v["exp_avg_sq"].cpu()) for k, v in opt.state_dict()["state"].items()})
+    assert res["0"][0] == res["1"][0]
+    for k in res["0"][1]:
+        assert torch.equal(res["0"][1][k], res["1"][1][k]), k
+    for k in res["0"][2]:
+        assert torch.equal(res["0"][2][k][0], res["1"][2][k][0]) and torch.equal(res["0"][2][k][1], res["1"][2][k][1]), k
+
+
 def test_table_adam_kernels_bits_equal_the_c_restatement(cuda):
     """The dense streaming pass (untouched rows: L2-only gradient) and the touched-row kernel against
     oracle/adam_elem_ref.c, which tests/test_host_logic.py pins bit-for-bit to torch's CPU Adam."""
