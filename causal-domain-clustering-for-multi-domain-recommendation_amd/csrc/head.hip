@@ -131,6 +131,11 @@ __device__ __forceinline__ int head_section(const cdc_head_args& a, int t) {    
 }
 
 #define HEAD_BWD_WAVES 8
+// NT: the tower loops are unrolled to NT (4 or CDC_HEAD_MAX_TOWERS).  Unrolled to 8 the kernel needs 231 VGPRs (half of them spilled
+// scalar registers: eight towers' pointers and strides): two of its waves no longer fit on a SIMD beside the two low-priority waves of
+// the background replay slice (2 x 231 + 2 x 64 > 512), its workgroups waited for the slice to retire and the launch took 51 us in the
+// C2 step against 19 alone.  At NT = 4: 150.
+template <int NT>
 __global__ void __launch_bounds__(HEAD_BWD_WAVES * 64) k_head_bwd(const cdc_head_args a, int width) {
     CDC_PRIO_MAIN();
     extern __shared__ float head_sh[];                                   // [HEAD_BWD_WAVES][width]
@@ -158,14 +163,14 @@ __global__ void __launch_bounds__(HEAD_BWD_WAVES * 64) k_head_bwd(const cdc_head
             c = a.bce_group ? a.bce_group[rr] : 0;
             tgt = a.bce_y_i16 ? (float)a.bce_y_i16[rr] : a.bce_y_f32[rr];
         }
-        float o[CDC_HEAD_MAX_TOWERS], dout_in[CDC_HEAD_MAX_TOWERS];
+        float o[NT], dout_in[NT];
 #pragma unroll
-        for (int t = 0; t < CDC_HEAD_MAX_TOWERS; ++t) {
+        for (int t = 0; t < NT; ++t) {
             o[t] = t < a.n_tower ? a.out[rr * a.ld_out + t] : 0.5f;
             dout_in[t] = (!bce && t < a.n_tower) ? a.d_out[rr * a.ld_dout + t] : 0.f;
         }
         float wx[HEAD_KJ], wold[HEAD_KJ], wk[HEAD_KJ];
-        float tx[CDC_HEAD_MAX_TOWERS][HEAD_TJ], told[CDC_HEAD_MAX_TOWERS][HEAD_TJ], twk[CDC_HEAD_MAX_TOWERS][HEAD_TJ];
+        float tx[NT][HEAD_TJ], told[NT][HEAD_TJ], twk[NT][HEAD_TJ];
         if (small) {
 #pragma unroll
             for (int j = 0; j < HEAD_KJ; ++j) {
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(HEAD_BWD_WAVES * 64) k_head_bwd(const cdc_head
                 wk[j] = (in && a.wide_dx) ? a.wide_w[k] : 0.f;
             }
 #pragma unroll
-            for (int t = 0; t < CDC_HEAD_MAX_TOWERS; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < HEAD_TJ; ++j) {
                     const int k = lane + 64 * j;
@@ -189,10 +194,10 @@ __global__ void __launch_bounds__(HEAD_BWD_WAVES * 64) k_head_bwd(const cdc_head
         // (1) the logit gradient of every tower of this row (every lane forms all of them: n_tower is small)
         if (c < 0 || c >= a.n_tower) c = 0;
         const int own = (int)c;
-        float d[CDC_HEAD_MAX_TOWERS];
+        float d[NT];
         float dsum = 0.f;
 #pragma unroll
-        for (int t = 0; t < CDC_HEAD_MAX_TOWERS; ++t) {
+        for (int t = 0; t < NT; ++t) {
             d[t] = 0.f;
             if (t < a.n_tower) {
                 float dout;
@@ -210,7 +215,7 @@ __global__ void __launch_bounds__(HEAD_BWD_WAVES * 64) k_head_bwd(const cdc_head
         // (2) towers: dx_t = d_t * w_t, dw_t += d_t * x_t, db_t += d_t
         int off = 0;
 #pragma unroll
-        for (int t = 0; t < CDC_HEAD_MAX_TOWERS; ++t) {
+        for (int t = 0; t < NT; ++t) {
             if (t >= a.n_tower) break;
             const cdc_head_tower& T = a.t[t];
             const float dt = d[t];
@@ -346,7 +351,10 @@ extern "C" int cdc_head_bwd(const cdc_head_args* a, void* stream) {
     const int width = head_width(a);
     CDC_CHECK_ARG((size_t)HEAD_BWD_WAVES * width * 4 <= 64 * 1024, CDC_E_TOOBIG, "head_bwd: too many weight-gradient columns for one pass");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_head_bwd, dim3(CDC_ROWDOT_PARTS), dim3(HEAD_BWD_WAVES * 64), HEAD_BWD_WAVES * width * sizeof(float), st, *a, width);
+    if (a->n_tower <= 4)
+        hipLaunchKernelGGL(k_head_bwd<4>, dim3(CDC_ROWDOT_PARTS), dim3(HEAD_BWD_WAVES * 64), HEAD_BWD_WAVES * width * sizeof(float), st, *a, width);
+    else
+        hipLaunchKernelGGL(k_head_bwd<CDC_HEAD_MAX_TOWERS>, dim3(CDC_ROWDOT_PARTS), dim3(HEAD_BWD_WAVES * 64), HEAD_BWD_WAVES * width * sizeof(float), st, *a, width);
     CDC_LAUNCH_CHECK("head_bwd");
     hipLaunchKernelGGL(k_head_bwd_final, dim3((unsigned)cdc_ceil_div(width + 1, HEAD_WAVES)), dim3(HEAD_THREADS), 0, st, *a, width);
     CDC_LAUNCH_CHECK("head_bwd_final");
