@@ -345,7 +345,8 @@ def main():
 
 # C-ABI call -> kernel name in the rocprofv3 summaries
 _KERNEL_OF = {"cdc_embed_lazy_flush(slice)": "k_lazy_flush", "cdc_embed_adam_dense_pass": "k_adam_dense_pass",
-              "cdc_glinear_fwd": "k_g2_nt", "cdc_glinear_bwd_x": "k_g2_nt", "cdc_embed_gather_fwd": "k_gather_fwd"}
+              "cdc_glinear_fwd": "k_g2_nt", "cdc_glinear_bwd_x": "k_g2_nt", "cdc_glinear_pair_fwd": "k_pair_fwd",
+              "cdc_embed_gather_fwd": "k_gather_fwd"}
 
 
 def profiled_traffic(call_name):

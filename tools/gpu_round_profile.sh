@@ -44,6 +44,6 @@ with open(f"{O}/pmc_default_fetch_write.txt", "w") as f:
             f.write(l + "\n")
 print("pmc fetch/write written:", len(acc), "kernels")
 PY
-bash tools/gpu_pmc.sh $O "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY" k_lazy_flush k_g2_nt k_g2_tn k_cgc_mid > /dev/null 2>&1 || exit 1
-bash tools/gpu_pmc.sh $O "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" k_g2_nt k_g2_tn k_cgc_mid > /dev/null 2>&1 || exit 1
+bash tools/gpu_pmc.sh $O "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_ANY" k_lazy_flush k_g2_nt k_g2_tn k_cgc_mid k_pair_fwd > /dev/null 2>&1 || exit 1
+bash tools/gpu_pmc.sh $O "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" k_g2_nt k_g2_tn k_cgc_mid k_pair_fwd > /dev/null 2>&1 || exit 1
 ls $O
