@@ -89,6 +89,7 @@ class TrainStep:
             z = dict(device=dev)
             self.send_ids = torch.full((N, cap, F), -1, dtype=torch.int32, **z)
             self.recv_ids = torch.full((N, cap, F), -1, dtype=torch.int32, **z)
+            self.recv_ids_alt = torch.full((N, cap, F), -1, dtype=torch.int32, **z)   # the id exchange one step ahead lands here
             self.slot_of = torch.zeros((F, self.B), dtype=torch.int32, **z)
             self.overflow = torch.zeros(1, dtype=torch.int32, **z)
             self.rows_send = torch.zeros((N, cap, F * D), dtype=torch.float32, **z)
@@ -389,28 +390,42 @@ class TrainStep:
                 merged.append((is_comm, [fn]))
         return merged
 
-    def _dp_sequence_sharded(self):
+    def _dp_sequence_sharded(self, ahead=False, have=False, prefetch=False, p=0):
         """Row-sharded table: [(is_comm, [fn...])].  Per step and rank the table work is that of the LOCAL batch:
             sort local rows -> bucket by owner | a2a ids | owner: merge the sorted lists, catch-up, gather |
             a2a rows | expand, forward, BCE, backward, per-row gradient sums, pack | all-reduce arena, a2a grads |
-            owner: per-row sums over the senders, Adam update of its rows; dense Adam."""
+            owner: per-row sums over the senders, Adam update of its rows; dense Adam.
+        ahead (step(..., next_X=) in use): the step counter is advanced by the staging launch, and the first two items — which
+        read nothing but ids — run one step AHEAD: with `prefetch` the NEXT batch (ids_next) is sorted and bucketed in the segment
+        of the grad-weight launches (the local sort workspace and the slot lists are free once `pack` has run) and its id exchange
+        is started behind the gradient all-reduce, into the OTHER of two receive buffers (this step's owner update still reads
+        its own); with `have` this step starts at the owner's `serve`, after awaiting that exchange.  p: which receive buffer
+        holds THIS step's lists."""
         opt, plan, emb, dp = self.opt, self.plan, self.emb, self.dist
         B, F, D, N, cap, Bv = self.B, emb.F, emb.D, self.world, self.cap, self.Bv
         lib = self.lib
+        bufs = (self.recv_ids, self.recv_ids_alt)
+        recv_cur, recv_nxt = bufs[p], bufs[1 - p]
 
         def st():
             return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-        def stage0():
-            ws = opt.begin_step_sort(emb.ids, emb.offsets, B, F, D, "local", err=emb.err)   # ++step, index, sort: one launch chain
+        def sort_bucket(ids, begin):
+            ws = opt.begin_step_sort(ids, emb.offsets, B, F, D, "local", err=emb.err, begin=begin)   # [++step,] index, sort
             L.launch("cdc_shard_bucket", lib.cdc_shard_bucket,
                      (ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), self.send_ids.data_ptr(), self.slot_of.data_ptr(),
                       self.overflow.data_ptr(), B, F, N, cap), st())
 
+        def stage0():
+            sort_bucket(emb.ids, begin=not ahead)
+
+        def stage0_next():
+            sort_bucket(self.ids_next, begin=False)
+
         def serve():
-            opt.table_catchup_rows(self.recv_ids, Bv, F, D, "owner", runs=N, flush=False)   # each sender's list is sorted
+            opt.table_catchup_rows(recv_cur, Bv, F, D, "owner", runs=N, flush=False)   # each sender's list is sorted
             L.launch("cdc_embed_gather_fwd(owner)", lib.cdc_embed_gather_fwd,
-                     (self.recv_ids.data_ptr(), self.zero_offsets.data_ptr(), opt.table.data_ptr(), self.rows_send.data_ptr(),
+                     (recv_cur.data_ptr(), self.zero_offsets.data_ptr(), opt.table.data_ptr(), self.rows_send.data_ptr(),
                       None, None, Bv, F, D, opt.table.shape[0]), st())
 
         emb_shadow = plan.shadow_convert_step(emb.out) if (plan.use_g2 and plan.has_shadow(emb.out)) else None
@@ -439,9 +454,14 @@ class TrainStep:
         def exchange_finish():
             dp.wait(pending.pop("grads", None))
             dp.all_reduce_sum(self.arena_and_loss)                      # dense gradients + the loss scalar behind them
+            if prefetch:                                                # the next step's row lists travel under this step's updates
+                self._ids_pending = dp.all_to_all_start(recv_nxt, self.send_ids)
+
+        def ids_await():
+            dp.wait(self.__dict__.pop("_ids_pending", None))
 
         def update():
-            opt.table_step(self.recv_ids, self.grads_recv, Bv, F, D, "owner", short_segments=True)
+            opt.table_step(recv_cur, self.grads_recv, Bv, F, D, "owner", short_segments=True)
             opt.flush_slice()                           # off the rows-exchange critical path: after the owner's update
             opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
             self._reg()
@@ -453,8 +473,11 @@ class TrainStep:
                     step(s_)
             return fn
 
-        seq = [(False, stage0), (True, lambda: dp.all_to_all(self.recv_ids, self.send_ids)), (False, serve),
-               (True, lambda: dp.all_to_all(self.rows_recv, self.rows_send)), (False, expand)]
+        if have:
+            seq = [(True, ids_await), (False, serve)]
+        else:
+            seq = [(False, stage0), (True, lambda: dp.all_to_all(recv_cur, self.send_ids)), (False, serve)]
+        seq += [(True, lambda: dp.all_to_all(self.rows_recv, self.rows_send)), (False, expand)]
         fwd = [s_ for s_ in plan.fwd_steps if s_ is not emb.fwd_step]
         for is_comm, steps in plan.segments(fwd):
             seq.append((is_comm, run_steps(steps)))
@@ -462,8 +485,10 @@ class TrainStep:
         late = set(id(s_) for s_ in plan.deferred_dw_steps)
         for is_comm, steps in plan.segments([s_ for s_ in plan.bwd_steps if id(s_) not in late]):
             seq.append((is_comm, run_steps(steps)))
-        seq += [(False, pack), (True, exchange_rows_start), (False, run_steps(plan.deferred_dw_steps)), (True, exchange_finish),
-                (False, update)]
+        seq += [(False, pack), (True, exchange_rows_start), (False, run_steps(plan.deferred_dw_steps))]
+        if prefetch:
+            seq.append((False, stage0_next))
+        seq += [(True, exchange_finish), (False, update)]
         merged = []
         for is_comm, fn in seq:
             if merged and not is_comm and not merged[-1][0]:
@@ -486,14 +511,44 @@ class TrainStep:
             self.dist.all_reduce_sum(t)
         opt.table_last.fill_(int(opt.step_dev.item()))
 
-    def _step_dp(self):
-        if self._dp_seq is None:
-            self._dp_seq = self._dp_sequence_sharded() if self.table_dist == "sharded" else self._dp_sequence()
-        for i, (is_comm, fns) in enumerate(self._dp_seq):
+    def _ahead_dp(self):
+        """Data parallel, row-sharded table: the local sort, the bucketing and the id exchange of batch t+1 leave step t+1's
+        critical path when the caller names the next batch (step(..., next_X=)); see _dp_sequence_sharded.  CDC_SORT_AHEAD=0: off."""
+        if getattr(self, "_ahead_dp_ok", None) is None:
+            self._ahead_dp_ok = (self.dp_on and self.table_dist == "sharded" and os.environ.get("CDC_SORT_AHEAD", "1") != "0")
+            if self._ahead_dp_ok:
+                self.ids_next = torch.zeros_like(self.emb.ids)
+                self._parity, self._sorted_for, self._dp_seqs = 0, None, {}
+        return self._ahead_dp_ok
+
+    def _step_dp(self, X=None, nx=None):
+        key = None
+        if getattr(self, "_ahead_dp_ok", False):
+            xk = (X.data_ptr(), X._version) if torch.is_tensor(X) else None
+            have = self._sorted_for is not None and self._sorted_for[:2] == xk
+            if not have:
+                self.__dict__.pop("_ids_pending", None)                 # (an exchange started for a batch that did not come: its
+            prefetch = nx is not None                                   #  buffer is simply overwritten by the next one)
+            p = self._parity
+            key = (have, prefetch, p)
+            seq = self._dp_seqs.get(key)
+            if seq is None:
+                seq = self._dp_seqs[key] = self._dp_sequence_sharded(ahead=True, have=have, prefetch=prefetch, p=p)
+            if prefetch:
+                self._parity = 1 - p
+                self._sorted_for = (nx.data_ptr(), nx._version, nx)
+            else:
+                self._sorted_for = None
+        else:
+            if self._dp_seq is None:
+                self._dp_seq = self._dp_sequence_sharded() if self.table_dist == "sharded" else self._dp_sequence()
+            seq = self._dp_seq
+        for i, (is_comm, fns) in enumerate(seq):
             if is_comm or not (self.use_graph and self._warm >= 2):
                 for fn in fns:
                     fn()
                 continue
+            i = (key, i)
             g = self._stage_graphs.get(i)
             if g is None:
                 # thread-local capture mode: the RCCL watchdog thread keeps querying events while we capture
@@ -536,6 +591,8 @@ class TrainStep:
         ahead = (not self.dp_on) and self._sort_ahead() and self._overlap()      # (profile(overlap=False) switches the side chain off)
         if not ahead and getattr(self, "_ahead_ok", False):
             self._sorted_for = None
+        ahead_dp = self.dp_on and self._ahead_dp()
+        ahead = ahead or ahead_dp
         nx = None
         if fast and ahead:                                        # + the next batch's ids for the look-ahead sort, + begin_step
             if (next_X is not None and next_X.is_cuda and next_X.dtype == torch.int32 and next_X.is_contiguous() and
@@ -558,7 +615,7 @@ class TrainStep:
             if ahead:
                 self.opt.begin_step()
         if self.dp_on:
-            self._step_dp()
+            self._step_dp(X if fast else None, nx)
         elif ahead:
             self._step_ahead(X if fast else None, nx)
         elif self.use_graph and self._warm >= 2:

@@ -93,11 +93,23 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_
     X, y, g = _data(world)
     gb = B_LOCAL * world
     losses = []
+    # CDC_TEST_AHEAD=1: every step names the next batch (step(..., next_X=)): local sort, bucketing and id exchange run one step
+    # ahead; step 1 announces a batch that never comes (step 2 then sorts and exchanges its own), the last step announces nothing
+    ahead = os.environ.get("CDC_TEST_AHEAD") == "1"
+    shards = []
     for s in range(STEPS):
         lo = s * gb + rank * B_LOCAL
         sl = slice(lo, lo + B_LOCAL)
-        bce, _ = ts.step(torch.from_numpy(X[sl]).to(dev), torch.from_numpy(y[sl]).to(dev), torch.from_numpy(g[sl]).to(dev))
+        shards.append((torch.from_numpy(X[sl]).to(dev), torch.from_numpy(y[sl]).to(dev), torch.from_numpy(g[sl]).to(dev)))
+    decoy = shards[0][0].flip(0).contiguous()
+    for s in range(STEPS):
+        nxt = None
+        if ahead and s + 1 < STEPS:
+            nxt = decoy if s == 1 else shards[s + 1][0]
+        bce, _ = ts.step(*shards[s], next_X=nxt)
         losses.append(float(bce.item()))
+    if ahead and table_dist == "sharded" and table_mode == "lazy":
+        assert ts._ahead_dp_ok and len(ts._dp_seqs) >= 3, "the look-ahead sequences were not used"
     ts.check_ids()
     ts.gather_table()                 # flush + (row-sharded table) every owner's rows to every rank
     torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "m": opt.table_m.cpu(), "losses": losses},
@@ -251,6 +263,21 @@ def test_three_ranks_row_sharded_table(cuda, tmp_path):
             continue
         atol = 5e-4 if k.endswith("running_mean") else 2e-5
         assert_close(outs[0]["sd"][k], v, 5e-4, atol, f"3-rank vs 1-rank: {k}")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_ranks_row_sharded_with_sort_and_id_exchange_one_step_ahead(cuda, tmp_path, monkeypatch, use_graph):
+    """step(..., next_X=) under data parallelism: the next batch's local sort, bucketing and id exchange leave the next step's
+    critical path (trainer._dp_sequence_sharded).  Same replicas, same single-process reference as without."""
+    monkeypatch.setenv("CDC_TEST_AHEAD", "1")
+    test_two_ranks_stay_identical(cuda, tmp_path, "lazy", use_graph, "sharded")
+
+
+def test_one_rank_through_rccl_with_the_id_exchange_one_step_ahead(cuda, tmp_path, monkeypatch):
+    """the same over RCCL (forced one-rank group): the look-ahead id exchange is an ASYNC all-to-all on the communicator's stream,
+    awaited at the start of the next step"""
+    monkeypatch.setenv("CDC_TEST_AHEAD", "1")
+    test_one_rank_through_rccl(cuda, tmp_path, "sharded", True)
 
 
 @pytest.mark.parametrize("table_dist,use_graph", [("sharded", True), ("sharded", False), ("replicated", True)])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Large-batch asymptote of the contraction launches and of the gather: the C2 model's forward/backward
-launches timed one by one (the same launch issued back to back on an idle chip) at B = 4096 (the benchmark batch), 16384 and
-32768 (the per-field sort limit of the drop-in table gradient) — same layer shapes, only the row count grows.  Shows which launches are latency-bound at B = 4096 (their TFLOP/s or
+launches timed one by one (the same launch issued back to back on an idle chip) at B = 4096 (the benchmark batch), 16384,
+32768 and 65536 — same layer shapes, only the row count grows (above 32768, the per-field sort limit of the table gradient, the
+plan is built by a forward call alone and its backward launches are timed on whatever the buffers hold).  Shows which launches are latency-bound at B = 4096 (their TFLOP/s or
 GB/s keeps rising with B) and where the kernels level off.
 
     python tools/asymptote_probe.py > profiles/round3/asymptote.txt
@@ -26,11 +27,12 @@ m.set_precision("bf16")
 m.train()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 print("# launch                          B      us/launch   TFLOP/s (bf16 MFMA peak 2500)   or GB/s (HBM peak 8000)")
-for B in (4096, 16384, 32768):
+for B in (4096, 16384, 32768, 65536):
     rng = np.random.default_rng(0)
     X = torch.from_numpy(rng.integers(0, V, size=(B, F_)).astype(np.int32)).to(dev)
     out = m(X)
-    out.backward(torch.ones_like(out))
+    if B <= 32768:
+        out.backward(torch.ones_like(out))
     torch.cuda.synchronize()
     plan = m.plan_holder(B).plan
     rows = []

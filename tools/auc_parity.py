@@ -253,7 +253,7 @@ def summarise(args, ev, init_hash=None):
               "init_sha": any_side.get("init_sha"), "torch": any_side.get("torch"), "cpu_sides": cpu,
               "cpu_vs_cpu_floor": res.get("cpu_vs_cpu_floor"), "ref_reorderings": res.get("ref_reorderings"),
               "bf16_restatement_runs": sorted(k for k in cpu if k.startswith("oracle_bf16")),
-              "made_by": "tools/auc_parity.py --sides ref,ref_rev,ref_perm1..5,oracle (build container, imports /root/reference/model/ple.py) "
+              "made_by": "tools/auc_parity.py --sides ref,ref_rev,ref_perm1..N,oracle[,oracle_bf16..] (build container, imports /root/reference/model/ple.py) "
                          "+ --summarise --fixture"}
         json.dump(fx, open(args.fixture, "w"), indent=1)
         print("wrote", args.fixture)
