@@ -515,7 +515,11 @@ class TrainStep:
         """Data parallel, row-sharded table: the local sort, the bucketing and the id exchange of batch t+1 leave step t+1's
         critical path when the caller names the next batch (step(..., next_X=)); see _dp_sequence_sharded.  CDC_SORT_AHEAD=0: off."""
         if getattr(self, "_ahead_dp_ok", None) is None:
-            self._ahead_dp_ok = (self.dp_on and self.table_dist == "sharded" and os.environ.get("CDC_SORT_AHEAD", "1") != "0")
+            # (a forced one-rank group has no transfer for the moved work to hide under — measured 0.803 -> 0.818 ms/step on the
+            #  one-GPU box, the step there is bound by the host-side issue of its segments — so it takes part only with
+            #  CDC_SORT_AHEAD=2, which the RCCL call-path test sets)
+            env = os.environ.get("CDC_SORT_AHEAD", "1")
+            self._ahead_dp_ok = (self.dp_on and self.table_dist == "sharded" and env != "0" and (self.world > 1 or env == "2"))
             if self._ahead_dp_ok:
                 self.ids_next = torch.zeros_like(self.emb.ids)
                 self._parity, self._sorted_for, self._dp_seqs = 0, None, {}

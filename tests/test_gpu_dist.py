@@ -277,6 +277,7 @@ def test_one_rank_through_rccl_with_the_id_exchange_one_step_ahead(cuda, tmp_pat
     """the same over RCCL (forced one-rank group): the look-ahead id exchange is an ASYNC all-to-all on the communicator's stream,
     awaited at the start of the next step"""
     monkeypatch.setenv("CDC_TEST_AHEAD", "1")
+    monkeypatch.setenv("CDC_SORT_AHEAD", "2")                      # (a one-rank group takes part only when asked to: trainer._ahead_dp)
     test_one_rank_through_rccl(cuda, tmp_path, "sharded", True)
 
 
