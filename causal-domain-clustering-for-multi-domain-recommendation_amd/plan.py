@@ -549,7 +549,9 @@ class Plan:
             self.bwd_steps.append(step)
             self.deferred_dw_steps.append(step)
         self.bwd_steps[0:0] = self._emit_transposes()
-        self.fwd_steps[0:0] = self._emit_wshadows()
+        wsh = self._emit_wshadows()
+        self.fwd_steps[0:0] = wsh
+        self.n_wshadow_steps = len(wsh)      # the head of fwd_steps that reads nothing but the weights (trainer: runs beside the catch-up)
         self.finalized = True
 
     def comm(self, fn):

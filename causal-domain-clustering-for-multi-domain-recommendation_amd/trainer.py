@@ -280,28 +280,66 @@ class TrainStep:
         return self._ahead_ok
 
     def _launch_ahead(self, have, prefetch, p):
-        """_launch_all's lazy branch with the row sort taken out of the chain: have = this batch's sorted rows are in workspace a<p>
-        (sorted by the previous step), prefetch = sort the batch in ids_next into workspace a<1-p> on the side chain.  begin_step's
-        work was done by the staging launch (cdc_stage_batch_next)."""
+        """_launch_all's lazy branch with the row sort out of the chain and the catch-up on the SIDE chain: have = this batch's
+        sorted rows are in workspace a<p> (sorted by the previous step), prefetch = sort the batch in ids_next into workspace
+        a<1-p>.  begin_step's work was done by the staging launch (cdc_stage_batch_next).
+            side:  [sort] catch-up * | slice, [sort of the next batch]
+            main:  weight shadows    | (wait *) gather, forward, BCE, backward, grad-weight launches, dense Adam | join | row update
+        The fork sits at the head of the step: the weight-shadow launch reads nothing of the table and covers the cross-queue edge
+        (by the kernel trace, profiles/round3/step_timeline.txt, the fork-after-catch-up form left 12 us between the catch-up and
+        the first forward launch)."""
         opt, plan, emb = self.opt, self.plan, self.emb
         B, F, D = self.B, emb.F, emb.D
         cur, nxt = f"a{p}", f"a{1 - p}"
-        if not have:
-            opt.begin_step_sort(emb.ids, emb.offsets, B, F, D, tag=cur, begin=False)
-        opt.catchup_sorted(B, F, D, tag=cur)
         main = torch.cuda.current_stream()
         side = self._side_stream()
+        # measured (same box, ms/step): fork after the catch-up + row update behind the join 0.411 / 0.412; catch-up on the side chain
+        # under the weight-shadow launch 0.403; row update on the side chain as well (waiting for dE by an event, beside the
+        # grad-weight launches and the dense Adam) 0.420 / 0.424 — two more cross-queue edges cost more than the 24 us they free;
+        # main chain captured FIRST behind the catch-up (so that it stays on the origin queue and the side chain takes the
+        # cross-queue edge): the replayed graph then starts the slice 150 us late, 0.476
+        early = os.environ.get("CDC_EARLY_FORK", "1") != "0"
+        tail_side = os.environ.get("CDC_TABLE_STEP_SIDE", "0") == "1"
+        st = C.c_void_p(main.cuda_stream)
+        if not early:
+            if not have:
+                opt.begin_step_sort(emb.ids, emb.offsets, B, F, D, tag=cur, begin=False)
+            opt.catchup_sorted(B, F, D, tag=cur)
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            if early:
+                if not have:
+                    opt.begin_step_sort(emb.ids, emb.offsets, B, F, D, tag=cur, begin=False)
+                opt.catchup_sorted(B, F, D, tag=cur)
+                rows_ready = torch.cuda.Event()
+                rows_ready.record(side)
             opt.flush_slice(background_waves=self._overlap_waves)
             if prefetch:
                 opt.begin_step_sort(self.ids_next, emb.offsets, B, F, D, tag=nxt, begin=False)
-        plan.forward()
+        nws = getattr(plan, "n_wshadow_steps", 0) if early else 0
+        for fn in plan.fwd_steps[:nws]:
+            fn(st)
+        if early:
+            main.wait_event(rows_ready)
+        for fn in plan.fwd_steps[nws:]:
+            fn(st)
         self._bce()
-        plan.backward()
+        late = set(id(s_) for s_ in plan.deferred_dw_steps)
+        for fn in plan.bwd_steps:
+            if id(fn) not in late:
+                fn(st)
+        if tail_side:
+            grad_ready = torch.cuda.Event()
+            grad_ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(grad_ready)
+                opt.table_step(emb.idx, emb.out.grad.root, B, F, D, tag=cur)
+        for fn in plan.deferred_dw_steps:
+            fn(st)
         opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
         main.wait_stream(side)
-        opt.table_step(emb.idx, emb.out.grad.root, B, F, D, tag=cur)
+        if not tail_side:
+            opt.table_step(emb.idx, emb.out.grad.root, B, F, D, tag=cur)
         self._reg()
 
     def _step_ahead(self, X, nx):

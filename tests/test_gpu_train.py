@@ -535,7 +535,9 @@ def test_fused_catchup_gather_equals_the_two_launches(cuda, monkeypatch, D, prec
                         torch.from_numpy(X[:, 2].astype(np.int64)).to(cuda)))
     batches.append(batches[1])                                          # the same rows again, two steps later
     bad = batches[2][0].clone()
-    bad[5, 1] = 3000                                                    # one id past its field's vocabulary -> next field's first row? no: past the table for the last field only
+    # (an id past its field's vocabulary that still lies INSIDE the table aliases another field's row: gathered like the reference
+    #  gathers it, but the row then sits in two fields' sorted lists and is updated once per list in no defined order — the
+    #  sorted lists are per field, INTEGRATION.md "ids"; not exercised here)
     bad[7, 4] = 7                                                       # last field: 7 is outside [0, 7) and outside the table
     res = {}
     for fused in ("1", "0"):
