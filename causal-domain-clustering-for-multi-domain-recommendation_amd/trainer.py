@@ -314,7 +314,8 @@ class TrainStep:
                 rows_ready = torch.cuda.Event()
                 rows_ready.record(side)
             opt.flush_slice(background_waves=self._overlap_waves)
-            if prefetch:          # behind the slice (ahead of it the sort delays the whole side chain into the backward: 0.401 -> 0.443 ms)
+            if prefetch:          # behind the slice (ahead of it the sort delays the whole side chain into the backward: 0.401 -> 0.443 ms;
+                                  # held back by an event until the backward chain has run: 0.408 -> 0.427)
                 opt.begin_step_sort(self.ids_next, emb.offsets, B, F, D, tag=nxt, begin=False)
         nws = getattr(plan, "n_wshadow_steps", 0) if early else 0
         for fn in plan.fwd_steps[:nws]:
