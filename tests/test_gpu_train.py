@@ -235,7 +235,8 @@ def test_row_sort_one_batch_ahead_trains_bit_identically(cuda, monkeypatch, use_
                 nxt = Xs[i + 1][:B // 2]                 # wrong shape: ignored
             bce, _ = ts.step(Xs[i], ys[i], gs[i], next_X=nxt)
             losses.append(float(bce.item()))
-        assert bool(getattr(ts, "_ahead_ok", False)) == (ahead == "1")
+        # (the look-ahead rides on the side chain: CDC_OVERLAP=0 or the fused catch-up + gather switch it off)
+        assert bool(getattr(ts, "_ahead_ok", False)) == (ahead == "1" and ts._overlap() and not ts._fuse_gather())
         opt.flush_table()
         res[ahead] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
                       {k: (v["exp_avg"].cpu(), v["exp_avg_sq"].cpu()) for k, v in opt.state_dict()["state"].items()})
