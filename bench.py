@@ -291,6 +291,8 @@ def main():
     depth = replay_depth(opt)                    # (host-synchronising: before the warm-up, so the timed region starts on a busy GPU)
     run(ts, max(args.warmup, 1))
     elapsed = timed(ts, args.steps)
+    if os.environ.get("CDC_BENCH_REPEAT"):                     # development: the same bracket again (is the first one special?)
+        print("brackets ms/step:", [round(elapsed / args.steps * 1e3, 4)] + [round(timed(ts, args.steps) / args.steps * 1e3, 4) for _ in range(4)], file=sys.stderr)
     loss_val = float(ts.loss.item())
     elapsed_local = None
     if ts_local is not None:
