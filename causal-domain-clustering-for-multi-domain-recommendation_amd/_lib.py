@@ -153,6 +153,7 @@ class MidGate2(C.Structure):
 
 
 PAIR_MAX_EXPERT = 16
+ADAM_CHUNK = 4096
 
 
 class PairExpert(C.Structure):
@@ -362,6 +363,7 @@ _SIGNATURES = {
     "cdc_star_fuse_bwd": (c_i32, [C.POINTER(StarFuseArgs), c_p]),
     "cdc_sum_slices": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_adam_multi": (c_i32, [C.POINTER(AdamArgs), c_p]),
+    "cdc_adam_multi_table": (c_i32, [C.POINTER(AdamArgs), c_p, c_p, c_p, c_i32, c_p]),
     "cdc_step_increment": (c_i32, [c_p, c_p]),
     "cdc_begin_step": (c_i32, [c_p, c_p, c_i32, c_p]),
     "cdc_fill_f32": (c_i32, [c_p, c_f, c_i64, c_p]),

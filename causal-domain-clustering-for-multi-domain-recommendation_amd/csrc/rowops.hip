@@ -1598,27 +1598,15 @@ extern "C" int cdc_cross_bwd(const float* d_out, int64_t ldo, const float* x0, i
 // =================================================================================================
 // dense-parameter Adam, multi-tensor (run.py:720-721 + the L2 term of model/layer.py:96-112)
 // =================================================================================================
-#define ADAM_CHUNK 4096
+#define ADAM_CHUNK CDC_ADAM_CHUNK
 typedef float adam_f4 __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args a) {
-    // Which tensor does this workgroup's chunk belong to?  Walking the argument block one tensor at a time costs a scalar
-    // cache miss per tensor (12 us for the last of 48); instead lane i reads tensor i's size, a wave scan turns the chunk
-    // counts into offsets and a ballot names the tensor — one vector load for the whole search, the same in every wave.
-    const int lane = threadIdx.x & 63;
-    const int64_t n_l = lane < a.n_tensors ? a.t[lane].n : 0;
-    const int nc = (int)((n_l + ADAM_CHUNK - 1) / ADAM_CHUNK);
-    int inc = nc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
-    const int exc = inc - nc;
-    const unsigned long long owner = __ballot((int)blockIdx.x >= exc && (int)blockIdx.x < inc);
-    if (owner == 0ull) return;
-    const int ti = __builtin_amdgcn_readfirstlane(__ffsll((long long)owner) - 1);
-    const int chunk = (int)blockIdx.x - __builtin_amdgcn_readlane(exc, ti);
-    const cdc_adam_tensor& T = a.t[ti];
+struct AdamHdr {                        // what a chunk needs of cdc_adam_args besides its tensor
+    float lerp_w, beta2, one_minus_beta2, eps, weight_decay, grad_scale;
+    const float* step_scalars; int32_t n_scalars;
+    const int32_t* step_dev;
+    double* reg_sum; const double* reg_seed;
+};
+__device__ __forceinline__ void adam_chunk(const AdamHdr& a, const cdc_adam_tensor& T, const int chunk) {
     AdamConsts c;
     c.lerp_w = a.lerp_w; c.beta2 = a.beta2; c.omb2 = a.one_minus_beta2; c.eps = a.eps; c.wd = a.weight_decay;
     c.l2_twice = 2.f * T.l2;
@@ -1735,6 +1723,41 @@ __global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args 
     }
 }
 
+__global__ void __launch_bounds__(ROW_THREADS) k_adam_multi(const cdc_adam_args a) {
+    // Which tensor does this workgroup's chunk belong to?  Walking the argument block one tensor at a time costs a scalar
+    // cache miss per tensor (12 us for the last of 48); instead lane i reads tensor i's size, a wave scan turns the chunk
+    // counts into offsets and a ballot names the tensor — one vector load for the whole search, the same in every wave.
+    const int lane = threadIdx.x & 63;
+    const int64_t n_l = lane < a.n_tensors ? a.t[lane].n : 0;
+    const int nc = (int)((n_l + ADAM_CHUNK - 1) / ADAM_CHUNK);
+    int inc = nc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    const int exc = inc - nc;
+    const unsigned long long owner = __ballot((int)blockIdx.x >= exc && (int)blockIdx.x < inc);
+    if (owner == 0ull) return;
+    const int ti = __builtin_amdgcn_readfirstlane(__ffsll((long long)owner) - 1);
+    const int chunk = (int)blockIdx.x - __builtin_amdgcn_readlane(exc, ti);
+    const cdc_adam_tensor& T = a.t[ti];
+    const AdamHdr h = {a.lerp_w, a.beta2, a.one_minus_beta2, a.eps, a.weight_decay, a.grad_scale, a.step_scalars, a.n_scalars, a.step_dev,
+                       a.reg_sum, a.reg_seed};
+    adam_chunk(h, T, chunk);
+}
+
+// any number of tensors in ONE launch: the tensor descriptors and the workgroup -> (tensor, chunk) map live in device memory (built
+// once per parameter set by the caller); the 48-tensor limit above is the 4 KB kernel-argument block, and two launches cost the
+// C2 step 8 us more than one
+__global__ void __launch_bounds__(ROW_THREADS) k_adam_multi_tab(const AdamHdr h, const cdc_adam_tensor* __restrict__ tab,
+                                                                const int32_t* __restrict__ wg_tensor, const int32_t* __restrict__ wg_chunk) {
+    const int ti = __builtin_amdgcn_readfirstlane(wg_tensor[blockIdx.x]);
+    const int chunk = __builtin_amdgcn_readfirstlane(wg_chunk[blockIdx.x]);
+    const cdc_adam_tensor T = tab[ti];
+    adam_chunk(h, T, chunk);
+}
+
 extern "C" int cdc_adam_multi(const cdc_adam_args* a, void* stream) {
     CDC_CHECK_ARG(a && a->n_tensors > 0 && a->n_tensors <= CDC_MAX_TENSORS && a->step_dev && a->step_scalars && a->n_scalars > 0,
                   CDC_E_BADARG, "adam_multi: bad argument");
@@ -1748,6 +1771,17 @@ extern "C" int cdc_adam_multi(const cdc_adam_args* a, void* stream) {
     CDC_CHECK_ARG(chunks < (1ll << 31), CDC_E_TOOBIG, "adam_multi: too many chunks");
     hipLaunchKernelGGL(k_adam_multi, dim3(chunks), dim3(ROW_THREADS), 0, (hipStream_t)stream, *a);
     CDC_LAUNCH_CHECK("adam_multi");
+    return 0;
+}
+
+extern "C" int cdc_adam_multi_table(const cdc_adam_args* a, const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev,
+                                    const int32_t* wg_chunk_dev, int32_t n_workgroups, void* stream) {
+    CDC_CHECK_ARG(a && tensors_dev && wg_tensor_dev && wg_chunk_dev && n_workgroups > 0 && a->step_dev && a->step_scalars && a->n_scalars > 0,
+                  CDC_E_BADARG, "adam_multi_table: bad argument");
+    const AdamHdr h = {a->lerp_w, a->beta2, a->one_minus_beta2, a->eps, a->weight_decay, a->grad_scale, a->step_scalars, a->n_scalars,
+                       a->step_dev, a->reg_sum, a->reg_seed};
+    hipLaunchKernelGGL(k_adam_multi_tab, dim3(n_workgroups), dim3(ROW_THREADS), 0, (hipStream_t)stream, h, tensors_dev, wg_tensor_dev, wg_chunk_dev);
+    CDC_LAUNCH_CHECK("adam_multi_table");
     return 0;
 }
 

@@ -314,6 +314,32 @@ class FusedAdam:
                     st = (torch.zeros_like(p.data), torch.zeros_like(p.data))
                     self.state[k] = st
                 items.append((p, g, st))
+            self._dense_table = None
+            if len(items) > L.MAX_TENSORS and os.environ.get("CDC_ADAM_TABLE", "1") != "0":
+                # more tensors than one kernel-argument block holds: ONE launch whose descriptors and workgroup map are device arrays
+                tab = (L.AdamTensor * len(items))()
+                wg_t, wg_c = [], []
+                for i, (p, g, st) in enumerate(items):
+                    T = tab[i]
+                    T.w, T.g, T.m, T.v, T.n = p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), p.numel()
+                    T.l2 = float(torch.tensor(self._l2_of.get(id(p), 0.0), dtype=torch.float64).to(torch.float32))
+                    sl = slabs.get(g.data_ptr())
+                    T.slabs, T.slab_stride, T.n_slabs = sl if sl is not None else (None, 0, 0)
+                    nck = -(-p.numel() // L.ADAM_CHUNK)
+                    wg_t += [i] * nck
+                    wg_c += list(range(nck))
+                hdr = L.AdamArgs()
+                hdr.n_tensors = 0
+                hdr.lerp_w, hdr.beta2, hdr.one_minus_beta2, hdr.eps, hdr.weight_decay = self._lerp_w, self._beta2, self._omb2, self._eps, self._wd
+                hdr.step_scalars, hdr.n_scalars = self.scalars.data_ptr(), self.scalars.shape[0]
+                hdr.grad_scale = self.grad_scale
+                hdr.step_dev = self.step_dev.data_ptr()
+                hdr.reg_sum = self.reg_sum.data_ptr()
+                hdr.reg_seed = self.table_reg.data_ptr() if self.table_mode == "lazy" else 0
+                dev_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+                self._dense_table = (hdr, dev_tab, torch.tensor(wg_t, dtype=torch.int32, device=self.device),
+                                     torch.tensor(wg_c, dtype=torch.int32, device=self.device), len(wg_t))
+                items = []
             args = []
             for c0 in range(0, len(items), L.MAX_TENSORS):
                 a = L.AdamArgs()
@@ -338,6 +364,9 @@ class FusedAdam:
                 args.append(a)
             self._dense_args, self._dense_sig = args, sig
         s = self._stream()
+        if getattr(self, "_dense_table", None) is not None:
+            hdr, tab, wg_t, wg_c, n_wg = self._dense_table
+            L.launch("cdc_adam_multi", self.lib.cdc_adam_multi_table, (C.byref(hdr), tab.data_ptr(), wg_t.data_ptr(), wg_c.data_ptr(), n_wg), s)
         for a in self._dense_args:
             L.launch("cdc_adam_multi", self.lib.cdc_adam_multi, (C.byref(a),), s)
 

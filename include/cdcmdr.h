@@ -836,6 +836,13 @@ typedef struct {
     cdc_adam_tensor t[CDC_MAX_TENSORS];
 } cdc_adam_args;
 int cdc_adam_multi(const cdc_adam_args* a, void* stream);
+/* the same for ANY number of tensors in one launch: the descriptors (a->t is not read) and the workgroup -> (tensor, chunk of
+ * CDC_ADAM_CHUNK elements) map are device arrays the caller builds once per parameter set: workgroup i updates elements
+ * [wg_chunk[i] * CDC_ADAM_CHUNK, ...) of tensor wg_tensor[i].  (cdc_adam_multi's limit of CDC_MAX_TENSORS is the 4 KB kernel-argument
+ * block; a model with more dense tensors needed several launches.) */
+#define CDC_ADAM_CHUNK 4096
+int cdc_adam_multi_table(const cdc_adam_args* a, const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev,
+                         const int32_t* wg_chunk_dev, int32_t n_workgroups, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * STAR parameter fusion (reference: model/star.py:90-93,100-102,169-176): for every domain g
