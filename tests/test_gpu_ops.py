@@ -572,3 +572,90 @@ def test_segment_sum_every_length_class(cuda, D):
                 ref = vals.astype(np.float64).sum(0)
                 assert np.allclose(out[f, j], ref, rtol=2e-5, atol=2e-5 * np.sqrt(len(rows))), (f, j, len(rows))
         assert (out[f, c[f]:] == 7.0).all()                          # slots past the unique rows stay untouched
+
+
+def test_adam_multi_table_equals_the_argument_block_launches_and_torch_adam(cuda):
+    """cdc_adam_multi (<= 48 tensors per launch, descriptors as kernel arguments) and cdc_adam_multi_table (any number, descriptors
+    and workgroup map in device memory) on the same 70 tensors — whole chunks, ragged tails, unaligned sizes, a gradient given as
+    three split-K slabs — bit-identical, and equal to torch.optim.Adam with the L2 term in the gradient (run.py:720-721)."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    g_ = torch.Generator().manual_seed(3)
+    sizes = [5000, 4096, 8192 + 7, 33, 1, 4097, 12288] * 10
+    lr, b1, b2, eps, wd, l2 = 1e-3, 0.9, 0.99, 1e-8, 1e-8, 1e-5
+    w0 = [torch.randn(n, generator=g_) for n in sizes]
+    gr = [torch.randn(n, generator=g_) * 0.1 for n in sizes]
+    m0 = [torch.randn(n, generator=g_) * 0.01 for n in sizes]
+    v0 = [torch.rand(n, generator=g_) * 1e-3 for n in sizes]
+    t = 7                                                             # the step being taken
+    from cdcmdr_amd.optim import step_scalar_table
+    scal = step_scalar_table(lr, b1, b2, n=32).to(cuda).contiguous()         # row t: lr / (1 - b1^t), sqrt(1 - b2^t)
+    step_dev = torch.full((1,), t, dtype=torch.int32, device=cuda)
+    # a gradient as three slabs whose in-order sum is the gradient (tensor 2)
+    parts = [gr[2] * 0.5, gr[2] * 0.25, gr[2] - gr[2] * 0.5 - gr[2] * 0.25]
+    slab_stride = sizes[2] + 9
+    slabs = torch.zeros(3 * slab_stride)
+    for s_, p_ in enumerate(parts):
+        slabs[s_ * slab_stride:s_ * slab_stride + sizes[2]] = p_
+    g2_sum = (torch.zeros_like(parts[0]) + parts[0] + parts[1]) + parts[2]
+    slabs = slabs.to(cuda)
+
+    def run(table):
+        w = [x.clone().to(cuda) for x in w0]
+        m = [x.clone().to(cuda) for x in m0]
+        v = [x.clone().to(cuda) for x in v0]
+        g = [x.clone().to(cuda) for x in gr]
+        reg = torch.zeros(1, dtype=torch.float64, device=cuda)
+
+        def fill(T, i):
+            T.w, T.g, T.m, T.v, T.n, T.l2 = w[i].data_ptr(), g[i].data_ptr(), m[i].data_ptr(), v[i].data_ptr(), sizes[i], l2
+            if i == 2:
+                T.slabs, T.slab_stride, T.n_slabs = slabs.data_ptr(), slab_stride, 3
+            else:
+                T.slabs, T.slab_stride, T.n_slabs = None, 0, 0
+
+        def header(a):
+            a.lerp_w, a.beta2, a.one_minus_beta2, a.eps, a.weight_decay = 1 - b1, b2, 1 - b2, eps, wd
+            a.step_scalars, a.n_scalars, a.grad_scale, a.step_dev, a.reg_sum, a.reg_seed = scal.data_ptr(), 32, 1.0, step_dev.data_ptr(), reg.data_ptr(), None
+        st = torch.cuda.current_stream().cuda_stream
+        if table:
+            tab = (L.AdamTensor * len(sizes))()
+            wg_t, wg_c = [], []
+            for i in range(len(sizes)):
+                fill(tab[i], i)
+                nck = -(-sizes[i] // L.ADAM_CHUNK)
+                wg_t += [i] * nck
+                wg_c += list(range(nck))
+            hdr = L.AdamArgs()
+            header(hdr)
+            dev_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(cuda)
+            wt, wc = torch.tensor(wg_t, dtype=torch.int32, device=cuda), torch.tensor(wg_c, dtype=torch.int32, device=cuda)
+            assert lib.cdc_adam_multi_table(C.byref(hdr), dev_tab.data_ptr(), wt.data_ptr(), wc.data_ptr(), len(wg_t), st) == 0
+        else:
+            for c0 in range(0, len(sizes), L.MAX_TENSORS):
+                a = L.AdamArgs()
+                header(a)
+                n = min(L.MAX_TENSORS, len(sizes) - c0)
+                a.n_tensors = n
+                for i in range(n):
+                    fill(a.t[i], c0 + i)
+                assert lib.cdc_adam_multi(C.byref(a), st) == 0
+        torch.cuda.synchronize()
+        return [x.cpu() for x in w], [x.cpu() for x in m], [x.cpu() for x in v], float(reg.item())
+    wa, ma, va, ra = run(False)
+    wb, mb, vb, rb = run(True)
+    for i in range(len(sizes)):
+        assert torch.equal(wa[i], wb[i]) and torch.equal(ma[i], mb[i]) and torch.equal(va[i], vb[i]), f"tensor {i} ({sizes[i]} elements)"
+    assert abs(ra - rb) <= 1e-12 * abs(ra)
+    # torch.optim.Adam on w with grad + 2*l2*w (weight_decay adds wd*w itself), from the same moments at step t
+    for i in (0, 2, 3, 5):
+        p = torch.nn.Parameter(w0[i].clone())
+        opt = torch.optim.Adam([p], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+        opt.state[p] = {"step": torch.tensor(float(t - 1)), "exp_avg": m0[i].clone(), "exp_avg_sq": v0[i].clone()}
+        gi = g2_sum if i == 2 else gr[i]
+        p.grad = gi + 2 * l2 * w0[i]
+        opt.step()
+        assert_close(wb[i], p.detach(), 2e-6, 2e-7, f"torch.optim.Adam, tensor {i}")
+    # (w*w is formed in fp32 and l2 is a float: 1e-7 relative)
+    assert abs(rb - l2 * sum(float((x.double() ** 2).sum()) for x in w0)) <= 1e-6 * rb
