@@ -164,7 +164,7 @@ def train_epoch(step, loader, log_interval=None, log=None):
                 batch = nxt
                 continue
             ts = step.sibling(X.shape[0])
-        ahead = nxt[0] if (nxt is not None and ts is step and nxt[0].shape[0] == step.B and step.world == 1) else None
+        ahead = nxt[0] if (nxt is not None and ts is step and nxt[0].shape[0] == step.B) else None
         bce, reg = ts.step(*batch, next_X=ahead) if ahead is not None else ts.step(*batch)
         batch = nxt
         acc += bce.double().sum() + reg
