@@ -30,6 +30,8 @@ void cdc_set_error(const char* fmt, ...);
 // gemm2.hip: grad-weight from bf16 shadows (called by cdc_glinear_bwd_w)
 int g2_launch_bwd_w(const cdc_lin_bwdw_args* a, int64_t slab_stride, hipStream_t st);
 bool g2_bwd_w_uses_small_tiles(const cdc_lin_bwdw_args* a);
+int g2_launch_bwd_w_dual(const cdc_lin_bwdw_args* wide, const cdc_lin_bwdw_args* narrow, const cdc_lin_bwdw_args* tabs_dev, int64_t slab_wide,
+                         int64_t slab_narrow, hipStream_t st);
 
 static inline int64_t cdc_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

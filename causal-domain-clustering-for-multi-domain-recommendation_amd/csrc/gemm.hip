@@ -1140,6 +1140,26 @@ extern "C" int cdc_transpose_multi(const cdc_transpose_args* a, void* stream) {
     return 0;
 }
 
+extern "C" int cdc_glinear_bwd_w_pair(const cdc_lin_bwdw_args* wide, const cdc_lin_bwdw_args* narrow, const cdc_lin_bwdw_args* tabs_dev,
+                                      void* stream) {
+    CDC_CHECK_ARG(wide && narrow && tabs_dev, CDC_E_BADARG, "glinear_bwd_w_pair: null argument");
+    int64_t slab[2] = {0, 0};
+    for (int w = 0; w < 2; ++w) {
+        const cdc_lin_bwdw_args* a = w ? narrow : wide;
+        CDC_CHECK_ARG(a->n_groups > 0 && a->n_groups <= CDC_MAX_GROUPS && !a->row_offsets && a->split_k <= 256, CDC_E_BADARG,
+                      "glinear_bwd_w_pair: bad group count / ragged rows / split");
+        CDC_CHECK_ARG(a->split_k <= 1 || (a->workspace && a->defer_reduce), CDC_E_BADARG,
+                      "glinear_bwd_w_pair: a split launch of the pair leaves its slabs to the consumer (defer_reduce)");
+        for (int g = 0; g < a->n_groups; ++g) {
+            const cdc_bwdw_group& G = a->g[g];
+            CDC_CHECK_ARG(G.dw && G.M >= 0 && G.N > 0 && G.K > 0 && G.lddw >= G.K && !(a->defer_reduce && G.accumulate), CDC_E_BADARG,
+                          "glinear_bwd_w_pair: group %d malformed", g);
+            slab[w] += (int64_t)G.N * G.K + G.N;
+        }
+    }
+    return g2_launch_bwd_w_dual(wide, narrow, tabs_dev, slab[0], slab[1], (hipStream_t)stream);
+}
+
 extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void* stream) {
     CDC_CHECK_ARG(a && a->n_groups > 0 && a->n_groups <= CDC_MAX_GROUPS, CDC_E_BADARG, "glinear_bwd_w: bad group count");
     CDC_CHECK_ARG(prec == CDC_PREC_BF16 || prec == CDC_PREC_F32, CDC_E_BADARG, "glinear_bwd_w: bad precision");

@@ -515,17 +515,18 @@ __device__ __forceinline__ bf16x8_t g2_tr_fragment(const unsigned char* tile, in
     return u.v;
 }
 
+// (the body is a device function so that one launch can run two tile classes: k_g2_tn_dual below; `a` may live in the kernel
+// argument block or in device memory)
 template <int BMO, int BNO, int NSTAGE>
-__global__ void __launch_bounds__(G2_THREADS, 2) k_g2_tn(const cdc_lin_bwdw_args a, int64_t slab_stride) {
-    CDC_PRIO_MAIN();
+__device__ __forceinline__ void g2_tn_body(const cdc_lin_bwdw_args& a, const int64_t slab_stride, const int bid, const int nblk,
+                                           unsigned char* const smem) {
     typedef G2Tn<BMO> TA;
     typedef G2Tn<BNO> TB;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
     constexpr int MT = BMO / 32, NT = BNO / 32;
     constexpr int LOADS = TA::PER_WAVE + TB::PER_WAVE;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int S = a.split_k > 1 ? a.split_k : 1;
-    const int id = g2_xcd_remap(blockIdx.x, gridDim.x);
+    const int id = g2_xcd_remap(bid, nblk);
     const int split = id % S;
     int tile = id / S;
     int64_t g_off = 0;
@@ -652,6 +653,24 @@ __global__ void __launch_bounds__(G2_THREADS, 2) k_g2_tn(const cdc_lin_bwdw_args
 }
 
 // called by cdc_glinear_bwd_w (gemm.hip) when every group of a CDC_PREC_BF16 launch carries its shadows
+template <int BMO, int BNO, int NSTAGE>
+__global__ void __launch_bounds__(G2_THREADS, 2) k_g2_tn(const cdc_lin_bwdw_args a, int64_t slab_stride) {
+    CDC_PRIO_MAIN();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    g2_tn_body<BMO, BNO, NSTAGE>(a, slab_stride, blockIdx.x, gridDim.x, smem);
+}
+// the wide class (128 x 128 tiles) and the narrow class (64 x 64 tiles) of a step's batched grad-weight contractions in ONE launch:
+// workgroups [0, n_wide) run the first body on tabs[0], the rest the second on tabs[1] (argument blocks in device memory: two of
+// them do not fit the 4 KB kernel-argument block).  Nothing of the two classes depends on the other; as two launches the second
+// one's 14 us sat behind the first one's tail.
+__global__ void __launch_bounds__(G2_THREADS, 2) k_g2_tn_dual(const cdc_lin_bwdw_args* __restrict__ tabs, int64_t slab_wide, int64_t slab_narrow,
+                                                              int n_wide) {
+    CDC_PRIO_MAIN();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x < n_wide) g2_tn_body<128, 128, 2>(tabs[0], slab_wide, blockIdx.x, n_wide, smem);
+    else g2_tn_body<64, 64, 3>(tabs[1], slab_narrow, (int)blockIdx.x - n_wide, (int)gridDim.x - n_wide, smem);
+}
+
 int g2_launch_bwd_w(const cdc_lin_bwdw_args* a, int64_t slab_stride, hipStream_t st) {
     int max_n = 0, max_k = 0;
     for (int g = 0; g < a->n_groups; ++g) {
@@ -675,6 +694,36 @@ int g2_launch_bwd_w(const cdc_lin_bwdw_args* a, int64_t slab_stride, hipStream_t
     if (small) hipLaunchKernelGGL((k_g2_tn<64, 64, 3>), dim3((unsigned)grid), dim3(G2_THREADS), 3 * (G2Tn<64>::BYTES * 2), st, *a, slab_stride);
     else       hipLaunchKernelGGL((k_g2_tn<128, 128, 2>), dim3((unsigned)grid), dim3(G2_THREADS), 2 * (G2Tn<128>::BYTES * 2), st, *a, slab_stride);
     CDC_LAUNCH_CHECK("glinear_bwd_w(shadows)");
+    return 0;
+}
+static int64_t g2_tn_tiles(const cdc_lin_bwdw_args* a, int T) {
+    int64_t t = 0;
+    for (int g = 0; g < a->n_groups; ++g) t += cdc_ceil_div(a->g[g].N, T) * cdc_ceil_div(a->g[g].K, T);
+    return t;
+}
+int g2_launch_bwd_w_dual(const cdc_lin_bwdw_args* wide, const cdc_lin_bwdw_args* narrow, const cdc_lin_bwdw_args* tabs_dev, int64_t slab_wide,
+                         int64_t slab_narrow, hipStream_t st) {
+    for (int w = 0; w < 2; ++w) {
+        const cdc_lin_bwdw_args* a = w ? narrow : wide;
+        for (int g = 0; g < a->n_groups; ++g) {
+            const cdc_bwdw_group& G = a->g[g];
+            CDC_CHECK_ARG(G.dzh && G.xh && ((((uintptr_t)G.dzh) | ((uintptr_t)G.xh)) & 15) == 0 && G.lddzh % 8 == 0 && G.ldxh % 8 == 0, CDC_E_ALIGN,
+                          "glinear_bwd_w_pair: group %d of the %s class: bf16 shadows, 16-byte aligned, row strides multiples of 8", g, w ? "narrow" : "wide");
+            CDC_CHECK_ARG(w ? G.N <= 64 : true, CDC_E_BADARG, "glinear_bwd_w_pair: group %d of the narrow class has %d output rows", g, G.N);
+        }
+    }
+    const int64_t nw = g2_tn_tiles(wide, 128) * (wide->split_k > 1 ? wide->split_k : 1);
+    const int64_t nn = g2_tn_tiles(narrow, 64) * (narrow->split_k > 1 ? narrow->split_k : 1);
+    CDC_CHECK_ARG(nw + nn < (1ll << 31) && nw > 0 && nn > 0, CDC_E_TOOBIG, "glinear_bwd_w_pair: grid out of range");
+    constexpr int LDS_W = 2 * (G2Tn<128>::BYTES * 2), LDS_N = 3 * (G2Tn<64>::BYTES * 2);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_g2_tn_dual, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_W > LDS_N ? LDS_W : LDS_N);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_g2_tn_dual, dim3((unsigned)(nw + nn)), dim3(G2_THREADS), LDS_W > LDS_N ? LDS_W : LDS_N, st, tabs_dev, slab_wide, slab_narrow,
+                       (int)nw);
+    CDC_LAUNCH_CHECK("glinear_bwd_w_pair");
     return 0;
 }
 bool g2_bwd_w_uses_small_tiles(const cdc_lin_bwdw_args* a) {

@@ -532,6 +532,13 @@ class Plan:
             self._gemm_ws = torch.empty(shared + extra, dtype=torch.float32, device=self.device)
             for a in self._gemm_ws_users:
                 a.workspace = self._gemm_ws.data_ptr()
+        pair = None
+        if (len(dw) == 2 and all(id(a) in own or a.split_k <= 1 for a, _ in dw) and self.defer_dw_reduce and
+                os.environ.get("CDC_DW_PAIR", "1") != "0"):
+            (aw, _), (an, _) = dw
+            shad = lambda a: all(a.g[i].dzh and a.g[i].xh for i in range(a.n_groups))      # noqa: E731
+            if shad(aw) and shad(an) and any(aw.g[i].N > 64 for i in range(aw.n_groups)) and all(an.g[i].N <= 64 for i in range(an.n_groups)):
+                pair = (aw, an)
         for a, fl in dw:
             a.workspace = self._gemm_ws.data_ptr()
             if id(a) in own:
@@ -545,7 +552,18 @@ class Plan:
                     if G.db:
                         self.grad_slabs[G.db] = (a.workspace + 4 * (pos + G.N * G.K), slab, a.split_k)
                     pos += G.N * G.K + G.N
+            if pair is not None:
+                continue
             step = self.call("cdc_glinear_bwd_w", C.byref(a), self.prec, flops=fl)
+            self.bwd_steps.append(step)
+            self.deferred_dw_steps.append(step)
+        if pair is not None:
+            # the wide and the narrow class of the batched grad-weight contractions in one launch (csrc/gemm2.hip k_g2_tn_dual): the
+            # two argument blocks travel as a device copy, made now that their workspaces are final
+            aw, an = pair
+            self._dw_pair_dev = torch.frombuffer(bytearray(bytes(aw) + bytes(an)), dtype=torch.uint8).to(self.device)
+            step = self.call("cdc_glinear_bwd_w_pair", C.byref(aw), C.byref(an), self._dw_pair_dev.data_ptr(), what="cdc_glinear_bwd_w",
+                             flops=sum(fl for _, fl in dw))
             self.bwd_steps.append(step)
             self.deferred_dw_steps.append(step)
         self.bwd_steps[0:0] = self._emit_transposes()

@@ -379,6 +379,12 @@ typedef struct {
     cdc_bwdw_group g[CDC_MAX_GROUPS];
 } cdc_lin_bwdw_args;
 int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void* stream);
+/* two grad-weight launches of the bf16-shadow form in ONE launch: `wide` (128 x 128 output tiles) and `narrow` (every group N <= 64:
+ * 64 x 64 tiles), e.g. a step's two batched launches.  tabs_dev: a DEVICE copy of the two argument blocks, [wide, narrow] (two blocks do
+ * not fit a kernel-argument block); the host copies are read for validation and the grid.  Each block: every group with both shadows,
+ * no row_offsets, and either split_k <= 1 or defer_reduce (the slab-adding launch is left to the consumer).  Same arithmetic as two
+ * cdc_glinear_bwd_w calls. */
+int cdc_glinear_bwd_w_pair(const cdc_lin_bwdw_args* wide, const cdc_lin_bwdw_args* narrow, const cdc_lin_bwdw_args* tabs_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gate softmax + expert pooling (reference: model/ple.py:89-94,105-123; model/mmoe.py:37-40,58-60)
