@@ -35,7 +35,7 @@ def _batches(n, seed=1):
     return X.reshape(n, B, FIELDS), y.reshape(n, B), X[:, 10].astype(np.int64).reshape(n, B)
 
 
-def _run(cuda, table_mode, use_graph=False, n=4, fast_replay=False, precision="f32", dropout=0.0):
+def _run(cuda, table_mode, use_graph=False, n=4, fast_replay=False, precision="f32", dropout=0.0, announce=False):
     from cdcmdr_amd.optim import FusedAdam
     from cdcmdr_amd.trainer import TrainStep
     model = _model(cuda, precision, dropout)
@@ -43,9 +43,14 @@ def _run(cuda, table_mode, use_graph=False, n=4, fast_replay=False, precision="f
     ts = TrainStep(model, opt, B, use_graph=use_graph)
     X, y, g = _batches(n)
     losses = []
+    Xd = [torch.from_numpy(X[s]).to(cuda) for s in range(n)]
     for s in range(n):
-        bce, _ = ts.step(torch.from_numpy(X[s]).to(cuda), torch.from_numpy(y[s]).to(cuda), torch.from_numpy(g[s]).to(cuda))
+        # announce: every step names the next batch, whose rows are then sorted on the side chain of this step (trainer._sort_ahead)
+        nxt = Xd[s + 1] if (announce and s + 1 < n) else None
+        bce, _ = ts.step(Xd[s], torch.from_numpy(y[s]).to(cuda), torch.from_numpy(g[s]).to(cuda), next_X=nxt)
         losses.append(bce.clone())
+    if announce:
+        assert getattr(ts, "_ahead_ok", False) and ts._parity == (n - 1) % 2, "the look-ahead sort was not used"
     ts.check_ids()
     opt.flush_table()
     touched = np.unique((X + np.arange(FIELDS, dtype=np.int64) * VOCAB).reshape(-1))
@@ -80,6 +85,9 @@ def test_full_size_step_is_deterministic_and_mode_independent(cuda):
     # bf16 contractions + dropout (the bench configuration): still deterministic run to run, graph or not
     a = _run(cuda, "lazy", use_graph=True, fast_replay=True, precision="bf16", dropout=0.2)
     _same(a, _run(cuda, "lazy", use_graph=False, fast_replay=True, precision="bf16", dropout=0.2), "bench configuration, graph vs eager")
+    # the row sort of the next batch one step ahead (what bench.py and data.train_epoch do): same bits
+    _same(a, _run(cuda, "lazy", use_graph=True, fast_replay=True, precision="bf16", dropout=0.2, announce=True),
+          "bench configuration, next batch announced vs every step sorting its own")
     # untouched rows moved ~lr per step, touched or not the table stayed finite
     assert np.isfinite(dense["checksum"])
 
