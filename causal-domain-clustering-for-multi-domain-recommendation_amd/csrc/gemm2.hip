@@ -311,6 +311,41 @@ __global__ void __launch_bounds__(G2_THREADS, (G2Cfg<BM, BN, NSTAGE>::BLOCKS_PER
                     *reinterpret_cast<bf16x8_t*>(hp + (int64_t)lr * O.ldyh) = h8;
                 }
             }
+        } else if (act_all && O.mask != nullptr && O.mask_bf16 && !O.accumulate) {
+            // grad-input whose activation mask is a bf16 shadow (the expert stacks): ALL of the thread's mask vectors are fetched
+            // before the first is used — one at a time, every pass of the row loop waited a memory latency (the layer-2 grad-input
+            // launch: 2 K slabs of MFMA work behind 8 such waits)
+            constexpr int PASSES = G2_BM / ROWS_PER_PASS;
+            bf16x8_t m8[PASSES];
+#pragma unroll
+            for (int p_ = 0; p_ < PASSES; ++p_) {
+                const int lr = lr0 + p_ * ROWS_PER_PASS;
+                m8[p_] = lr < row_end ? *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const __bf16*>(O.mask) + (int64_t)(i0 + lr) * O.ldmask + col)
+                                      : bf16x8_t{};
+            }
+#pragma unroll
+            for (int p_ = 0; p_ < PASSES; ++p_) {
+                const int lr = lr0 + p_ * ROWS_PER_PASS;
+                if (lr >= row_end) break;
+                f32x4_t lo = *reinterpret_cast<const f32x4_t*>(ct + lr * Cfg::CS + c8);
+                f32x4_t hi = *reinterpret_cast<const f32x4_t*>(ct + lr * Cfg::CS + c8 + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    lo[q] = (float)m8[p_][q] > 0.f ? lo[q] * a.mask_scale : 0.f;
+                    hi[q] = (float)m8[p_][4 + q] > 0.f ? hi[q] * a.mask_scale : 0.f;
+                }
+                if (G2_PROBE & 8) { if (lo[0] != 123.456f) continue; }
+                if (yp) {
+                    *reinterpret_cast<f32x4_t*>(yp + (int64_t)lr * O.ldy) = lo;
+                    *reinterpret_cast<f32x4_t*>(yp + (int64_t)lr * O.ldy + 4) = hi;
+                }
+                if (hp) {
+                    bf16x8_t h8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { h8[q] = (__bf16)lo[q]; h8[4 + q] = (__bf16)hi[q]; }
+                    *reinterpret_cast<bf16x8_t*>(hp + (int64_t)lr * O.ldyh) = h8;
+                }
+            }
         } else {
             const bool masked = act_all && O.mask != nullptr;
 #pragma unroll 2
