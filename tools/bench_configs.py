@@ -23,11 +23,11 @@ def run(name, model, mode, B, field_dims, n_domain, domain_idx, steps=60, warm=3
     yd = torch.from_numpy(y).to(dev).view(pool, B)
     gd = Xd[:, :, domain_idx].to(torch.int64) if mode in ("multi", "star") else None
     for i in range(warm):
-        ts.step(Xd[i % pool], yd[i % pool], None if gd is None else gd[i % pool])
+        ts.step(Xd[i % pool], yd[i % pool], None if gd is None else gd[i % pool], next_X=Xd[(i + 1) % pool])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        ts.step(Xd[i % pool], yd[i % pool], None if gd is None else gd[i % pool])
+    for i in range(warm, warm + steps):
+        ts.step(Xd[i % pool], yd[i % pool], None if gd is None else gd[i % pool], next_X=Xd[(i + 1) % pool])
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     ts.check_ids()
