@@ -269,6 +269,33 @@ class HeadArgs(C.Structure):
                 ("bce_inv_count", c_f), ("pad2_", c_i32), ("t", HeadTower * HEAD_MAX_TOWERS)]
 
 
+TOWER_MAX = 4
+TOWER_ROWS = 128
+TOWER_ERR_TIMEOUT = 0x40000000
+
+
+class TowerLayer(C.Structure):
+    _fields_ = [("wh", c_p), ("ldwh", c_i64), ("wt", c_p), ("ldwt", c_i64), ("bias", c_p), ("z", c_p), ("ldz", c_i64),
+                ("dzh", c_p), ("lddzh", c_i64), ("gamma", c_p), ("beta", c_p), ("running_mean", c_p), ("running_var", c_p),
+                ("num_batches_tracked", c_p), ("save_mean", c_p), ("save_invstd", c_p), ("dgamma", c_p), ("dbeta", c_p)]
+
+
+class TowerDesc(C.Structure):
+    _fields_ = [("xh", c_p), ("ldxh", c_i64), ("dx", c_p), ("lddx", c_i64), ("accumulate_dx", c_i32), ("pad_", c_i32),
+                ("l1", TowerLayer), ("l2", TowerLayer), ("a1h", c_p), ("lda1h", c_i64), ("a2", c_p), ("lda2", c_i64),
+                ("wo", c_p), ("bo", c_p), ("dwo", c_p), ("dbo", c_p)]
+
+
+class TowerArgs(C.Structure):
+    _fields_ = [("n_tower", c_i32), ("H0", c_i32), ("H1", c_i32), ("H2", c_i32), ("M", c_i64), ("relu", c_i32), ("sigmoid", c_i32),
+                ("drop_p", c_f), ("eps", c_f), ("momentum", c_f), ("pad_", c_i32), ("seed1", C.c_uint64), ("seed2", C.c_uint64),
+                ("seed_offset_dev", c_p), ("out", c_p), ("ld_out", c_i64), ("d_out", c_p), ("ld_dout", c_i64),
+                ("wide_x", c_p), ("ld_wide", c_i64), ("wide_w", c_p), ("wide_bias", c_p), ("wide_dx", c_p), ("ld_wide_dx", c_i64),
+                ("wide_dw", c_p), ("wide_dbias", c_p), ("wide_K", c_i32), ("accumulate_wide_dx", c_i32),
+                ("bce_group", c_p), ("bce_y_i16", c_p), ("bce_y_f32", c_p), ("bce_loss", c_p), ("bce_inv_count", c_f), ("pad2_", c_i32),
+                ("workspace", c_p), ("err", c_p), ("t", TowerDesc * TOWER_MAX)]
+
+
 class StarFuseArgs(C.Structure):
     _fields_ = [("n", c_i32), ("op", c_i32), ("size", c_i64), ("s", c_p), ("ds", c_p), ("accumulate_ds", c_i32), ("pad_", c_i32),
                 ("a", c_p * MAX_GROUPS), ("out", c_p * MAX_GROUPS), ("da", c_p * MAX_GROUPS)]
@@ -337,6 +364,9 @@ _SIGNATURES = {
     "cdc_head_fwd": (c_i32, [C.POINTER(HeadArgs), c_p]),
     "cdc_head_bwd": (c_i32, [C.POINTER(HeadArgs), c_p]),
     "cdc_head_workspace_floats": (c_i64, [C.POINTER(HeadArgs)]),
+    "cdc_tower_fwd": (c_i32, [C.POINTER(TowerArgs), c_p]),
+    "cdc_tower_bwd": (c_i32, [C.POINTER(TowerArgs), c_p]),
+    "cdc_tower_workspace_bytes": (c_i64, [C.POINTER(TowerArgs)]),
     "cdc_bce_fwd_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f, c_p]),
     "cdc_attn_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),
     "cdc_attn_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),

@@ -14,7 +14,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libcdcmdr.so")
 STAMP = os.path.join(PKG_DIR, "libcdcmdr.so.stamp")
 
-SOURCES = ["misc.hip", "embedding.hip", "gemm.hip", "gemm2.hip", "rowops.hip", "cgc.hip", "pair.hip", "head.hip", "metrics.hip", "attention.hip"]
+SOURCES = ["misc.hip", "embedding.hip", "gemm.hip", "gemm2.hip", "rowops.hip", "cgc.hip", "pair.hip", "head.hip", "tower.hip", "metrics.hip", "attention.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-ffp-contract=off"]
 
 

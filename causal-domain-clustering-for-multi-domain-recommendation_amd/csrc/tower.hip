@@ -1,0 +1,1020 @@
+// tower.hip — the towers of a multi-tower model in ONE forward and ONE backward launch (round 4).
+//
+// Reference: BaseModel.tower_forward (model/layer.py:35-56) over MultiLayerPerceptron(H0, (H1, H2), dropout, output_layer=True)
+// towers (model/layer.py:178-206): per tower Linear -> BatchNorm1d -> ReLU -> Dropout -> Linear -> BatchNorm1d -> ReLU -> Dropout ->
+// Linear(->1), `+= other` (the wide term, model/layer.py:122-126), Sigmoid; in the training step BCELoss(mean) on the row's own
+// tower (run.py:484,723) and the whole backward of the chain.
+//
+// Before (round 3): 13 launches of 5.5-15 us each for 0.3 % of the step's flops — two bf16 contractions, two BatchNorm
+// normalisations, the head, and the mirror chain (head backward + ordered final, 2 x (statistics, normalise), two grad-input
+// contractions): 111 us of the 305 us main chain of a C2 step (profiles/round3/step_timeline.txt).  Every one of them only
+// re-reads what its predecessor wrote; what forces launch boundaries is BatchNorm's batch statistics — a sum over ALL rows
+// between any two layers.  Here a workgroup owns CDC_TOWER_ROWS rows of one tower and keeps them in LDS from the first
+// contraction to the sigmoid (forward) and from the loss gradient to the input gradient (backward); the column sums are
+// exchanged among the workgroups of a tower INSIDE the launch:
+//     publish partial sums (write-through stores) -> every storing wave drains (s_waitcnt vmcnt(0)) -> workgroup barrier ->
+//     ONE lane adds to the tower's arrival counter (agent scope) ... ONE lane polls the counter (write-through loads, bounded
+//     spin) -> workgroup barrier -> every workgroup adds ALL partials up in the same fixed order (write-through loads).
+// That is the hand-off of MI355X_MICROARCH.md (inter-workgroup visibility: "ONE lane of each storing workgroup ... agent-scope
+// atomic add" / "sc1 load poll of that counter" / "stores, all sc1; loads, all sc1"): no fence, no reliance on placement.  Every
+// word another workgroup reads is stored and loaded through tw_st/tw_ld below (relaxed agent-scope atomics = global_store/load
+// ... sc1), nothing else.  Work that needs no exchange runs under the waits: the wide term's dot products (forward), the wide
+// term's gradients (backward).  A spin that runs out sets CDC_TOWER_ERR_TIMEOUT in *err and a poison word that ends the other
+// waits of the launch at once, so the grid always drains.  Residency: at most 256 workgroups of 256 threads, one per CU, <= 128
+// VGPRs — they fit beside the background replay slice (2 x 64 VGPRs per SIMD, no LDS); kernels of the other queue that hold a
+// CU finish without depending on this launch.
+//
+// Arithmetic = that of the launches replaced (csrc/gemm2.hip, csrc/rowops.hip k_bn_*_v4, csrc/head.hip): bf16 operands rounded
+// to nearest even from fp32, v_mfma_f32_16x16x32_bf16 over K in ascending 32-wide steps, bias added in fp32 afterwards; BatchNorm
+// statistics as fp64 sums per 64-row chunk (wave q adds rows 16q..16q+15, quarters in order) and chunks added as NP interleaved
+// partial sums in order — the bits of cdc_gemm_bf16_nt's statistics epilogue + cdc_bn_fwd; (x - mean) * invstd * gamma + beta;
+// the 32-bit dropout stream of the BatchNorm launches (stream 64 + tower, one hash per column pair).  The backward's column
+// sums are fp64 sums per row block in a fixed order of their own (not the bits of k_bn_bwd_stats_v4's shuffle tree).
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define TW_THREADS 256
+#define TW_ROWS CDC_TOWER_ROWS
+#define TW_KARG __attribute__((address_space(4)))
+#define TW_GLOBAL __attribute__((address_space(1)))
+#define TW_SLAB (TW_ROWS * 128)              /* one 64-column bf16 slab of a 128-row operand tile */
+#define TW_SPIN_LIMIT 200000u                /* polls of ~1 us: a wait gives up after ~0.2 s */
+#define TW_HDR_BYTES 4096
+#define TW_LINE 32                           /* ints per 128-byte line: every counter on a line of its own */
+// header lines
+#define TW_F1(t) (t)
+#define TW_F2(t) (4 + (t))
+#define TW_FDONE 8
+#define TW_B3(t) (9 + (t))
+#define TW_B4 13
+#define TW_BDONE 14
+#define TW_POISON 15
+
+// ---- inter-workgroup accessors: relaxed agent-scope atomics on GLOBAL pointers (global_load / global_store ... sc1)
+template <typename T> __device__ __forceinline__ T tw_ld(const T* p) {
+    return __hip_atomic_load((const TW_GLOBAL T*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ void tw_st(T* p, T v) {
+    __hip_atomic_store((TW_GLOBAL T*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int tw_add(int* p, int v) {
+    return __hip_atomic_fetch_add((TW_GLOBAL int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tw_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// every storing wave has drained and passed the workgroup barrier before this: ONE lane signals for the workgroup
+__device__ __forceinline__ void tw_arrive(int* hdr, int line) { tw_add(hdr + line * TW_LINE, 1); }
+// ONE lane: bounded poll of an arrival counter.  false = gave up (the launch's results are void; *err says so)
+__device__ __forceinline__ bool tw_wait(int* hdr, int line, int target, int32_t* err) {
+    int* cnt = hdr + line * TW_LINE;
+    int* poison = hdr + TW_POISON * TW_LINE;
+    for (unsigned spins = 0;; ++spins) {
+        if (tw_ld(cnt) >= target) return true;
+        __builtin_amdgcn_s_sleep(8);
+        if ((spins & 63u) == 63u && tw_ld(poison) != 0) return false;
+        if (spins >= TW_SPIN_LIMIT) {
+            tw_st(poison, 1);
+            if (err) __hip_atomic_fetch_or((TW_GLOBAL int32_t*)err, (int32_t)CDC_TOWER_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+}
+// the last workgroup through `done_line` puts every word of its direction back to zero for the next launch (all others are
+// past their last poll: a workgroup adds here after it)
+__device__ __forceinline__ void tw_finish(int* hdr, int done_line, int n_wg, int first_line, int last_line) {
+    const int old = tw_add(hdr + done_line * TW_LINE, 1);
+    if (old == n_wg - 1) {
+        for (int l = first_line; l <= last_line; ++l) tw_st(hdr + l * TW_LINE, 0);
+        tw_st(hdr + TW_POISON * TW_LINE, 0);
+    }
+}
+
+// ---- workspace layout (bytes from the start of `workspace`)
+struct TwLayout {
+    int64_t st1, st2;        // forward: per 64-row chunk column sums (x, x^2): [chunk][n_tower*H][2] doubles
+    int64_t b2, b1;          // backward: per row block column sums (dz, dz*xhat): [block][n_tower*H][2] doubles
+    int64_t hd;              // backward: head weight-gradient partials [block][n_tower][H2 + 4] floats (slot H2 = bias)
+    int64_t wd;              // backward: wide weight-gradient partials [n_tower*block][WD_LD] floats (slot wide_K = bias)
+    int64_t loss;            // backward: [block] doubles
+    int64_t total;
+    int wd_ld;
+};
+__host__ __device__ inline TwLayout tw_layout(int n_tower, int H1, int H2, int64_t M, int wide_K) {
+    TwLayout L;
+    const int64_t nchunk = (M + 63) / 64, G = (M + TW_ROWS - 1) / TW_ROWS;
+    int64_t o = TW_HDR_BYTES;
+    L.st1 = o; o += nchunk * n_tower * H1 * 16;
+    L.st2 = o; o += nchunk * n_tower * H2 * 16;
+    L.b2 = o; o += G * n_tower * H2 * 16;
+    L.b1 = o; o += G * n_tower * H1 * 16;
+    L.hd = o; o += G * n_tower * (H2 + 4) * 4;
+    L.wd_ld = (wide_K + 1 + 3) / 4 * 4;
+    L.wd = o; o += (int64_t)n_tower * G * L.wd_ld * 4;
+    o = (o + 15) / 16 * 16;
+    L.loss = o; o += G * 8;
+    L.total = (o + 127) / 128 * 128;
+    return L;
+}
+
+// ---- operand tiles in LDS: rows of 128 bytes (64 bf16), the 16-byte chunk index XORed by (row & 7) as in csrc/gemm2.hip
+__device__ __forceinline__ void tw_glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const TW_GLOBAL void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+// rows [0, n_rows) of a row-major bf16 matrix (row stride ld elements, 64-column slab `slab`) -> tile; n_rows a multiple of 32;
+// rows >= valid are fetched from row valid-1 (their products are never stored)
+__device__ __forceinline__ void tw_load_tile(const __bf16* src, int64_t ld, int slab, int n_rows, int valid, unsigned char* tile,
+                                             int wave, int lane) {
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+    const int per_wave = n_rows / 4;
+    for (int q = 0; q < per_wave / 8; ++q) {
+        const int r0 = wave * per_wave + q * 8;
+        int r = r0 + lrow;
+        r = r < valid ? r : valid - 1;
+        tw_glds16(src + (int64_t)r * ld + slab * 64 + lchunk * 8, tile + r0 * 128);
+    }
+}
+__device__ __forceinline__ bf16x8_t tw_frag(const unsigned char* tile, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ void tw_put8(unsigned char* tile, int row, int chunk, const float (&v)[8]) {
+    bf16x8_t h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) h[q] = (__bf16)v[q];
+    *reinterpret_cast<bf16x8_t*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4)) = h;
+}
+
+// C[128 x NT*16] += A[128 x KS*32] * B^T, wave w owns rows 32w..32w+31; A, B tiles in LDS (slabs of 64 columns)
+template <int NT, int KS>
+__device__ __forceinline__ void tw_mfma(const unsigned char* A, const unsigned char* Bt, int b_slab_bytes, f32x4_t (&acc)[2][NT], int wave, int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const unsigned char* As = A + (ks >> 1) * TW_SLAB;
+        const unsigned char* Bs = Bt + (ks >> 1) * b_slab_bytes;
+        const int chunk = (ks & 1) * 4 + fq;
+        bf16x8_t af[2], bfr[NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[mt] = tw_frag(As, wave * 32 + mt * 16 + frow, chunk);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bfr[nt] = tw_frag(Bs, nt * 16 + frow, chunk);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void tw_acc_to_tile(const f32x4_t (&acc)[2][NT], float* ct, int cs, int wave, int lane) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ct[(wave * 32 + mt * 16 + (lane >> 4) * 4 + r) * cs + nt * 16 + (lane & 15)] = acc[mt][nt][r];
+}
+
+// ---- forward statistics of one layer: this workgroup's (at most two) 64-row chunks -> workspace, in the order of
+// cdc_gemm_bf16_nt's statistics epilogue (csrc/gemm2.hip): wave q adds rows 16q..16q+15 of the chunk, quarters in order.
+// All threads call (barriers inside).  Only wave 0 stores; it drains before it returns.
+template <int C>
+__device__ __forceinline__ void tw_fwd_chunk_sums(const float* ct, int cs, int row0, int M, double* quarter /*[4][64][2]*/, double* ws,
+                                                  int total_c, int col0, int wave, int lane) {
+#pragma unroll
+    for (int h = 0; h < TW_ROWS / 64; ++h) {
+        const int r_lo = row0 + h * 64;
+        if (r_lo >= M) break;                                            // uniform
+        const int rows = min(64, M - r_lo);
+        double s1 = 0.0, s2 = 0.0;
+        if (lane < C) {
+            for (int r = wave * 16; r < min(wave * 16 + 16, rows); ++r) {
+                const double x = (double)ct[(h * 64 + r) * cs + lane];
+                s1 += x; s2 += x * x;
+            }
+        }
+        quarter[(wave * 64 + lane) * 2] = s1; quarter[(wave * 64 + lane) * 2 + 1] = s2;
+        __syncthreads();
+        if (wave == 0 && lane < C) {
+            double* p = ws + ((int64_t)(r_lo / 64) * total_c + col0 + lane) * 2;
+            tw_st(p, ((quarter[(0 * 64 + lane) * 2] + quarter[(1 * 64 + lane) * 2]) + quarter[(2 * 64 + lane) * 2]) + quarter[(3 * 64 + lane) * 2]);
+            tw_st(p + 1, ((quarter[(0 * 64 + lane) * 2 + 1] + quarter[(1 * 64 + lane) * 2 + 1]) + quarter[(2 * 64 + lane) * 2 + 1]) + quarter[(3 * 64 + lane) * 2 + 1]);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) tw_drain();
+}
+// Sum over `n_parts` published partial records of the tower's C columns, as cdc_bn_fwd's bn_sum_partials_v does: NP = 256 / C
+// threads per column take records pt, pt + NP, ... and the NP sums are added in order.  out[2][C] doubles in LDS.  All threads call.
+template <int C>
+__device__ __forceinline__ void tw_gather_sums(const double* ws, int n_parts, int total_c, int col0, double* part /*[2][NP][C]*/, double* out, int tid) {
+    constexpr int NP = TW_THREADS / C;
+    const int j = tid % C, pt = tid / C;
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll 4
+    for (int k = pt; k < n_parts; k += NP) {
+        const double* p = ws + ((int64_t)k * total_c + col0 + j) * 2;
+        a1 += tw_ld(p); a2 += tw_ld(p + 1);
+    }
+    part[(0 * NP + pt) * C + j] = a1; part[(1 * NP + pt) * C + j] = a2;
+    __syncthreads();
+    if (tid < C) {
+        double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { b1 += part[(0 * NP + q) * C + tid]; b2 += part[(1 * NP + q) * C + tid]; }
+        out[tid] = b1; out[C + tid] = b2;
+    }
+    __syncthreads();
+}
+// batch mean / biased variance -> col_mean, col_inv (LDS); the tower's first workgroup also writes what the module keeps
+template <int C>
+__device__ __forceinline__ void tw_finish_stats(const double* sums, int Ms, float eps, float momentum, bool writer, float* save_mean,
+                                                float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, float* col_mean,
+                                                float* col_inv, int tid) {
+    if (tid < C) {
+        const double s1 = sums[tid], s2 = sums[C + tid];
+        const double mu = s1 / Ms;
+        double var = s2 / Ms - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)mu;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (writer) {
+            if (save_mean) save_mean[tid] = mean;
+            if (save_invstd) save_invstd[tid] = invstd;
+            if (running_mean) {
+                const double unbiased = Ms > 1 ? var * ((double)Ms / (double)(Ms - 1)) : var;
+                running_mean[tid] = (1.f - momentum) * running_mean[tid] + momentum * mean;
+                running_var[tid] = (1.f - momentum) * running_var[tid] + momentum * (float)unbiased;
+            }
+        }
+        col_mean[tid] = mean; col_inv[tid] = invstd;
+    }
+    if (writer && tid == 0 && nbt) *nbt += 1;
+    __syncthreads();
+}
+// normalise + ReLU + dropout of 8 neighbouring columns (k_bn_apply_v4's arithmetic and dropout decisions)
+__device__ __forceinline__ void tw_bn_apply8(float (&v)[8], const float* col_mean, const float* col_inv, const float* gamma, const float* beta, int c,
+                                             bool relu, float drop_p, float keep_scale, uint32_t thr16, uint32_t seed32, int grow) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float x = (v[q] - col_mean[c + q]) * col_inv[c + q] * gamma[c + q] + beta[c + q];
+        if (relu) x = fmaxf(x, 0.f);
+        v[q] = x;
+    }
+    if (drop_p > 0.f) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const uint32_t h = g2_drop_bits(seed32, grow, (c >> 1) + pr);
+            v[2 * pr] = (h & 0xFFFFu) < thr16 ? 0.f : v[2 * pr] * keep_scale;
+            v[2 * pr + 1] = (h >> 16) < thr16 ? 0.f : v[2 * pr + 1] * keep_scale;
+        }
+    }
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+template <int NK0, int H1, int H2>
+struct TwFwdCfg {
+    static constexpr int CS1 = H1 + 4, CS2 = H2 + 4;
+    static constexpr int XS = 0;                                     // [NK0][128][64] bf16
+    static constexpr int W1S = XS + NK0 * TW_SLAB;                   // [NK0][H1][64] bf16
+    static constexpr int W2S = W1S + NK0 * H1 * 128;                 // [H1/64][H2][64] bf16
+    static constexpr int A1S = W2S + (H1 / 64) * H2 * 128;           // [H1/64][128][64] bf16
+    static constexpr int CT = A1S + (H1 / 64) * TW_SLAB;             // [128][CS1] fp32 (layer 2: [128][CS2])
+    static constexpr int PART = CT + TW_ROWS * CS1 * 4;              // [2][8][64] doubles (also the chunk quarters)
+    static constexpr int SUMS = PART + 2 * 8 * 64 * 8;               // [2][64] doubles
+    static constexpr int CMEAN = SUMS + 2 * 64 * 8;                  // [64] floats
+    static constexpr int CINV = CMEAN + 64 * 4;
+    static constexpr int WIDE = CINV + 64 * 4;                       // [128] floats
+    static constexpr int SMEM = WIDE + TW_ROWS * 4;
+};
+
+template <int NK0, int H1, int H2>
+__global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a_by_value) {
+    CDC_PRIO_MAIN();
+    (void)a_by_value;
+    const TW_KARG cdc_tower_args& a = *(const TW_KARG cdc_tower_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef TwFwdCfg<NK0, H1, H2> Cfg;
+    static_assert(H1 % 64 == 0 && H1 <= 64 && H2 % 16 == 0 && H2 <= 64 && H2 % 8 == 0, "instantiated shapes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = (int)a.M, n_tower = a.n_tower;
+    const int G = (M + TW_ROWS - 1) / TW_ROWS;
+    const int t = (int)blockIdx.x / G, jb = (int)blockIdx.x - t * G;
+    const int row0 = jb * TW_ROWS, rows = min(TW_ROWS, M - row0);
+    const TW_KARG cdc_tower_desc& T = a.t[t];
+    int* hdr = reinterpret_cast<int*>(a.workspace);
+    const TwLayout L = tw_layout(n_tower, H1, H2, M, a.wide_x ? a.wide_K : 0);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(a.workspace);
+    int32_t* err = a.err;
+    const bool writer = jb == 0;
+
+    unsigned char* XS = smem + Cfg::XS;
+    unsigned char* W1S = smem + Cfg::W1S;
+    unsigned char* W2S = smem + Cfg::W2S;
+    unsigned char* A1S = smem + Cfg::A1S;
+    float* ct = reinterpret_cast<float*>(smem + Cfg::CT);
+    double* part = reinterpret_cast<double*>(smem + Cfg::PART);
+    double* sums = reinterpret_cast<double*>(smem + Cfg::SUMS);
+    float* col_mean = reinterpret_cast<float*>(smem + Cfg::CMEAN);
+    float* col_inv = reinterpret_cast<float*>(smem + Cfg::CINV);
+    float* wide_s = reinterpret_cast<float*>(smem + Cfg::WIDE);
+
+    // ---- operands of both contractions: global -> LDS, all in flight at once
+    {
+        const __bf16* xh = reinterpret_cast<const __bf16*>(T.xh) + (int64_t)row0 * T.ldxh;
+        const __bf16* w1 = reinterpret_cast<const __bf16*>(T.l1.wh);
+        const __bf16* w2 = reinterpret_cast<const __bf16*>(T.l2.wh);
+        const int64_t ldx = T.ldxh, ldw1 = T.l1.ldwh, ldw2 = T.l2.ldwh;
+#pragma unroll
+        for (int s = 0; s < NK0; ++s) {
+            tw_load_tile(xh, ldx, s, TW_ROWS, rows, XS + s * TW_SLAB, wave, lane);
+            tw_load_tile(w1, ldw1, s, H1, H1, W1S + s * H1 * 128, wave, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < H1 / 64; ++s) tw_load_tile(w2, ldw2, s, H2, H2, W2S + s * H2 * 128, wave, lane);
+    }
+    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thr16 = (uint32_t)(a.drop_p * 65536.f + 0.5f);
+    const bool relu = a.relu != 0;
+    const float drop_p = a.drop_p;
+    tw_drain();
+    __syncthreads();
+
+    // ================= layer 1: Z1 = X W1^T + b1
+    {
+        f32x4_t acc[2][H1 / 16];
+        tw_mfma<H1 / 16, NK0 * 2>(XS, W1S, H1 * 128, acc, wave, lane);
+        tw_acc_to_tile<H1 / 16>(acc, ct, Cfg::CS1, wave, lane);
+    }
+    __syncthreads();
+    {
+        constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+        const int c = (tid % C8) * 8, lr0 = tid / C8;
+        const float* bias = T.l1.bias;
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bias + c), b1 = *reinterpret_cast<const f32x4_t*>(bias + c + 4);
+        float* z = T.l1.z; const int64_t ldz = T.l1.ldz;
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            f32x4_t lo = *reinterpret_cast<const f32x4_t*>(ct + lr * Cfg::CS1 + c) + b0;
+            f32x4_t hi = *reinterpret_cast<const f32x4_t*>(ct + lr * Cfg::CS1 + c + 4) + b1;
+            *reinterpret_cast<f32x4_t*>(ct + lr * Cfg::CS1 + c) = lo;
+            *reinterpret_cast<f32x4_t*>(ct + lr * Cfg::CS1 + c + 4) = hi;
+            if (lr < rows) {
+                *reinterpret_cast<f32x4_t*>(z + (int64_t)(row0 + lr) * ldz + c) = lo;
+                *reinterpret_cast<f32x4_t*>(z + (int64_t)(row0 + lr) * ldz + c + 4) = hi;
+            }
+        }
+    }
+    __syncthreads();
+    tw_fwd_chunk_sums<H1>(ct, Cfg::CS1, row0, M, part, reinterpret_cast<double*>(wsb + L.st1), n_tower * H1, t * H1, wave, lane);
+    if (tid == 0) tw_arrive(hdr, TW_F1(t));
+
+    // ---- under the wait: the wide term of this block's rows (model/layer.py:122-126), half a wave per row, 16-byte lanes
+    if (a.wide_x) {
+        const float* wx = a.wide_x; const int64_t ldw = a.ld_wide; const int K4 = a.wide_K >> 2;
+        const int hl = lane & 31, half = lane >> 5;
+        f32x4_t wv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[q] = (hl + 32 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(a.wide_w + 4 * (hl + 32 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const float wb = a.wide_bias ? a.wide_bias[0] : 0.f;
+        for (int i = 0; i < 16; ++i) {
+            const int lr = wave * 32 + i * 2 + half;
+            const int gr = row0 + min(lr, rows - 1);
+            f32x4_t xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                xv[q] = (hl + 32 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(wx + (int64_t)gr * ldw + 4 * (hl + 32 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s += (xv[q][0] * wv[q][0] + xv[q][1] * wv[q][1]) + (xv[q][2] * wv[q][2] + xv[q][3] * wv[q][3]);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (hl == 0) wide_s[lr] = s + wb;
+        }
+    }
+    if (tid == 0) (void)tw_wait(hdr, TW_F1(t), G, err);
+    __syncthreads();
+    tw_gather_sums<H1>(reinterpret_cast<const double*>(wsb + L.st1), (M + 63) / 64, n_tower * H1, t * H1, part, sums, tid);
+    tw_finish_stats<H1>(sums, M, a.eps, a.momentum, writer, T.l1.save_mean, T.l1.save_invstd, T.l1.running_mean, T.l1.running_var,
+                        T.l1.num_batches_tracked, col_mean, col_inv, tid);
+
+    // ---- A1 = dropout(relu(bn(Z1))): bf16 into the A operand image of layer 2 and into its global copy
+    {
+        constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+        const int c8 = tid % C8, c = c8 * 8, lr0 = tid / C8;
+        const uint32_t seed32 = drop_p > 0.f ? g2_seed32(a.seed1, a.seed_offset_dev, 64 + t) : 0u;
+        const float* gamma = T.l1.gamma; const float* beta = T.l1.beta;
+        __bf16* a1h = reinterpret_cast<__bf16*>(T.a1h); const int64_t lda = T.lda1h;
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ct[lr * Cfg::CS1 + c + q];
+            tw_bn_apply8(v, col_mean, col_inv, gamma, beta, c, relu, drop_p, keep_scale, thr16, seed32, row0 + lr);
+            tw_put8(A1S + (c8 >> 3) * TW_SLAB, lr, c8 & 7, v);
+            if (lr < rows) {
+                bf16x8_t h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h[q] = (__bf16)v[q];
+                *reinterpret_cast<bf16x8_t*>(a1h + (int64_t)(row0 + lr) * lda + c) = h;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================= layer 2: Z2 = A1 W2^T + b2
+    {
+        f32x4_t acc[2][H2 / 16];
+        tw_mfma<H2 / 16, H1 / 32>(A1S, W2S, H2 * 128, acc, wave, lane);
+        tw_acc_to_tile<H2 / 16>(acc, ct, Cfg::CS2, wave, lane);
+    }
+    __syncthreads();
+    {
+        constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+        const int c = (tid % C8) * 8, lr0 = tid / C8;
+        const float* bias = T.l2.bias;
+        const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bias + c), b1 = *reinterpret_cast<const f32x4_t*>(bias + c + 4);
+        float* z = T.l2.z; const int64_t ldz = T.l2.ldz;
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            f32x4_t lo = *reinterpret_cast<const f32x4_t*>(ct + lr * Cfg::CS2 + c) + b0;
+            f32x4_t hi = *reinterpret_cast<const f32x4_t*>(ct + lr * Cfg::CS2 + c + 4) + b1;
+            *reinterpret_cast<f32x4_t*>(ct + lr * Cfg::CS2 + c) = lo;
+            *reinterpret_cast<f32x4_t*>(ct + lr * Cfg::CS2 + c + 4) = hi;
+            if (lr < rows) {
+                *reinterpret_cast<f32x4_t*>(z + (int64_t)(row0 + lr) * ldz + c) = lo;
+                *reinterpret_cast<f32x4_t*>(z + (int64_t)(row0 + lr) * ldz + c + 4) = hi;
+            }
+        }
+    }
+    __syncthreads();
+    tw_fwd_chunk_sums<H2>(ct, Cfg::CS2, row0, M, part, reinterpret_cast<double*>(wsb + L.st2), n_tower * H2, t * H2, wave, lane);
+    if (tid == 0) {
+        tw_arrive(hdr, TW_F2(t));
+        (void)tw_wait(hdr, TW_F2(t), G, err);
+    }
+    __syncthreads();
+    tw_gather_sums<H2>(reinterpret_cast<const double*>(wsb + L.st2), (M + 63) / 64, n_tower * H2, t * H2, part, sums, tid);
+    tw_finish_stats<H2>(sums, M, a.eps, a.momentum, writer, T.l2.save_mean, T.l2.save_invstd, T.l2.running_mean, T.l2.running_var,
+                        T.l2.num_batches_tracked, col_mean, col_inv, tid);
+    // ---- A2 = dropout(relu(bn(Z2))) in fp32: kept in the tile for the head, written out for the backward
+    {
+        constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+        const int c = (tid % C8) * 8, lr0 = tid / C8;
+        const uint32_t seed32 = drop_p > 0.f ? g2_seed32(a.seed2, a.seed_offset_dev, 64 + t) : 0u;
+        const float* gamma = T.l2.gamma; const float* beta = T.l2.beta;
+        float* a2 = T.a2; const int64_t lda = T.lda2;
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ct[lr * Cfg::CS2 + c + q];
+            tw_bn_apply8(v, col_mean, col_inv, gamma, beta, c, relu, drop_p, keep_scale, thr16, seed32, row0 + lr);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ct[lr * Cfg::CS2 + c + q] = v[q];
+            if (lr < rows) {
+                *reinterpret_cast<f32x4_t*>(a2 + (int64_t)(row0 + lr) * lda + c) = f32x4_t{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4_t*>(a2 + (int64_t)(row0 + lr) * lda + c + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the head: Linear(H2 -> 1) + wide term + sigmoid, a wave per row with lane = column (k_head_fwd's order)
+    {
+        const float wo = lane < H2 ? T.wo[lane] : 0.f;
+        const float bo = T.bo ? T.bo[0] : 0.f;
+        const bool has_wide = a.wide_x != nullptr, sig = a.sigmoid != 0;
+        float* out = a.out; const int64_t ldo = a.ld_out;
+        for (int i = 0; i < 32; ++i) {
+            const int lr = wave * 32 + i;
+            float acc = lane < H2 ? ct[lr * Cfg::CS2 + lane] * wo : 0.f;
+            acc = wave_sum(acc);
+            if (lane == 0 && lr < rows) {
+                if (T.bo) acc += bo;
+                if (has_wide) acc += wide_s[lr];
+                if (sig) acc = 1.f / (1.f + expf(-acc));
+                out[(int64_t)(row0 + lr) * ldo + t] = acc;
+            }
+        }
+    }
+    if (tid == 0) tw_finish(hdr, TW_FDONE, n_tower * G, TW_F1(0), TW_FDONE);
+}
+
+// =================================================================================================
+// backward
+// =================================================================================================
+template <int NK0, int H1, int H2>
+struct TwBwdCfg {
+    static constexpr int H0 = NK0 * 64;
+    static constexpr int CSX = H0 + 4, CS1 = H1 + 4, CS2 = H2 + 4;
+    static constexpr int WT2S = 0;                                   // [H1][64] bf16: W2^T rows (K = H2, zero padded)
+    static constexpr int WT1S = WT2S + H1 * 128;                     // [H0][64] bf16: W1^T rows (K = H1)
+    static constexpr int AS = WT1S + H0 * 128;                       // [128][64] bf16: the A operand (dZ2, then dZ1)
+    static constexpr int P = AS + TW_SLAB;                           // fp32 tiles, see the phases
+    static constexpr int P_L1 = 2 * TW_ROWS * CS1 * 4;               // [dZ | xhat] of layer 1
+    static constexpr int P_L2 = 3 * TW_ROWS * CS2 * 4;               // [dZ | xhat | a2] of layer 2
+    static constexpr int P_X = TW_ROWS * CSX * 4;                    // dX
+    static constexpr int P_BYTES = (P_L1 > P_L2 ? (P_L1 > P_X ? P_L1 : P_X) : (P_L2 > P_X ? P_L2 : P_X));
+    static constexpr int PART = P + P_BYTES;                         // [2][8][64] doubles
+    static constexpr int SUMS = PART + 2 * 8 * 64 * 8;               // [2][64] doubles
+    static constexpr int DS = SUMS + 2 * 64 * 8;                     // d[128], dsum[128] floats, own list [128] ints, loss [128] doubles
+    static constexpr int DSUM = DS + TW_ROWS * 4;
+    static constexpr int OWN = DSUM + TW_ROWS * 4;
+    static constexpr int LOSS = OWN + (2 * TW_ROWS + 4) * 4;
+    static constexpr int WDW = LOSS + TW_ROWS * 8;                   // [4 waves][520] floats: the wide term's weight-gradient partials
+    static constexpr int SMEM = WDW + 4 * 520 * 4;
+};
+
+// column sums over this block's rows of tile u (and of u * w, in double) by NPT = 256 / C threads per column, parts added in order
+template <int C>
+__device__ __forceinline__ void tw_block_sums(const float* u, const float* w, int cs, int nrows, double* part, double* out, int tid) {
+    constexpr int NPT = TW_THREADS / C, RPP = TW_ROWS / NPT;
+    const int j = tid % C, pt = tid / C;
+    double s1 = 0.0, s2 = 0.0;
+    const int r_end = min((pt + 1) * RPP, nrows);
+    for (int r = pt * RPP; r < r_end; ++r) {
+        const float x = u[r * cs + j];
+        s1 += (double)x;
+        s2 += (double)x * (double)w[r * cs + j];
+    }
+    part[(0 * NPT + pt) * C + j] = s1; part[(1 * NPT + pt) * C + j] = s2;
+    __syncthreads();
+    if (tid < C) {
+        double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { b1 += part[(0 * NPT + q) * C + tid]; b2 += part[(1 * NPT + q) * C + tid]; }
+        out[tid] = b1; out[C + tid] = b2;
+    }
+    __syncthreads();
+}
+
+template <int NK0, int H1, int H2>
+__global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a_by_value) {
+    CDC_PRIO_MAIN();
+    (void)a_by_value;
+    const TW_KARG cdc_tower_args& a = *(const TW_KARG cdc_tower_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef TwBwdCfg<NK0, H1, H2> Cfg;
+    constexpr int H0 = Cfg::H0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = (int)a.M, n_tower = a.n_tower;
+    const int G = (M + TW_ROWS - 1) / TW_ROWS;
+    const int n_wg = n_tower * G;
+    const int t = (int)blockIdx.x / G, jb = (int)blockIdx.x - t * G;
+    const int row0 = jb * TW_ROWS, rows = min(TW_ROWS, M - row0);
+    const TW_KARG cdc_tower_desc& T = a.t[t];
+    int* hdr = reinterpret_cast<int*>(a.workspace);
+    const bool has_wide = a.wide_x != nullptr;
+    const int wide_K = has_wide ? a.wide_K : 0;
+    const TwLayout L = tw_layout(n_tower, H1, H2, M, wide_K);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(a.workspace);
+    int32_t* err = a.err;
+    const bool writer = jb == 0;
+    const bool bce = a.bce_y_i16 != nullptr || a.bce_y_f32 != nullptr;
+
+    unsigned char* WT2S = smem + Cfg::WT2S;
+    unsigned char* WT1S = smem + Cfg::WT1S;
+    unsigned char* AS = smem + Cfg::AS;
+    float* P = reinterpret_cast<float*>(smem + Cfg::P);
+    double* part = reinterpret_cast<double*>(smem + Cfg::PART);
+    double* sums = reinterpret_cast<double*>(smem + Cfg::SUMS);
+    float* d_s = reinterpret_cast<float*>(smem + Cfg::DS);
+    float* dsum_s = reinterpret_cast<float*>(smem + Cfg::DSUM);
+    int* own_s = reinterpret_cast<int*>(smem + Cfg::OWN);            // [0..n_own): rows of this block whose wide gradient is formed here; [128] = n_own
+    int* mine_s = own_s + TW_ROWS + 4;                               // [128] flags
+    double* loss_s = reinterpret_cast<double*>(smem + Cfg::LOSS);
+    float* wdw_s = reinterpret_cast<float*>(smem + Cfg::WDW);
+
+    // ---- grad-input operands: W2^T and W1^T -> LDS (needed after the first exchange: they land under everything before it)
+    tw_load_tile(reinterpret_cast<const __bf16*>(T.l2.wt), T.l2.ldwt, 0, H1, H1, WT2S, wave, lane);
+    tw_load_tile(reinterpret_cast<const __bf16*>(T.l1.wt), T.l1.ldwt, 0, H0, H0, WT1S, wave, lane);
+
+    const float mask_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const bool masked = a.relu != 0 || mask_scale != 1.f;
+    const float invM = 1.f / (float)M;
+
+    // ---- (1) logit gradients of the block's rows (k_head_bwd's arithmetic: BCELoss(mean) on the row's own tower, or d_out)
+    if (tid < TW_ROWS) {
+        float d_t = 0.f, dsum = 0.f;
+        int mine = 0;
+        double lp = 0.0;
+        if (tid < rows) {
+            const int64_t r = row0 + tid;
+            int own = 0;
+            float tgt = 0.f;
+            if (bce) {
+                int64_t c = a.bce_group ? a.bce_group[r] : 0;
+                if (c < 0 || c >= n_tower) c = 0;
+                own = (int)c;
+                tgt = a.bce_y_i16 ? (float)a.bce_y_i16[r] : a.bce_y_f32[r];
+            }
+            for (int tt = 0; tt < n_tower; ++tt) {
+                const float o = a.out[r * a.ld_out + tt];
+                float dout;
+                if (bce) {
+                    if (tt == own) {
+                        lp = (double)((tgt - 1.f) * fmaxf(log1pf(-o), -100.f) - tgt * fmaxf(logf(o), -100.f));
+                        dout = a.bce_inv_count * (o - tgt) / fmaxf((1.f - o) * o, 1e-12f);
+                    } else dout = 0.f;
+                } else dout = a.d_out[r * a.ld_dout + tt];
+                const float d = a.sigmoid ? dout * o * (1.f - o) : dout;
+                dsum += d;                                               // ascending tower order
+                if (tt == t) d_t = d;
+            }
+            const int owner = bce ? own : (int)(r % n_tower);            // which tower's workgroup forms the row's wide gradient
+            mine = owner == t;
+        }
+        d_s[tid] = d_t; dsum_s[tid] = dsum;
+        loss_s[tid] = (t == 0) ? lp : 0.0;
+        mine_s[tid] = mine;
+    }
+    __syncthreads();
+    if (wave == 0) {                                                     // compact list of the rows whose wide gradient is formed here
+        int base = 0;
+#pragma unroll
+        for (int h = 0; h < TW_ROWS / 64; ++h) {
+            const int flag = mine_s[h * 64 + lane];
+            const unsigned long long bal = __ballot(flag != 0);
+            if (flag) own_s[base + __popcll(bal & ((1ull << lane) - 1ull))] = h * 64 + lane;
+            base += __popcll(bal);
+        }
+        if (lane == 0) own_s[TW_ROWS] = base;
+    }
+    __syncthreads();
+
+    // ---- (2) layer-2 pieces: dz2 = mask(a2) * d * wo, xhat2 -> tiles; head weight-gradient products ride on the a2 tile
+    float* DZ2 = P;
+    float* XH2 = P + TW_ROWS * Cfg::CS2;
+    float* A2T = P + 2 * TW_ROWS * Cfg::CS2;
+    {
+        constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+        const int c = (tid % C8) * 8, lr0 = tid / C8;
+        const float* z2 = T.l2.z; const int64_t ldz = T.l2.ldz;
+        const float* a2 = T.a2; const int64_t lda = T.lda2;
+        float wo[8], mean[8], inv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { wo[q] = T.wo[c + q]; mean[q] = T.l2.save_mean[c + q]; inv[q] = T.l2.save_invstd[c + q]; }
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            f32x4_t zl = {0.f, 0.f, 0.f, 0.f}, zh = zl, al = zl, ah = zl;
+            if (lr < rows) {
+                zl = *reinterpret_cast<const f32x4_t*>(z2 + (int64_t)(row0 + lr) * ldz + c);
+                zh = *reinterpret_cast<const f32x4_t*>(z2 + (int64_t)(row0 + lr) * ldz + c + 4);
+                al = *reinterpret_cast<const f32x4_t*>(a2 + (int64_t)(row0 + lr) * lda + c);
+                ah = *reinterpret_cast<const f32x4_t*>(a2 + (int64_t)(row0 + lr) * lda + c + 4);
+            }
+            const float d = d_s[lr];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float zv = q < 4 ? zl[q] : zh[q - 4], av = q < 4 ? al[q] : ah[q - 4];
+                float dz = d * wo[q];
+                if (masked) dz = av > 0.f ? dz * mask_scale : 0.f;
+                DZ2[lr * Cfg::CS2 + c + q] = dz;
+                XH2[lr * Cfg::CS2 + c + q] = (zv - mean[q]) * inv[q];
+                A2T[lr * Cfg::CS2 + c + q] = av;
+            }
+        }
+    }
+    __syncthreads();
+    tw_block_sums<H2>(DZ2, XH2, Cfg::CS2, rows, part, sums, tid);
+    {
+        double* b2 = reinterpret_cast<double*>(wsb + L.b2) + ((int64_t)jb * n_tower * H2 + t * H2) * 2;
+        if (tid < H2) { tw_st(b2 + 2 * tid, sums[tid]); tw_st(b2 + 2 * tid + 1, sums[H2 + tid]); }
+    }
+    // head weight gradient of this block: dwo[c] = sum_r d[r] a2[r, c], dbo = sum_r d[r]  (fp64 sums, stored as fp32 partials)
+    {
+        constexpr int NPT = TW_THREADS / H2, RPP = TW_ROWS / NPT;
+        const int j = tid % H2, pt = tid / H2;
+        double s = 0.0, sb = 0.0;
+        for (int r = pt * RPP; r < min((pt + 1) * RPP, rows); ++r) { s += (double)(d_s[r] * A2T[r * Cfg::CS2 + j]); sb += (double)d_s[r]; }
+        part[(0 * NPT + pt) * H2 + j] = s; part[(1 * NPT + pt) * H2 + j] = sb;
+        __syncthreads();
+        float* hd = reinterpret_cast<float*>(wsb + L.hd) + ((int64_t)jb * n_tower + t) * (H2 + 4);
+        if (tid < H2) {
+            double b = 0.0;
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) b += part[(0 * NPT + q) * H2 + tid];
+            tw_st(hd + tid, (float)b);
+        } else if (tid == H2) {
+            double b = 0.0;
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) b += part[(1 * NPT + q) * H2 + 0];
+            tw_st(hd + H2, (float)b);
+        }
+        if (t == 0 && tid == 64) {                                       // the block's loss partial (row order)
+            double s_ = 0.0;
+            for (int r = 0; r < rows; ++r) s_ += loss_s[r];
+            tw_st(reinterpret_cast<double*>(wsb + L.loss) + jb, s_);
+        }
+    }
+    tw_drain();
+    __syncthreads();
+    if (tid == 0) tw_arrive(hdr, TW_B3(t));
+
+    // ---- under the wait: the wide term's gradients for the rows this workgroup owns (k_head_bwd (3)): a wave per row
+    if (has_wide) {
+        const int K4 = wide_K >> 2;
+        const int n_own = own_s[TW_ROWS];
+        f32x4_t wv[2], dwv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wv[q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(a.wide_w + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            dwv[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        float dbv = 0.f;
+        const bool rmw = a.wide_dx && a.accumulate_wide_dx;
+        for (int i = wave; i < n_own; i += 4) {
+            const int lr = own_s[i];
+            const int64_t r = row0 + lr;
+            const float ds = dsum_s[lr];
+            f32x4_t xv[2], ov[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool in = (lane + 64 * q) < K4;
+                xv[q] = in ? *reinterpret_cast<const f32x4_t*>(a.wide_x + r * a.ld_wide + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                ov[q] = (in && rmw) ? *reinterpret_cast<const f32x4_t*>(a.wide_dx + r * a.ld_wide_dx + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if ((lane + 64 * q) >= K4) continue;
+                dwv[q] += xv[q] * ds;
+                if (a.wide_dx) {
+                    const f32x4_t v = wv[q] * ds;
+                    *reinterpret_cast<f32x4_t*>(a.wide_dx + r * a.ld_wide_dx + 4 * (lane + 64 * q)) = rmw ? ov[q] + v : v;
+                }
+            }
+            dbv += ds;
+        }
+        // rows nobody owns here still need their wide_dx written when this launch is the first writer: every row has exactly one
+        // owner (its own tower's workgroup of the same block), so nothing is left out
+        float* mine = wdw_s + wave * 520;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if ((lane + 64 * q) < K4) *reinterpret_cast<f32x4_t*>(mine + 4 * (lane + 64 * q)) = dwv[q];
+        if (lane == 0) mine[wide_K] = dbv;
+        __syncthreads();
+        float* wd = reinterpret_cast<float*>(wsb + L.wd) + ((int64_t)t * G + jb) * L.wd_ld;
+        for (int k = tid; k <= wide_K; k += TW_THREADS)
+            tw_st(wd + k, ((wdw_s[k] + wdw_s[520 + k]) + wdw_s[2 * 520 + k]) + wdw_s[3 * 520 + k]);
+    }
+    if (tid == 0) (void)tw_wait(hdr, TW_B3(t), G, err);
+    __syncthreads();
+    tw_gather_sums<H2>(reinterpret_cast<const double*>(wsb + L.b2), G, n_tower * H2, t * H2, part, sums, tid);
+    if (writer) {
+        if (tid < H2) {
+            if (T.l2.dbeta) T.l2.dbeta[tid] = (float)sums[tid];
+            if (T.l2.dgamma) T.l2.dgamma[tid] = (float)sums[H2 + tid];
+        }
+        // the tower's head gradient: block partials in block order
+        if (tid >= 64 && tid < 64 + H2 + 1) {
+            const int k = tid - 64;
+            const float* hd = reinterpret_cast<const float*>(wsb + L.hd) + (int64_t)t * (H2 + 4) + k;
+            float s = 0.f;
+            for (int b = 0; b < G; ++b) s += tw_ld(hd + (int64_t)b * n_tower * (H2 + 4));
+            if (k < H2) { if (T.dwo) T.dwo[k] = s; }
+            else if (T.dbo) T.dbo[0] = s;
+        }
+    }
+    // ---- (3) dZ2 = gamma invstd (dz - (db + xhat dg) / M) -> A operand image + global bf16 copy (grad-weight launch)
+    {
+        constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+        const int c8 = tid % C8, c = c8 * 8, lr0 = tid / C8;
+        float k1[8], db[8], dg[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            k1[q] = T.l2.gamma[c + q] * T.l2.save_invstd[c + q];
+            db[q] = (float)sums[c + q]; dg[q] = (float)sums[H2 + c + q];
+        }
+        __bf16* dzh = reinterpret_cast<__bf16*>(T.l2.dzh); const int64_t ldd = T.l2.lddzh;
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = k1[q] * (DZ2[lr * Cfg::CS2 + c + q] - invM * (db[q] + XH2[lr * Cfg::CS2 + c + q] * dg[q]));
+            tw_put8(AS, lr, c8, v);
+            if (lr < rows) {
+                bf16x8_t h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h[q] = (__bf16)v[q];
+                *reinterpret_cast<bf16x8_t*>(dzh + (int64_t)(row0 + lr) * ldd + c) = h;
+            }
+        }
+    }
+    tw_drain();                                                          // (also: the W^T tiles have landed)
+    __syncthreads();
+    // ---- (4) dA1 = dZ2 W2 -> tile; dz1 = mask(a1) * dA1, xhat1 -> tiles (dz1 in place)
+    float* DZ1 = P;
+    float* XH1 = P + TW_ROWS * Cfg::CS1;
+    {
+        f32x4_t acc[2][H1 / 16];
+        tw_mfma<H1 / 16, H2 / 32>(AS, WT2S, 0, acc, wave, lane);
+        tw_acc_to_tile<H1 / 16>(acc, DZ1, Cfg::CS1, wave, lane);
+    }
+    __syncthreads();
+    {
+        constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+        const int c = (tid % C8) * 8, lr0 = tid / C8;
+        const float* z1 = T.l1.z; const int64_t ldz = T.l1.ldz;
+        const __bf16* a1h = reinterpret_cast<const __bf16*>(T.a1h); const int64_t lda = T.lda1h;
+        float mean[8], inv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { mean[q] = T.l1.save_mean[c + q]; inv[q] = T.l1.save_invstd[c + q]; }
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            f32x4_t zl = {0.f, 0.f, 0.f, 0.f}, zh = zl;
+            bf16x8_t m8 = {};
+            if (lr < rows) {
+                zl = *reinterpret_cast<const f32x4_t*>(z1 + (int64_t)(row0 + lr) * ldz + c);
+                zh = *reinterpret_cast<const f32x4_t*>(z1 + (int64_t)(row0 + lr) * ldz + c + 4);
+                m8 = *reinterpret_cast<const bf16x8_t*>(a1h + (int64_t)(row0 + lr) * lda + c);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float dz = DZ1[lr * Cfg::CS1 + c + q];
+                if (masked) dz = (float)m8[q] > 0.f ? dz * mask_scale : 0.f;
+                if (lr >= rows) dz = 0.f;
+                DZ1[lr * Cfg::CS1 + c + q] = dz;
+                XH1[lr * Cfg::CS1 + c + q] = ((q < 4 ? zl[q] : zh[q - 4]) - mean[q]) * inv[q];
+            }
+        }
+    }
+    __syncthreads();
+    tw_block_sums<H1>(DZ1, XH1, Cfg::CS1, rows, part, sums, tid);
+    {
+        double* b1 = reinterpret_cast<double*>(wsb + L.b1) + ((int64_t)jb * n_tower * H1 + t * H1) * 2;
+        if (tid < H1) { tw_st(b1 + 2 * tid, sums[tid]); tw_st(b1 + 2 * tid + 1, sums[H1 + tid]); }
+    }
+    tw_drain();
+    __syncthreads();
+    if (tid == 0) {
+        tw_arrive(hdr, TW_B4);                                           // ALL towers: the wide gradient's partials come from all of them
+        (void)tw_wait(hdr, TW_B4, n_wg, err);
+    }
+    __syncthreads();
+    tw_gather_sums<H1>(reinterpret_cast<const double*>(wsb + L.b1), G, n_tower * H1, t * H1, part, sums, tid);
+    if (writer && tid < H1) {
+        if (T.l1.dbeta) T.l1.dbeta[tid] = (float)sums[tid];
+        if (T.l1.dgamma) T.l1.dgamma[tid] = (float)sums[H1 + tid];
+    }
+    // ---- (5) dZ1 -> A operand image + global bf16 copy
+    {
+        constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+        const int c8 = tid % C8, c = c8 * 8, lr0 = tid / C8;
+        float k1[8], db[8], dg[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            k1[q] = T.l1.gamma[c + q] * T.l1.save_invstd[c + q];
+            db[q] = (float)sums[c + q]; dg[q] = (float)sums[H1 + c + q];
+        }
+        __bf16* dzh = reinterpret_cast<__bf16*>(T.l1.dzh); const int64_t ldd = T.l1.lddzh;
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = k1[q] * (DZ1[lr * Cfg::CS1 + c + q] - invM * (db[q] + XH1[lr * Cfg::CS1 + c + q] * dg[q]));
+            tw_put8(AS, lr, c8, v);
+            if (lr < rows) {
+                bf16x8_t h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) h[q] = (__bf16)v[q];
+                *reinterpret_cast<bf16x8_t*>(dzh + (int64_t)(row0 + lr) * ldd + c) = h;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- (6) dX = dZ1 W1 -> tile -> global
+    {
+        f32x4_t acc[2][H0 / 16];
+        tw_mfma<H0 / 16, H1 / 32>(AS, WT1S, 0, acc, wave, lane);
+        tw_acc_to_tile<H0 / 16>(acc, P, Cfg::CSX, wave, lane);
+    }
+    __syncthreads();
+    if (T.dx) {
+        constexpr int C8 = H0 / 8, RPP = TW_THREADS / C8;
+        const int c = (tid % C8) * 8, lr0 = tid / C8;
+        float* dx = T.dx; const int64_t ldd = T.lddx;
+        const bool accx = T.accumulate_dx != 0;
+#pragma unroll
+        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+            if (lr >= rows) break;
+            f32x4_t lo = *reinterpret_cast<const f32x4_t*>(P + lr * Cfg::CSX + c);
+            f32x4_t hi = *reinterpret_cast<const f32x4_t*>(P + lr * Cfg::CSX + c + 4);
+            float* dst = dx + (int64_t)(row0 + lr) * ldd + c;
+            if (accx) { lo = *reinterpret_cast<const f32x4_t*>(dst) + lo; hi = *reinterpret_cast<const f32x4_t*>(dst + 4) + hi; }
+            *reinterpret_cast<f32x4_t*>(dst) = lo;
+            *reinterpret_cast<f32x4_t*>(dst + 4) = hi;
+        }
+    }
+    // ---- (7) sums over ALL workgroups (published before the last exchange): the wide term's weight gradient (a wave per
+    // column: lanes take partials l, l + 64, ... in order, then a butterfly) and the loss
+    if (has_wide) {
+        const float* wd = reinterpret_cast<const float*>(wsb + L.wd);
+        for (int k = (int)blockIdx.x * 4 + wave; k <= wide_K; k += n_wg * 4) {
+            float s = 0.f;
+            for (int p = lane; p < n_wg; p += 64) s += tw_ld(wd + (int64_t)p * L.wd_ld + k);
+            s = wave_sum(s);
+            if (lane == 0) {
+                if (k < wide_K) { if (a.wide_dw) a.wide_dw[k] = s; }
+                else if (a.wide_dbias) a.wide_dbias[0] = s;
+            }
+        }
+    }
+    if (bce && blockIdx.x == 0 && wave == 1 && a.bce_loss) {
+        const double* lp = reinterpret_cast<const double*>(wsb + L.loss);
+        double s = 0.0;
+        for (int b = lane; b < G; b += 64) s += tw_ld(lp + b);
+        s = wave_sum_d(s);
+        if (lane == 0) *a.bce_loss = (float)(s * (double)a.bce_inv_count);
+    }
+    if (tid == 0) tw_finish(hdr, TW_BDONE, n_wg, TW_B3(0), TW_BDONE);
+}
+
+// =================================================================================================
+// host
+// =================================================================================================
+static int tower_check(const cdc_tower_args* a, const char* who, bool bwd) {
+    CDC_CHECK_ARG(a && a->n_tower > 0 && a->n_tower <= CDC_TOWER_MAX, CDC_E_BADARG, "%s: bad tower count", who);
+    CDC_CHECK_ARG((a->H0 == 64 || a->H0 == 128) && a->H1 == 64 && a->H2 == 32, CDC_E_BADARG,
+                  "%s: instantiated for H0 in {64,128}, H1 = 64, H2 = 32 (got %d, %d, %d)", who, a->H0, a->H1, a->H2);
+    CDC_CHECK_ARG(a->M >= 2, CDC_E_BADARG, "%s: needs at least two rows (a batch of one skips BatchNorm: use the unfused launches)", who);
+    const int64_t G = cdc_ceil_div(a->M, TW_ROWS);
+    CDC_CHECK_ARG(a->n_tower * G <= 256, CDC_E_TOOBIG, "%s: %lld workgroups cannot all be resident (one per CU)", who, (long long)(a->n_tower * G));
+    CDC_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f, CDC_E_BADARG, "%s: dropout p out of range", who);
+    CDC_CHECK_ARG(a->workspace && (((uintptr_t)a->workspace) & 127) == 0 && a->out && a->ld_out >= a->n_tower, CDC_E_BADARG, "%s: workspace / out", who);
+    auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if (a->wide_x) {
+        CDC_CHECK_ARG(a->wide_w && a->wide_K > 0 && a->wide_K <= 512 && a->wide_K % 4 == 0 && a->ld_wide % 4 == 0 && al16(a->wide_x) && al16(a->wide_w),
+                      CDC_E_BADARG, "%s: wide term malformed (K <= 512, K %% 4 == 0, 16-byte aligned rows)", who);
+        if (bwd && a->wide_dx) CDC_CHECK_ARG(al16(a->wide_dx) && a->ld_wide_dx % 4 == 0, CDC_E_ALIGN, "%s: wide_dx alignment", who);
+    }
+    for (int t = 0; t < a->n_tower; ++t) {
+        const cdc_tower_desc& T = a->t[t];
+        CDC_CHECK_ARG(T.xh && al16(T.xh) && T.ldxh % 8 == 0 && T.ldxh >= a->H0, CDC_E_BADARG, "%s: tower %d input", who, t);
+        const cdc_tower_layer* Ls[2] = {&T.l1, &T.l2};
+        const int Ns[2] = {a->H1, a->H2}, Ks[2] = {a->H0, a->H1};
+        for (int l = 0; l < 2; ++l) {
+            const cdc_tower_layer& Y = *Ls[l];
+            CDC_CHECK_ARG(Y.bias && Y.z && al16(Y.z) && Y.ldz % 4 == 0 && Y.ldz >= Ns[l] && Y.gamma && Y.beta && Y.save_mean && Y.save_invstd,
+                          CDC_E_BADARG, "%s: tower %d layer %d", who, t, l + 1);
+            if (!bwd) CDC_CHECK_ARG(Y.wh && al16(Y.wh) && Y.ldwh % 8 == 0 && Y.ldwh >= (Ks[l] + 63) / 64 * 64, CDC_E_BADARG, "%s: tower %d layer %d weight copy", who, t, l + 1);
+            else CDC_CHECK_ARG(Y.wt && al16(Y.wt) && Y.ldwt % 8 == 0 && Y.ldwt >= 64 && Y.dzh && al16(Y.dzh) && Y.lddzh % 8 == 0 && Y.lddzh >= Ns[l],
+                               CDC_E_BADARG, "%s: tower %d layer %d transposed weight copy / dzh", who, t, l + 1);
+        }
+        CDC_CHECK_ARG(T.a1h && al16(T.a1h) && T.lda1h % 8 == 0 && T.a2 && al16(T.a2) && T.lda2 % 4 == 0 && T.wo, CDC_E_BADARG, "%s: tower %d activations / head", who, t);
+        if (bwd && T.dx) CDC_CHECK_ARG(al16(T.dx) && T.lddx % 4 == 0 && T.lddx >= a->H0, CDC_E_ALIGN, "%s: tower %d dx", who, t);
+    }
+    return 0;
+}
+
+extern "C" int64_t cdc_tower_workspace_bytes(const cdc_tower_args* a) {
+    if (!a || a->n_tower <= 0 || a->n_tower > CDC_TOWER_MAX || a->M <= 0) return -1;
+    return tw_layout(a->n_tower, a->H1, a->H2, a->M, a->wide_x ? a->wide_K : 0).total;
+}
+
+template <typename K>
+static void tower_attr(K kern, int bytes) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+
+extern "C" int cdc_tower_fwd(const cdc_tower_args* a, void* stream) {
+    const int rc = tower_check(a, "tower_fwd", false);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)(a->n_tower * cdc_ceil_div(a->M, TW_ROWS));
+    static bool attr_done = false;
+    if (!attr_done) {
+        tower_attr(k_tower_fwd<1, 64, 32>, TwFwdCfg<1, 64, 32>::SMEM);
+        tower_attr(k_tower_fwd<2, 64, 32>, TwFwdCfg<2, 64, 32>::SMEM);
+        attr_done = true;
+    }
+    constexpr int lds1 = TwFwdCfg<1, 64, 32>::SMEM, lds2 = TwFwdCfg<2, 64, 32>::SMEM;
+    if (a->H0 == 64) hipLaunchKernelGGL((k_tower_fwd<1, 64, 32>), dim3(grid), dim3(TW_THREADS), lds1, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((k_tower_fwd<2, 64, 32>), dim3(grid), dim3(TW_THREADS), lds2, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("tower_fwd");
+    return 0;
+}
+
+extern "C" int cdc_tower_bwd(const cdc_tower_args* a, void* stream) {
+    const int rc = tower_check(a, "tower_bwd", true);
+    if (rc) return rc;
+    const bool bce = a->bce_y_i16 || a->bce_y_f32;
+    CDC_CHECK_ARG(bce || a->d_out, CDC_E_BADARG, "tower_bwd: needs the output gradient or the fused loss");
+    CDC_CHECK_ARG(!bce || (a->sigmoid && a->bce_loss && a->bce_inv_count > 0.f), CDC_E_BADARG, "tower_bwd: the fused BCE needs sigmoid outputs and a loss pointer");
+    const unsigned grid = (unsigned)(a->n_tower * cdc_ceil_div(a->M, TW_ROWS));
+    static bool attr_done = false;
+    if (!attr_done) {
+        tower_attr(k_tower_bwd<1, 64, 32>, TwBwdCfg<1, 64, 32>::SMEM);
+        tower_attr(k_tower_bwd<2, 64, 32>, TwBwdCfg<2, 64, 32>::SMEM);
+        attr_done = true;
+    }
+    constexpr int lds1 = TwBwdCfg<1, 64, 32>::SMEM, lds2 = TwBwdCfg<2, 64, 32>::SMEM;
+    if (a->H0 == 64) hipLaunchKernelGGL((k_tower_bwd<1, 64, 32>), dim3(grid), dim3(TW_THREADS), lds1, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((k_tower_bwd<2, 64, 32>), dim3(grid), dim3(TW_THREADS), lds2, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("tower_bwd");
+    return 0;
+}

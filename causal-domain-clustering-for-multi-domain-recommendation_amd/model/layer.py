@@ -470,6 +470,9 @@ class BaseModel(HipModule):
         if fused:
             wide = {"x": wide_in, "w": self.linear.fc.weight, "b": self.linear.fc.bias}
             mlp_stack(plan, list(self.towers), tower_inputs, final_addends=other_outs, final_sigmoid=True, head_out=out, head_wide=wide)
+            # linear, BatchNorm, linear, BatchNorm and the head of all towers as ONE launch per direction where the shapes are the
+            # reference's (csrc/tower.hip; training plans on one GPU)
+            P.fuse_tower(plan)
             return out
         finals = [out.slice(i, i + 1) for i in range(n)]
         mlp_stack(plan, list(self.towers), tower_inputs, final_addends=other_outs, final_sigmoid=True, final_outs=finals)

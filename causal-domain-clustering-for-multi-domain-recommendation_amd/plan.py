@@ -1811,6 +1811,200 @@ class TowerHead:
         plan.bwd_steps.append(plan.call("cdc_head_bwd", C.byref(a)))
 
 
+class TowerChain:
+    """The towers of a multi-tower model as ONE launch per direction (csrc/tower.hip; model/layer.py:35-56,178-206): built from
+    the five ops the model described — GLinear, BatchNorm, GLinear, BatchNorm, TowerHead — where they have the instantiated
+    shape; it takes their place in plan.ops and uses their buffers, seeds and parameters.  The grad-weight contractions of the two
+    linear layers stay with the batched launch at the end of backward (the backward launch writes their dZ operands as bf16)."""
+
+    SHAPES = ((64, 64, 32), (128, 64, 32))      # (H0, H1, H2) csrc/tower.hip is instantiated for (config.py:39-42: tower_dims (64, 32))
+    enabled = True                              # tests set this to False to build the five launches at a matching shape
+
+    @classmethod
+    def match(cls, plan, l1, b1, l2, b2, head):
+        if not (isinstance(l1, GLinear) and isinstance(b1, BatchNorm) and isinstance(l2, GLinear) and isinstance(b2, BatchNorm) and
+                isinstance(head, TowerHead)):
+            return False
+        if not (plan.use_g2 and plan.training and plan.dist is None and plan.B >= 2):
+            return False
+        n = len(head.towers)
+        if not (0 < n <= L.TOWER_MAX and n * math.ceil(plan.B / L.TOWER_ROWS) <= 256):
+            return False
+        if head.addends or not head.sigmoid or head.M != plan.B:
+            return False
+        for lin in (l1, l2):
+            if not (lin.g2 and lin.row_offsets is None and lin.M == plan.B and not lin.adopted and not lin.relu and lin.drop_p == 0.0 and
+                    len(lin.groups) == n and all(isinstance(g["w"], torch.Tensor) and g.get("b") is not None and g["act_cols"] == 0
+                                                  for g in lin.groups)):
+                return False
+        for bn in (b1, b2):
+            if not (len(bn.segs) == n and bn.row_offsets is None and bn.M == plan.B and bn.relu and not bn.skip_le1 and
+                    all(s.get("gamma_param") is not None and s.get("row_group", 0) == 0 for s in bn.segs)):
+                return False
+        if b1.drop_p != b2.drop_p or b1.eps != b2.eps or b1.momentum != b2.momentum:
+            return False
+        H1, H0 = l1.groups[0]["w"].shape
+        H2 = l2.groups[0]["w"].shape[0]
+        if (H0, H1, H2) not in cls.SHAPES:
+            return False
+        same = CGCMid._same
+        for i in range(n):
+            g1, g2, s1, s2, t = l1.groups[i], l2.groups[i], b1.segs[i], b2.segs[i], head.towers[i]
+            if not (tuple(g1["w"].shape) == (H1, H0) and tuple(g2["w"].shape) == (H2, H1) and t["w"].numel() == H2):
+                return False
+            if not (same(g1["y"], s1["x"]) and same(s1["y"], g2["x"]) and same(g2["y"], s2["x"]) and same(s2["y"], t["x"])):
+                return False
+        if head.wide is not None:
+            w = head.wide
+            K = w["w"].numel()
+            if not (K <= 512 and K % 4 == 0 and w["x"].ld % 4 == 0 and w["x"].ptr % 16 == 0 and w["x"].cols == K):
+                return False
+        return True
+
+    def __init__(self, plan, l1, b1, l2, b2, head):
+        self.l1, self.b1, self.l2, self.b2, self.head = l1, b1, l2, b2, head
+        i = plan.ops.index(l1)
+        assert plan.ops[i:i + 5] == [l1, b1, l2, b2, head]
+        plan.ops[i:i + 5] = [self]
+        self.sigmoid, self.out, self.M = head.sigmoid, head.out, head.M
+        self.n = len(head.towers)
+        self.H1, self.H0 = l1.groups[0]["w"].shape
+        self.H2 = l2.groups[0]["w"].shape[0]
+        self.tmo_word = torch.zeros(1, dtype=torch.int32, device=plan.device)     # CDC_TOWER_ERR_TIMEOUT lands here (TrainStep.check_ids)
+        self.ws = None
+        self._keep = []
+        for op in (l1, l2):
+            op._keep = getattr(op, "_keep", [])
+        # the hidden activation is read by the second contraction and the grad-weight launch only: bf16 alone
+        for s in b1.segs:
+            plan.want_shadow(s["y"])
+            plan.make_value_half_only(s["y"])
+
+    def _fill(self, a, plan):
+        head, b1 = self.head, self.b1
+        a.n_tower, a.H0, a.H1, a.H2, a.M = self.n, self.H0, self.H1, self.H2, plan.B
+        a.relu, a.sigmoid = 1, 1 if head.sigmoid else 0
+        a.drop_p, a.eps, a.momentum = b1.drop_p, b1.eps, b1.momentum
+        a.seed1, a.seed2 = self.b1.seed & 0xFFFFFFFFFFFFFFFF, self.b2.seed & 0xFFFFFFFFFFFFFFFF
+        a.seed_offset_dev = plan.step_dev.data_ptr()
+        a.out, a.ld_out = head.out.ptr, head.out.ld
+        if head.wide is not None:
+            w = head.wide
+            a.wide_x, a.ld_wide = w["x"].ptr, w["x"].ld
+            a.wide_w = w["w"].data_ptr()
+            a.wide_bias = None if w.get("b") is None else w["b"].data_ptr()
+            a.wide_K = w["w"].numel()
+        a.err = self.tmo_word.data_ptr()
+        for i in range(self.n):
+            T = a.t[i]
+            g1, g2, s1, s2, t = self.l1.groups[i], self.l2.groups[i], self.b1.segs[i], self.b2.segs[i], head.towers[i]
+            T.xh, T.ldxh = plan.shadow_view(g1["x"])
+            for Y, g, s in ((T.l1, g1, s1), (T.l2, g2, s2)):
+                wh, wt = plan.wshadow(g["w"])
+                Y.wh, Y.ldwh = wh.data_ptr(), wh.stride(0)
+                Y.wt, Y.ldwt = wt.data_ptr(), wt.stride(0)
+                Y.bias = g["b"].data_ptr()
+                Y.z, Y.ldz = g["y"].ptr, g["y"].ld
+                Y.gamma, Y.beta = s["gamma"].data_ptr(), s["beta"].data_ptr()
+                Y.running_mean, Y.running_var = s["running_mean"].data_ptr(), s["running_var"].data_ptr()
+                nbt = s.get("num_batches_tracked")
+                Y.num_batches_tracked = None if nbt is None else nbt.data_ptr()
+                Y.save_mean, Y.save_invstd = s["save_mean"].data_ptr(), s["save_invstd"].data_ptr()
+            T.a1h, T.lda1h = plan.shadow_view(s1["y"])
+            T.a2, T.lda2 = s2["y"].ptr, s2["y"].ld
+            T.wo = t["w"].data_ptr()
+            T.bo = None if t.get("b") is None else t["b"].data_ptr()
+        if self.ws is None:
+            need = int(self.lib_ws_bytes(plan, a))
+            self.ws = torch.zeros(need, dtype=torch.uint8, device=plan.device)
+        a.workspace = self.ws.data_ptr()
+
+    @staticmethod
+    def lib_ws_bytes(plan, a):
+        n = plan.lib.cdc_tower_workspace_bytes(C.byref(a))
+        if n <= 0:
+            raise RuntimeError("cdc_tower_workspace_bytes refused the argument block")
+        return n
+
+    def build_fwd(self, plan):
+        plan.ensure_shadows([g["x"] for g in self.l1.groups], plan.fwd_steps)
+        a = L.TowerArgs()
+        self._fill(a, plan)
+        for s in self.b1.segs:
+            plan.mark_shadow(s["y"])
+        self._keep.append(a)
+        fl = sum(2.0 * plan.B * g["w"].shape[0] * g["w"].shape[1] for g in self.l1.groups + self.l2.groups)
+        step = plan.call("cdc_tower_fwd", C.byref(a), flops=fl)
+        self._fwd_calls = [step]
+        plan.fwd_steps.append(step)
+
+    def build_bwd(self, plan, gs):
+        head = self.head
+        a = L.TowerArgs()
+        self._fill(a, plan)
+        plan.ensure_grad(head.out, gs)
+        og = head.out.grad
+        a.d_out, a.ld_dout = og.ptr, og.ld
+        for i in range(self.n):
+            T = a.t[i]
+            g1, g2, s1, s2, t = self.l1.groups[i], self.l2.groups[i], self.b1.segs[i], self.b2.segs[i], head.towers[i]
+            if plan._claim_param(t["w"]) or (t.get("b") is not None and plan._claim_param(t["b"])):
+                raise RuntimeError("a tower's output layer is used twice in one plan")
+            T.dwo = plan.param_grad(t["w"]).data_ptr()
+            T.dbo = None if t.get("b") is None else plan.param_grad(t["b"]).data_ptr()
+            for Y, g, s in ((T.l2, g2, s2), (T.l1, g1, s1)):
+                if plan._claim_param(s["gamma_param"]) or plan._claim_param(s["beta_param"]):
+                    raise RuntimeError("BatchNorm parameters used twice in one plan")
+                Y.dgamma, Y.dbeta = plan.param_grad(s["gamma_param"]).data_ptr(), plan.param_grad(s["beta_param"]).data_ptr()
+                # dZ of the layer: bf16 alone, read by the batched grad-weight launch
+                if gs.claim(g["y"]):
+                    raise RuntimeError("TowerChain: a tower layer's output has another gradient writer")
+                plan.make_grad_half_only(g["y"])
+                Y.dzh, Y.lddzh = plan.shadow_view(g["y"].grad)
+                plan.mark_shadow(g["y"].grad)
+            x = g1["x"]
+            T.accumulate_dx = 1 if gs.claim(x) else 0
+            xg = x.grad
+            if plan.is_half_only(xg):
+                raise RuntimeError("TowerChain: the tower input's gradient is kept as bf16 only")
+            T.dx, T.lddx = xg.ptr, xg.ld
+        if head.wide is not None:
+            w = head.wide
+            if w["x"].mask is not None:
+                raise RuntimeError("the wide term cannot consume an activation-fused linear output")
+            xg = w["x"].grad
+            a.accumulate_wide_dx = 1 if gs.claim(w["x"]) else 0
+            a.wide_dx, a.ld_wide_dx = xg.ptr, xg.ld
+            if plan._claim_param(w["w"]) or (w.get("b") is not None and plan._claim_param(w["b"])):
+                raise RuntimeError("the wide term's parameters are used twice in one plan")
+            a.wide_dw = plan.param_grad(w["w"]).data_ptr()
+            a.wide_dbias = None if w.get("b") is None else plan.param_grad(w["b"]).data_ptr()
+        self._keep.append(a)
+        self.bwd_args = [a]                      # (trainer: the fused BCE is switched on in this launch)
+        fl = sum(2.0 * plan.B * g["w"].shape[0] * g["w"].shape[1] for g in self.l1.groups + self.l2.groups)
+        plan.bwd_steps.append(plan.call("cdc_tower_bwd", C.byref(a), flops=fl))
+        # the grad-weight contractions of both layers: batched launch at the end of backward (operands: the shadows written above)
+        for lin in (self.l2, self.l1):
+            lin.skip_bwd_x = True
+            lin.build_bwd(plan, gs)
+
+
+def fuse_tower(plan, enable=True):
+    """Replaces the run (GLinear, BatchNorm, GLinear, BatchNorm, TowerHead) of plan.ops that is the towers of a multi-tower model in
+    the instantiated shape by ONE TowerChain op (training plans on one GPU; every other shape, precision or mode keeps the five
+    ops)."""
+    if not (enable and TowerChain.enabled):
+        return 0
+    n = 0
+    i = 0
+    while i + 4 < len(plan.ops):
+        if TowerChain.match(plan, *plan.ops[i:i + 5]):
+            TowerChain(plan, *plan.ops[i:i + 5])
+            n += 1
+        i += 1
+    return n
+
+
 class CrossLayer:
     """DCN-v1 cross layer (model/layer.py:321-329): out = x0 * (xl·w) + b + xl."""
 

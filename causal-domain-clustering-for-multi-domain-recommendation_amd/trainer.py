@@ -141,7 +141,7 @@ class TrainStep:
         from . import plan as P
         out = self.out
         for op in self.plan.ops:
-            if isinstance(op, P.TowerHead) and op.sigmoid and op.out.root is out.root and op.out.col0 == out.col0 and op.out.cols == out.cols:
+            if isinstance(op, (P.TowerHead, P.TowerChain)) and op.sigmoid and op.out.root is out.root and op.out.col0 == out.col0 and op.out.cols == out.cols:
                 args = getattr(op, "bwd_args", [])
                 return args[0] if len(args) == 1 and op.M == self.B else None
         for op in self.plan.ops:
@@ -167,7 +167,9 @@ class TrainStep:
             if self._fuse_bce:
                 head.bce_group = None if self.group is None else self.group.data_ptr()
                 head.bce_y_i16, head.bce_y_f32 = self.y.data_ptr(), None
-                head.bce_loss, head.bce_partial = self.loss.data_ptr(), self._bce_partial.data_ptr()
+                head.bce_loss = self.loss.data_ptr()
+                if hasattr(type(head), "bce_partial"):            # (the fused tower launch keeps its partial sums in its own workspace)
+                    head.bce_partial = self._bce_partial.data_ptr()
                 head.bce_inv_count = 1.0 / self.global_B
                 return
             head.bce_y_i16 = head.bce_y_f32 = None
@@ -729,6 +731,13 @@ class TrainStep:
         if bad:
             self.emb.err.zero_()
             raise IndexError(f"index out of range in self (flat position {bad - 1})")
+        for op in self.plan.ops:                                  # in-launch exchanges that gave up (csrc/tower.hip)
+            word = getattr(op, "tmo_word", None)
+            if torch.is_tensor(word) and int(word.item()) & L.TOWER_ERR_TIMEOUT:
+                word.zero_()
+                getattr(op, "ws").zero_()
+                raise RuntimeError("the fused tower launch timed out waiting for its other workgroups (BatchNorm statistics "
+                                   "exchange); the results of that step are void")
         if self.dp_on and self.table_dist == "sharded":
             over = int(self.overflow.item())
             if over:

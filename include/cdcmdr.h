@@ -745,6 +745,87 @@ int cdc_head_bwd(const cdc_head_args* a, void* stream);
 int64_t cdc_head_workspace_floats(const cdc_head_args* a);
 
 /* ------------------------------------------------------------------------------------------
+ * The towers of a multi-tower model as ONE launch per direction (csrc/tower.hip, round 4).
+ * Reference: BaseModel.tower_forward (model/layer.py:35-56) over towers built by build_tower_output as
+ * MultiLayerPerceptron(H0, (H1, H2), dropout, output_layer=True) (model/layer.py:178-206):
+ *     Linear(H0->H1) -> BatchNorm1d -> ReLU -> Dropout -> Linear(H1->H2) -> BatchNorm1d -> ReLU -> Dropout -> Linear(H2->1)
+ *     -> `+= other` (the wide term, FeaturesLinear model/layer.py:122-126) -> Sigmoid -> column t of out [M, n_tower],
+ * in training mode (batch statistics); the backward also forms BCELoss(mean) on the row's own tower and its gradient
+ * (run.py:484,723) when the bce_* fields are set, like cdc_head_bwd.
+ *
+ * It replaces cdc_gemm_bf16_nt -> cdc_bn_fwd -> cdc_gemm_bf16_nt -> cdc_bn_fwd -> cdc_head_fwd (5 launches) and
+ * cdc_head_bwd (2) -> cdc_bn_bwd (2) -> cdc_gemm_bf16_nt -> cdc_bn_bwd (2) -> cdc_gemm_bf16_nt (8 launches) with the same
+ * arithmetic: bf16 MFMA operands / fp32 accumulate for the two contractions and their grad-input products, fp64 column sums
+ * for the BatchNorm statistics (forward: per 64-row chunk in the order of cdc_gemm_bf16_nt's statistics epilogue and
+ * cdc_bn_fwd's chunk sum, i.e. the same bits), the 32-bit dropout stream of the BatchNorm launches (stream 64 + tower).
+ * The grad-weight contractions of the two Linear layers stay with the batched grad-weight launch (cdc_glinear_bwd_w): the
+ * backward writes their dZ operands as bf16 (`dzh`), the forward the hidden activation `a1h`.
+ *
+ * Geometry: a workgroup owns CDC_TOWER_ROWS rows of one tower; grid = n_tower * ceil(M / CDC_TOWER_ROWS) workgroups, which
+ * must all be resident (checked against 256 CUs: M <= 256 / n_tower * CDC_TOWER_ROWS, else CDC_E_TOOBIG).  The column sums a
+ * BatchNorm needs over all rows are exchanged INSIDE the launch: every workgroup publishes its partial sums with write-through
+ * stores and adds to an arrival counter, waits (bounded) until the counter holds every workgroup of its tower, and adds the
+ * partials up in a fixed order (deterministic; identical in every workgroup).  A wait that runs out sets bit CDC_TOWER_ERR_TIMEOUT
+ * in *err (results of that step are then undefined) and poisons the remaining waits of the launch so that it still ends.
+ * `workspace`: cdc_tower_workspace_bytes() bytes, zeroed once by the caller, private to one (fwd, bwd) pair at a time.
+ * Instantiated for H0 in {64, 128}, H1 = 64, H2 = 32 (config.py:39-42: tower_dims (64, 32)); anything else: CDC_E_BADARG.
+ * ---------------------------------------------------------------------------------------- */
+#define CDC_TOWER_MAX 4
+#define CDC_TOWER_ROWS 128
+#define CDC_TOWER_ERR_TIMEOUT 0x40000000
+typedef struct {
+    const void* wh; int64_t ldwh;         /* [N, K64] bf16 weight copy, rows zero-padded to whole 64-element slabs (forward) */
+    const void* wt; int64_t ldwt;         /* [K, N64] bf16 transposed copy (backward: grad-input) */
+    const float* bias;                    /* [N] */
+    float* z; int64_t ldz;                /* [M, N] fp32 pre-normalisation output: written by the forward, read by the backward */
+    void* dzh; int64_t lddzh;             /* backward: [M, N] bf16 gradient w.r.t. z (operand of the grad-weight launch) */
+    const float* gamma; const float* beta;            /* BatchNorm1d that follows: [N] each */
+    float* running_mean; float* running_var;          /* updated by the forward (momentum, unbiased variance) */
+    int64_t* num_batches_tracked;                     /* incremented by the forward (may be NULL) */
+    float* save_mean; float* save_invstd;             /* [N]: forward -> backward */
+    float* dgamma; float* dbeta;                      /* backward (may be NULL) */
+} cdc_tower_layer;
+typedef struct {
+    const void* xh; int64_t ldxh;         /* [M, H0] bf16 copy of the tower's input, readable up to whole 64-element slabs */
+    float* dx; int64_t lddx;              /* backward: [M, H0] fp32 gradient w.r.t. the input */
+    int32_t accumulate_dx, pad_;
+    cdc_tower_layer l1, l2;
+    void* a1h; int64_t lda1h;             /* [M, H1] bf16 hidden activation after BatchNorm/ReLU/dropout (forward -> backward, grad-weight) */
+    float* a2; int64_t lda2;              /* [M, H2] fp32 second hidden activation (forward -> backward) */
+    const float* wo; const float* bo;     /* output Linear(H2 -> 1): [H2], [1] or NULL */
+    float* dwo; float* dbo;               /* backward: [H2], [1] (may be NULL) */
+} cdc_tower_desc;
+typedef struct {
+    int32_t n_tower, H0, H1, H2;
+    int64_t M;
+    int32_t relu, sigmoid;
+    float drop_p, eps, momentum;
+    int32_t pad_;
+    uint64_t seed1, seed2;                /* dropout streams of the two BatchNorm launches this replaces */
+    const int32_t* seed_offset_dev;
+    float* out; int64_t ld_out;           /* [M, n_tower] */
+    const float* d_out; int64_t ld_dout;  /* backward without the fused loss */
+    const float* wide_x; int64_t ld_wide; /* [M, wide_K] or NULL: input of the wide term added to every tower's logit */
+    const float* wide_w; const float* wide_bias;
+    float* wide_dx; int64_t ld_wide_dx;   /* backward: [M, wide_K] or NULL */
+    float* wide_dw; float* wide_dbias;
+    int32_t wide_K, accumulate_wide_dx;
+    /* fused BCELoss(mean) as in cdc_head_args: set bce_y_i16 or bce_y_f32 */
+    const int64_t* bce_group;
+    const int16_t* bce_y_i16;
+    const float* bce_y_f32;
+    float* bce_loss;
+    float bce_inv_count;
+    int32_t pad2_;
+    void* workspace;                      /* >= cdc_tower_workspace_bytes(), zeroed once */
+    int32_t* err;                         /* device word that receives CDC_TOWER_ERR_TIMEOUT (may be NULL) */
+    cdc_tower_desc t[CDC_TOWER_MAX];
+} cdc_tower_args;
+int64_t cdc_tower_workspace_bytes(const cdc_tower_args* a);
+int cdc_tower_fwd(const cdc_tower_args* a, void* stream);
+int cdc_tower_bwd(const cdc_tower_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Loss (reference: run.py:484,723 — BCELoss(mean) on probabilities gathered by group column,
  * log clamped at -100; backward as aten::binary_cross_entropy_backward with eps 1e-12)
  *   p [B, n_col]; group [B] int64 column per row (NULL => column 0); y int16/float labels.

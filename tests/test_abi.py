@@ -49,6 +49,7 @@ STRUCTS = {
     "cdc_g2_out": "G2Out", "cdc_g2_seg": "G2Seg", "cdc_g2_args": "G2Args", "cdc_wshadow_args": "WShadowArgs",
     "cdc_shadow_args": "ShadowArgs", "cdc_head_tower": "HeadTower", "cdc_head_args": "HeadArgs",
     "cdc_mid_gate1": "MidGate1", "cdc_mid_expert2": "MidExpert2", "cdc_mid_gate2": "MidGate2", "cdc_cgc_mid_fwd_args": "CgcMidFwdArgs",
+    "cdc_tower_layer": "TowerLayer", "cdc_tower_desc": "TowerDesc", "cdc_tower_args": "TowerArgs",
     "cdc_mid_bgate1": "MidBGate1", "cdc_mid_bexpert2": "MidBExpert2", "cdc_mid_bgate2": "MidBGate2", "cdc_cgc_mid_bwd_args": "CgcMidBwdArgs",
 }
 
@@ -83,6 +84,7 @@ def test_limits_match_the_header():
                        ("CDC_MAX_SEL", _lib.MAX_SEL), ("CDC_MAX_BN_SEGS", _lib.MAX_BN_SEGS), ("CDC_SORT_MAX_B", _lib.SORT_MAX_B), ("CDC_SORT_MAX_ROWS", _lib.SORT_MAX_ROWS),
                        ("CDC_BN_ROWS_PER_BLOCK", _lib.BN_ROWS_PER_BLOCK), ("CDC_ROWDOT_PARTS", _lib.ROWDOT_PARTS),
                        ("CDC_G2_MAX_OUT", _lib.G2_MAX_OUT), ("CDC_G2_MAX_SEG", _lib.G2_MAX_SEG), ("CDC_HEAD_MAX_TOWERS", _lib.HEAD_MAX_TOWERS),
+                       ("CDC_TOWER_MAX", _lib.TOWER_MAX), ("CDC_TOWER_ROWS", _lib.TOWER_ROWS),
                        ]:
         m = re.search(rf"#define\s+{macro}\s+(\d+)", src)
         assert m and int(m.group(1)) == val, macro
@@ -195,3 +197,19 @@ def test_entry_points_reject_bad_arguments_without_touching_the_device():
     assert lib.cdc_shard_bucket(one, one, one, one, one, 64, 3, 99, 8, None) < 0                       # more ranks than supported
     with pytest.raises(RuntimeError):
         _lib.check(-1, "probe")
+
+
+def test_fused_tower_launch_refuses_bad_arguments_without_a_launch():
+    from cdcmdr_amd import _lib as L
+    lib = L.load()
+    a = L.TowerArgs()
+    assert lib.cdc_tower_workspace_bytes(C.byref(a)) == -1
+    a.n_tower, a.H0, a.H1, a.H2, a.M = 3, 64, 64, 32, 4096
+    assert lib.cdc_tower_workspace_bytes(C.byref(a)) > 4096
+    assert lib.cdc_tower_fwd(C.byref(a), None) == -1                     # no workspace / buffers
+    a.H0 = 96
+    assert lib.cdc_tower_fwd(C.byref(a), None) == -1 and b"instantiated" in lib.cdc_last_error()
+    a.H0, a.M = 64, 1
+    assert lib.cdc_tower_bwd(C.byref(a), None) == -1 and b"two rows" in lib.cdc_last_error()
+    a.M = 128 * 100
+    assert lib.cdc_tower_fwd(C.byref(a), None) == -2 and b"resident" in lib.cdc_last_error()
