@@ -58,6 +58,7 @@ def parse():
                     help="1: the reference's default attention branch (config.py:24-28: 3 x MultiheadAttention(64, 2 heads) + residual) "
                          "on top of the BASELINE configuration, which is defined without it")
     ap.add_argument("--flush-every", type=int, default=64, help="lazy table: the whole table is replayed once per this many steps")
+    ap.add_argument("--fuse-towers", type=int, default=1, help="0: the towers as the five launches per direction the fused launch replaces (A/B only)")
     ap.add_argument("--pool", type=int, default=0,
                     help="resident synthetic batches cycled through; 0 = warmup+steps (max 1024), so that no batch repeats and "
                          "the lazy table replay sees realistic gaps between two look-ups of a row")
@@ -235,6 +236,9 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    if not args.fuse_towers:
+        from cdcmdr_amd import plan as _plan
+        _plan.TowerChain.enabled = False
     model, field_dims = build_model(args, device)
     table_mode = args.table_mode
     use_graph = bool(args.graph)        # under DP the launch stages between the collectives are graphs

@@ -51,6 +51,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define TW_B4 13
 #define TW_BDONE 14
 #define TW_POISON 15
+#ifndef TW_TRACE
+#define TW_TRACE 0          /* 1 (probe builds only): thread 0 of workgroup 0 stamps the 100 MHz wall clock at every phase boundary
+                               into header bytes [2048, 4096): forward stamps [0, 16), backward stamps [16, 32) */
+#endif
+#if TW_TRACE
+#define TW_STAMP(i) do { if (blockIdx.x == TW_TRACE - 1 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.workspace) + 2048)[(i)] = wall_clock64(); } while (0)
+#else
+#define TW_STAMP(i) do { } while (0)
+#endif
 
 // ---- inter-workgroup accessors: relaxed agent-scope atomics on GLOBAL pointers (global_load / global_store ... sc1)
 template <typename T> __device__ __forceinline__ T tw_ld(const T* p) {
@@ -98,6 +107,7 @@ struct TwLayout {
     int64_t hd;              // backward: head weight-gradient partials [block][n_tower][H2 + 4] floats (slot H2 = bias)
     int64_t wd;              // backward: wide weight-gradient partials [n_tower*block][WD_LD] floats (slot wide_K = bias)
     int64_t loss;            // backward: [block] doubles
+    int64_t wide;            // forward: the wide term of every row [M] floats (each row formed by ONE workgroup, read by all towers)
     int64_t total;
     int wd_ld;
 };
@@ -114,6 +124,7 @@ __host__ __device__ inline TwLayout tw_layout(int n_tower, int H1, int H2, int64
     L.wd = o; o += (int64_t)n_tower * G * L.wd_ld * 4;
     o = (o + 15) / 16 * 16;
     L.loss = o; o += G * 8;
+    L.wide = o; o += (M + 3) / 4 * 16;
     L.total = (o + 127) / 128 * 128;
     return L;
 }
@@ -181,44 +192,51 @@ __device__ __forceinline__ void tw_acc_to_tile(const f32x4_t (&acc)[2][NT], floa
 
 // ---- forward statistics of one layer: this workgroup's (at most two) 64-row chunks -> workspace, in the order of
 // cdc_gemm_bf16_nt's statistics epilogue (csrc/gemm2.hip): wave q adds rows 16q..16q+15 of the chunk, quarters in order.
-// All threads call (barriers inside).  Only wave 0 stores; it drains before it returns.
+// All threads call (barriers inside).  Waves 0 and 1 store; both have drained when the call returns.
 template <int C>
-__device__ __forceinline__ void tw_fwd_chunk_sums(const float* ct, int cs, int row0, int M, double* quarter /*[4][64][2]*/, double* ws,
+__device__ __forceinline__ void tw_fwd_chunk_sums(const float* ct, int cs, int row0, int M, double* quarter /*[2][4][64][2]*/, double* ws,
                                                   int total_c, int col0, int wave, int lane) {
-#pragma unroll
-    for (int h = 0; h < TW_ROWS / 64; ++h) {
-        const int r_lo = row0 + h * 64;
-        if (r_lo >= M) break;                                            // uniform
-        const int rows = min(64, M - r_lo);
-        double s1 = 0.0, s2 = 0.0;
-        if (lane < C) {
-            for (int r = wave * 16; r < min(wave * 16 + 16, rows); ++r) {
-                const double x = (double)ct[(h * 64 + r) * cs + lane];
-                s1 += x; s2 += x * x;
-            }
+    static_assert(TW_ROWS == 128, "two 64-row chunks per block");
+    const int rows0 = min(64, M - row0), rows1 = min(64, M - row0 - 64);          // rows of the two chunks (rows1 may be <= 0)
+    double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+    if (lane < C) {
+#pragma unroll 4
+        for (int r = wave * 16; r < wave * 16 + 16; ++r) {                         // two independent chains: the chunks' sums interleave
+            if (r < rows0) { const double x = (double)ct[r * cs + lane]; s1[0] += x; s2[0] += x * x; }
+            if (r < rows1) { const double x = (double)ct[(64 + r) * cs + lane]; s1[1] += x; s2[1] += x * x; }
         }
-        quarter[(wave * 64 + lane) * 2] = s1; quarter[(wave * 64 + lane) * 2 + 1] = s2;
-        __syncthreads();
-        if (wave == 0 && lane < C) {
-            double* p = ws + ((int64_t)(r_lo / 64) * total_c + col0 + lane) * 2;
-            tw_st(p, ((quarter[(0 * 64 + lane) * 2] + quarter[(1 * 64 + lane) * 2]) + quarter[(2 * 64 + lane) * 2]) + quarter[(3 * 64 + lane) * 2]);
-            tw_st(p + 1, ((quarter[(0 * 64 + lane) * 2 + 1] + quarter[(1 * 64 + lane) * 2 + 1]) + quarter[(2 * 64 + lane) * 2 + 1]) + quarter[(3 * 64 + lane) * 2 + 1]);
-        }
-        __syncthreads();
     }
-    if (wave == 0) tw_drain();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { quarter[((h * 4 + wave) * 64 + lane) * 2] = s1[h]; quarter[((h * 4 + wave) * 64 + lane) * 2 + 1] = s2[h]; }
+    __syncthreads();
+    if (wave < 2 && lane < C && (wave == 0 || rows1 > 0)) {                         // wave h publishes chunk h
+        const int h = wave;
+        double* p = ws + ((int64_t)(row0 / 64 + h) * total_c + col0 + lane) * 2;
+        const double* q = quarter + (h * 4 * 64 + lane) * 2;
+        tw_st(p, ((q[0] + q[64 * 2]) + q[2 * 64 * 2]) + q[3 * 64 * 2]);
+        tw_st(p + 1, ((q[1] + q[64 * 2 + 1]) + q[2 * 64 * 2 + 1]) + q[3 * 64 * 2 + 1]);
+    }
+    tw_drain();                                                                    // every wave: also what it stored before this call
+    __syncthreads();                                                               // (the storing waves have drained; `quarter` is free again)
 }
 // Sum over `n_parts` published partial records of the tower's C columns, as cdc_bn_fwd's bn_sum_partials_v does: NP = 256 / C
 // threads per column take records pt, pt + NP, ... and the NP sums are added in order.  out[2][C] doubles in LDS.  All threads call.
 template <int C>
 __device__ __forceinline__ void tw_gather_sums(const double* ws, int n_parts, int total_c, int col0, double* part /*[2][NP][C]*/, double* out, int tid) {
-    constexpr int NP = TW_THREADS / C;
+    constexpr int NP = TW_THREADS / C, BATCH = 16;
     const int j = tid % C, pt = tid / C;
     double a1 = 0.0, a2 = 0.0;
-#pragma unroll 4
-    for (int k = pt; k < n_parts; k += NP) {
-        const double* p = ws + ((int64_t)k * total_c + col0 + j) * 2;
-        a1 += tw_ld(p); a2 += tw_ld(p + 1);
+    for (int k0 = pt; k0 < n_parts; k0 += NP * BATCH) {                  // a batch's 32 loads are in flight together (one round trip
+        double v1[BATCH], v2[BATCH];                                     // to L2 per batch, not per record); the adds keep the order
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b) {
+            const int k = k0 + b * NP;
+            const double* p = ws + ((int64_t)(k < n_parts ? k : pt) * total_c + col0 + j) * 2;
+            v1[b] = tw_ld(p); v2[b] = tw_ld(p + 1);
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; ++b)
+            if (k0 + b * NP < n_parts) { a1 += v1[b]; a2 += v2[b]; }
     }
     part[(0 * NP + pt) * C + j] = a1; part[(1 * NP + pt) * C + j] = a2;
     __syncthreads();
@@ -275,6 +293,17 @@ __device__ __forceinline__ void tw_bn_apply8(float (&v)[8], const float* col_mea
     }
 }
 
+// the small per-column vectors of a tower, staged in LDS at kernel entry (a global load at the point of use is a round trip of
+// its own on the critical path of a workgroup): offsets in floats
+#define TW_PAR_B1 0          /* bias, gamma, beta of layer 1 (64 each) — backward: save_mean, gamma * save_invstd, save_invstd */
+#define TW_PAR_G1 64
+#define TW_PAR_BE1 128
+#define TW_PAR_B2 192        /* the same of layer 2 */
+#define TW_PAR_G2 256
+#define TW_PAR_BE2 320
+#define TW_PAR_WO 384        /* head weight [H2] and bias [1] */
+#define TW_PAR_FLOATS 456
+
 // =================================================================================================
 // forward
 // =================================================================================================
@@ -291,7 +320,8 @@ struct TwFwdCfg {
     static constexpr int CMEAN = SUMS + 2 * 64 * 8;                  // [64] floats
     static constexpr int CINV = CMEAN + 64 * 4;
     static constexpr int WIDE = CINV + 64 * 4;                       // [128] floats
-    static constexpr int SMEM = WIDE + TW_ROWS * 4;
+    static constexpr int PAR = WIDE + TW_ROWS * 4;                   // the layers' small vectors, fetched at entry (TW_PAR_*)
+    static constexpr int SMEM = PAR + TW_PAR_FLOATS * 4;
 };
 
 template <int NK0, int H1, int H2>
@@ -325,6 +355,16 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
     float* col_mean = reinterpret_cast<float*>(smem + Cfg::CMEAN);
     float* col_inv = reinterpret_cast<float*>(smem + Cfg::CINV);
     float* wide_s = reinterpret_cast<float*>(smem + Cfg::WIDE);
+    float* par_s = reinterpret_cast<float*>(smem + Cfg::PAR);
+    {
+        float v = 0.f;
+        const int k = tid & 63, which = tid >> 6;
+        if (which == 0 && k < H1) { par_s[TW_PAR_B1 + k] = T.l1.bias[k]; par_s[TW_PAR_G1 + k] = T.l1.gamma[k]; par_s[TW_PAR_BE1 + k] = T.l1.beta[k]; }
+        if (which == 1 && k < H2) { par_s[TW_PAR_B2 + k] = T.l2.bias[k]; par_s[TW_PAR_G2 + k] = T.l2.gamma[k]; par_s[TW_PAR_BE2 + k] = T.l2.beta[k]; }
+        if (which == 2 && k < H2) par_s[TW_PAR_WO + k] = T.wo[k];
+        if (which == 2 && k == H2) par_s[TW_PAR_WO + H2] = T.bo ? T.bo[0] : 0.f;
+        (void)v;
+    }
 
     // ---- operands of both contractions: global -> LDS, all in flight at once
     {
@@ -344,8 +384,10 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
     const uint32_t thr16 = (uint32_t)(a.drop_p * 65536.f + 0.5f);
     const bool relu = a.relu != 0;
     const float drop_p = a.drop_p;
+    TW_STAMP(0);
     tw_drain();
     __syncthreads();
+    TW_STAMP(1);
 
     // ================= layer 1: Z1 = X W1^T + b1
     {
@@ -357,7 +399,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
     {
         constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
         const int c = (tid % C8) * 8, lr0 = tid / C8;
-        const float* bias = T.l1.bias;
+        const float* bias = par_s + TW_PAR_B1;
         const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bias + c), b1 = *reinterpret_cast<const f32x4_t*>(bias + c + 4);
         float* z = T.l1.z; const int64_t ldz = T.l1.ldz;
 #pragma unroll
@@ -375,42 +417,65 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
     __syncthreads();
     tw_fwd_chunk_sums<H1>(ct, Cfg::CS1, row0, M, part, reinterpret_cast<double*>(wsb + L.st1), n_tower * H1, t * H1, wave, lane);
     if (tid == 0) tw_arrive(hdr, TW_F1(t));
+    TW_STAMP(2);
 
-    // ---- under the wait: the wide term of this block's rows (model/layer.py:122-126), half a wave per row, 16-byte lanes
+    // ---- under the wait: the wide term (model/layer.py:122-126) of this block's rows l = t, t + n_tower, ... (the other towers'
+    // workgroups of the block form the rest; everyone reads all of them behind the second exchange, which is why that one is an
+    // exchange of ALL workgroups): a wave per row, 16-byte lanes, the loads of twelve rows in flight together
     if (a.wide_x) {
         const float* wx = a.wide_x; const int64_t ldw = a.ld_wide; const int K4 = a.wide_K >> 2;
-        const int hl = lane & 31, half = lane >> 5;
-        f32x4_t wv[4];
+        float* pub = reinterpret_cast<float*>(wsb + L.wide);
+        f32x4_t wv[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wv[q] = (hl + 32 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(a.wide_w + 4 * (hl + 32 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 2; ++q) wv[q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(a.wide_w + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
         const float wb = a.wide_bias ? a.wide_bias[0] : 0.f;
-        for (int i = 0; i < 16; ++i) {
-            const int lr = wave * 32 + i * 2 + half;
-            const int gr = row0 + min(lr, rows - 1);
-            f32x4_t xv[4];
+        const int n_mine = (rows - t + n_tower - 1) / n_tower;           // rows t, t + n_tower, ... < rows
+        for (int i0 = wave; i0 < n_mine; i0 += 4 * 12) {
+            f32x4_t xv[12][2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                xv[q] = (hl + 32 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(wx + (int64_t)gr * ldw + 4 * (hl + 32 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            float s = 0.f;
+            for (int b = 0; b < 12; ++b) {
+                const int i = i0 + 4 * b;
+                const int64_t gr = row0 + t + (int64_t)n_tower * (i < n_mine ? i : i0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s += (xv[q][0] * wv[q][0] + xv[q][1] * wv[q][1]) + (xv[q][2] * wv[q][2] + xv[q][3] * wv[q][3]);
+                for (int q = 0; q < 2; ++q)
+                    xv[b][q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(wx + gr * ldw + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            float sv[12];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (hl == 0) wide_s[lr] = s + wb;
+            for (int b = 0; b < 12; ++b) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) s_ += (xv[b][q][0] * wv[q][0] + xv[b][q][1] * wv[q][1]) + (xv[b][q][2] * wv[q][2] + xv[b][q][3] * wv[q][3]);
+                sv[b] = s_;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)                             // twelve independent butterflies, step by step (a shuffle is ~100 cycles
+#pragma unroll
+                for (int b = 0; b < 12; ++b) sv[b] += __shfl_xor(sv[b], o, 64);   // of latency: one row after the other they add up)
+#pragma unroll
+            for (int b = 0; b < 12; ++b) {
+                const int i = i0 + 4 * b;
+                if (lane == 0 && i < n_mine) tw_st(pub + row0 + t + n_tower * i, sv[b] + wb);
+            }
         }
+        // (no drain here: these write-through stores have until the second exchange's arrival; every wave drains in front of the
+        // barrier that precedes it, tw_fwd_chunk_sums)
     }
+    TW_STAMP(3);
     if (tid == 0) (void)tw_wait(hdr, TW_F1(t), G, err);
     __syncthreads();
+    TW_STAMP(4);
     tw_gather_sums<H1>(reinterpret_cast<const double*>(wsb + L.st1), (M + 63) / 64, n_tower * H1, t * H1, part, sums, tid);
     tw_finish_stats<H1>(sums, M, a.eps, a.momentum, writer, T.l1.save_mean, T.l1.save_invstd, T.l1.running_mean, T.l1.running_var,
                         T.l1.num_batches_tracked, col_mean, col_inv, tid);
+    TW_STAMP(5);
 
     // ---- A1 = dropout(relu(bn(Z1))): bf16 into the A operand image of layer 2 and into its global copy
     {
         constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
         const int c8 = tid % C8, c = c8 * 8, lr0 = tid / C8;
         const uint32_t seed32 = drop_p > 0.f ? g2_seed32(a.seed1, a.seed_offset_dev, 64 + t) : 0u;
-        const float* gamma = T.l1.gamma; const float* beta = T.l1.beta;
+        const float* gamma = par_s + TW_PAR_G1; const float* beta = par_s + TW_PAR_BE1;
         __bf16* a1h = reinterpret_cast<__bf16*>(T.a1h); const int64_t lda = T.lda1h;
 #pragma unroll
         for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
@@ -439,7 +504,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
     {
         constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
         const int c = (tid % C8) * 8, lr0 = tid / C8;
-        const float* bias = T.l2.bias;
+        const float* bias = par_s + TW_PAR_B2;
         const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(bias + c), b1 = *reinterpret_cast<const f32x4_t*>(bias + c + 4);
         float* z = T.l2.z; const int64_t ldz = T.l2.ldz;
 #pragma unroll
@@ -456,20 +521,24 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
     }
     __syncthreads();
     tw_fwd_chunk_sums<H2>(ct, Cfg::CS2, row0, M, part, reinterpret_cast<double*>(wsb + L.st2), n_tower * H2, t * H2, wave, lane);
+    TW_STAMP(6);
     if (tid == 0) {
-        tw_arrive(hdr, TW_F2(t));
-        (void)tw_wait(hdr, TW_F2(t), G, err);
+        tw_arrive(hdr, TW_F2(0));                                        // ALL workgroups (the wide term's rows come from every tower's)
+        (void)tw_wait(hdr, TW_F2(0), n_tower * G, err);
     }
     __syncthreads();
+    TW_STAMP(7);
+    if (a.wide_x && tid < rows) wide_s[tid] = tw_ld(reinterpret_cast<const float*>(wsb + L.wide) + row0 + tid);
     tw_gather_sums<H2>(reinterpret_cast<const double*>(wsb + L.st2), (M + 63) / 64, n_tower * H2, t * H2, part, sums, tid);
     tw_finish_stats<H2>(sums, M, a.eps, a.momentum, writer, T.l2.save_mean, T.l2.save_invstd, T.l2.running_mean, T.l2.running_var,
                         T.l2.num_batches_tracked, col_mean, col_inv, tid);
+    TW_STAMP(8);
     // ---- A2 = dropout(relu(bn(Z2))) in fp32: kept in the tile for the head, written out for the backward
     {
         constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
         const int c = (tid % C8) * 8, lr0 = tid / C8;
         const uint32_t seed32 = drop_p > 0.f ? g2_seed32(a.seed2, a.seed_offset_dev, 64 + t) : 0u;
-        const float* gamma = T.l2.gamma; const float* beta = T.l2.beta;
+        const float* gamma = par_s + TW_PAR_G2; const float* beta = par_s + TW_PAR_BE2;
         float* a2 = T.a2; const int64_t lda = T.lda2;
 #pragma unroll
         for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
@@ -486,24 +555,26 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
         }
     }
     __syncthreads();
-    // ---- the head: Linear(H2 -> 1) + wide term + sigmoid, a wave per row with lane = column (k_head_fwd's order)
+    // ---- the head: Linear(H2 -> 1) + wide term + sigmoid; two threads per row, each half of the row's columns in ascending order
     {
-        const float wo = lane < H2 ? T.wo[lane] : 0.f;
-        const float bo = T.bo ? T.bo[0] : 0.f;
-        const bool has_wide = a.wide_x != nullptr, sig = a.sigmoid != 0;
-        float* out = a.out; const int64_t ldo = a.ld_out;
-        for (int i = 0; i < 32; ++i) {
-            const int lr = wave * 32 + i;
-            float acc = lane < H2 ? ct[lr * Cfg::CS2 + lane] * wo : 0.f;
-            acc = wave_sum(acc);
-            if (lane == 0 && lr < rows) {
-                if (T.bo) acc += bo;
-                if (has_wide) acc += wide_s[lr];
-                if (sig) acc = 1.f / (1.f + expf(-acc));
-                out[(int64_t)(row0 + lr) * ldo + t] = acc;
-            }
+        const int lr = tid >> 1, hf = tid & 1;
+        const float* arow = ct + lr * Cfg::CS2 + hf * (H2 / 2);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < H2 / 2; k += 4) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(arow + k);
+            const f32x4_t w = *reinterpret_cast<const f32x4_t*>(par_s + TW_PAR_WO + hf * (H2 / 2) + k);
+            acc += v[0] * w[0]; acc += v[1] * w[1]; acc += v[2] * w[2]; acc += v[3] * w[3];
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        if (hf == 0 && lr < rows) {
+            if (T.bo) acc += par_s[TW_PAR_WO + H2];
+            if (a.wide_x) acc += wide_s[lr];
+            if (a.sigmoid) acc = 1.f / (1.f + expf(-acc));
+            a.out[(int64_t)(row0 + lr) * a.ld_out + t] = acc;
         }
     }
+    TW_STAMP(9);
     if (tid == 0) tw_finish(hdr, TW_FDONE, n_tower * G, TW_F1(0), TW_FDONE);
 }
 
@@ -529,7 +600,8 @@ struct TwBwdCfg {
     static constexpr int OWN = DSUM + TW_ROWS * 4;
     static constexpr int LOSS = OWN + (2 * TW_ROWS + 4) * 4;
     static constexpr int WDW = LOSS + TW_ROWS * 8;                   // [4 waves][520] floats: the wide term's weight-gradient partials
-    static constexpr int SMEM = WDW + 4 * 520 * 4;
+    static constexpr int PAR = WDW + 4 * 520 * 4;                    // small vectors (TW_PAR_*: mean, gamma * invstd, invstd per layer; head weight)
+    static constexpr int SMEM = PAR + TW_PAR_FLOATS * 4;
 };
 
 // column sums over this block's rows of tile u (and of u * w, in double) by NPT = 256 / C threads per column, parts added in order
@@ -553,6 +625,52 @@ __device__ __forceinline__ void tw_block_sums(const float* u, const float* w, in
         out[tid] = b1; out[C + tid] = b2;
     }
     __syncthreads();
+}
+
+// the wide term's gradients of the rows in `own` (a wave per row, TW_WNB rows per round, their loads in flight together):
+// dx (+)= dsum * w,  dw += dsum * x,  db += dsum.  A round = its rows' inputs in registers (fetched ahead: the first round's loads
+// are issued before the layer-2 phase and land under it).
+#define TW_WNB 12
+struct TwWideRound { f32x4_t xv[TW_WNB][2]; int lr[TW_WNB]; };
+__device__ __forceinline__ void tw_wide_load(TwWideRound& R, const float* wide_x, int64_t ld_wide, const int* own, const float* dsum_s, int n_own,
+                                             int i0, int row0, int K4, int lane) {
+#pragma unroll
+    for (int b = 0; b < TW_WNB; ++b) {
+        const int i = i0 + 4 * b;
+        const int lr = own[i < n_own ? i : (i0 < n_own ? i0 : 0)];
+        R.lr[b] = lr;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            R.xv[b][q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(wide_x + (int64_t)(row0 + lr) * ld_wide + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <bool RMW>
+__device__ __forceinline__ void tw_wide_apply(const TwWideRound& R, float* wide_dx, int64_t ld_wide_dx, const float* dsum_s, int row0, int n_own, int i0, int K4,
+                                              const f32x4_t (&wv)[2], f32x4_t (&dwv)[2], float& dbv, int lane) {
+    f32x4_t ov[RMW ? TW_WNB : 1][2];
+    if constexpr (RMW) {
+#pragma unroll
+        for (int b = 0; b < TW_WNB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                ov[b][q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(wide_dx + (int64_t)(row0 + R.lr[b]) * ld_wide_dx + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int b = 0; b < TW_WNB; ++b) {
+        if (i0 + 4 * b >= n_own) break;                                  // uniform
+        const float ds = dsum_s[R.lr[b]];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if ((lane + 64 * q) >= K4) continue;
+            dwv[q] += R.xv[b][q] * ds;
+            if (wide_dx) {
+                f32x4_t v = wv[q] * ds;
+                if constexpr (RMW) v = ov[b][q] + v;
+                *reinterpret_cast<f32x4_t*>(wide_dx + (int64_t)(row0 + R.lr[b]) * ld_wide_dx + 4 * (lane + 64 * q)) = v;
+            }
+        }
+        dbv += ds;
+    }
 }
 
 template <int NK0, int H1, int H2>
@@ -592,6 +710,19 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     int* mine_s = own_s + TW_ROWS + 4;                               // [128] flags
     double* loss_s = reinterpret_cast<double*>(smem + Cfg::LOSS);
     float* wdw_s = reinterpret_cast<float*>(smem + Cfg::WDW);
+    float* par_s = reinterpret_cast<float*>(smem + Cfg::PAR);
+    {
+        const int k = tid & 63, which = tid >> 6;
+        if (which == 0 && k < H1) {
+            const float inv = T.l1.save_invstd[k];
+            par_s[TW_PAR_B1 + k] = T.l1.save_mean[k]; par_s[TW_PAR_G1 + k] = T.l1.gamma[k] * inv; par_s[TW_PAR_BE1 + k] = inv;
+        }
+        if (which == 1 && k < H2) {
+            const float inv = T.l2.save_invstd[k];
+            par_s[TW_PAR_B2 + k] = T.l2.save_mean[k]; par_s[TW_PAR_G2 + k] = T.l2.gamma[k] * inv; par_s[TW_PAR_BE2 + k] = inv;
+        }
+        if (which == 2 && k < H2) par_s[TW_PAR_WO + k] = T.wo[k];
+    }
 
     // ---- grad-input operands: W2^T and W1^T -> LDS (needed after the first exchange: they land under everything before it)
     tw_load_tile(reinterpret_cast<const __bf16*>(T.l2.wt), T.l2.ldwt, 0, H1, H1, WT2S, wave, lane);
@@ -600,6 +731,24 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     const float mask_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
     const bool masked = a.relu != 0 || mask_scale != 1.f;
     const float invM = 1.f / (float)M;
+    // this thread's layer-2 pieces (saved pre-normalisation values, activations): in flight under the logit-gradient phase
+    constexpr int L2P = TW_ROWS / (TW_THREADS / (H2 / 8));
+    f32x4_t qzl[L2P], qzh[L2P], qal[L2P], qah[L2P];
+    {
+        constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+        const int c = (tid % C8) * 8, lr0 = tid / C8;
+        const float* z2 = T.l2.z; const int64_t ldz = T.l2.ldz;
+        const float* a2 = T.a2; const int64_t lda = T.lda2;
+#pragma unroll
+        for (int i = 0; i < L2P; ++i) {
+            const int lr = min(lr0 + i * RPP, rows - 1);
+            qzl[i] = *reinterpret_cast<const f32x4_t*>(z2 + (int64_t)(row0 + lr) * ldz + c);
+            qzh[i] = *reinterpret_cast<const f32x4_t*>(z2 + (int64_t)(row0 + lr) * ldz + c + 4);
+            qal[i] = *reinterpret_cast<const f32x4_t*>(a2 + (int64_t)(row0 + lr) * lda + c);
+            qah[i] = *reinterpret_cast<const f32x4_t*>(a2 + (int64_t)(row0 + lr) * lda + c + 4);
+        }
+    }
+    TW_STAMP(16);
 
     // ---- (1) logit gradients of the block's rows (k_head_bwd's arithmetic: BCELoss(mean) on the row's own tower, or d_out)
     if (tid < TW_ROWS) {
@@ -650,6 +799,9 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     }
     __syncthreads();
 
+    TwWideRound wr;                                                      // first round of the wide gradients' inputs: lands under phase (2)
+    if (has_wide) tw_wide_load(wr, a.wide_x, a.ld_wide, own_s, dsum_s, own_s[TW_ROWS], wave, row0, wide_K >> 2, lane);
+    TW_STAMP(17);
     // ---- (2) layer-2 pieces: dz2 = mask(a2) * d * wo, xhat2 -> tiles; head weight-gradient products ride on the a2 tile
     float* DZ2 = P;
     float* XH2 = P + TW_ROWS * Cfg::CS2;
@@ -657,24 +809,17 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     {
         constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
         const int c = (tid % C8) * 8, lr0 = tid / C8;
-        const float* z2 = T.l2.z; const int64_t ldz = T.l2.ldz;
-        const float* a2 = T.a2; const int64_t lda = T.lda2;
         float wo[8], mean[8], inv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { wo[q] = T.wo[c + q]; mean[q] = T.l2.save_mean[c + q]; inv[q] = T.l2.save_invstd[c + q]; }
+        for (int q = 0; q < 8; ++q) { wo[q] = par_s[TW_PAR_WO + c + q]; mean[q] = par_s[TW_PAR_B2 + c + q]; inv[q] = par_s[TW_PAR_BE2 + c + q]; }
 #pragma unroll
-        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
-            f32x4_t zl = {0.f, 0.f, 0.f, 0.f}, zh = zl, al = zl, ah = zl;
-            if (lr < rows) {
-                zl = *reinterpret_cast<const f32x4_t*>(z2 + (int64_t)(row0 + lr) * ldz + c);
-                zh = *reinterpret_cast<const f32x4_t*>(z2 + (int64_t)(row0 + lr) * ldz + c + 4);
-                al = *reinterpret_cast<const f32x4_t*>(a2 + (int64_t)(row0 + lr) * lda + c);
-                ah = *reinterpret_cast<const f32x4_t*>(a2 + (int64_t)(row0 + lr) * lda + c + 4);
-            }
+        for (int i = 0; i < L2P; ++i) {
+            const int lr = lr0 + i * RPP;
+            const bool live = lr < rows;
             const float d = d_s[lr];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float zv = q < 4 ? zl[q] : zh[q - 4], av = q < 4 ? al[q] : ah[q - 4];
+                const float zv = q < 4 ? qzl[i][q] : qzh[i][q - 4], av = live ? (q < 4 ? qal[i][q] : qah[i][q - 4]) : 0.f;
                 float dz = d * wo[q];
                 if (masked) dz = av > 0.f ? dz * mask_scale : 0.f;
                 DZ2[lr * Cfg::CS2 + c + q] = dz;
@@ -709,15 +854,16 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
             for (int q = 0; q < NPT; ++q) b += part[(1 * NPT + q) * H2 + 0];
             tw_st(hd + H2, (float)b);
         }
-        if (t == 0 && tid == 64) {                                       // the block's loss partial (row order)
-            double s_ = 0.0;
-            for (int r = 0; r < rows; ++r) s_ += loss_s[r];
-            tw_st(reinterpret_cast<double*>(wsb + L.loss) + jb, s_);
+        if (t == 0 && wave == 1) {                                       // the block's loss partial
+            double s_ = (lane < rows ? loss_s[lane] : 0.0) + (lane + 64 < rows ? loss_s[lane + 64] : 0.0);
+            s_ = wave_sum_d(s_);
+            if (lane == 0) tw_st(reinterpret_cast<double*>(wsb + L.loss) + jb, s_);
         }
     }
     tw_drain();
     __syncthreads();
     if (tid == 0) tw_arrive(hdr, TW_B3(t));
+    TW_STAMP(18);
 
     // ---- under the wait: the wide term's gradients for the rows this workgroup owns (k_head_bwd (3)): a wave per row
     if (has_wide) {
@@ -731,27 +877,10 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
         }
         float dbv = 0.f;
         const bool rmw = a.wide_dx && a.accumulate_wide_dx;
-        for (int i = wave; i < n_own; i += 4) {
-            const int lr = own_s[i];
-            const int64_t r = row0 + lr;
-            const float ds = dsum_s[lr];
-            f32x4_t xv[2], ov[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const bool in = (lane + 64 * q) < K4;
-                xv[q] = in ? *reinterpret_cast<const f32x4_t*>(a.wide_x + r * a.ld_wide + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                ov[q] = (in && rmw) ? *reinterpret_cast<const f32x4_t*>(a.wide_dx + r * a.ld_wide_dx + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if ((lane + 64 * q) >= K4) continue;
-                dwv[q] += xv[q] * ds;
-                if (a.wide_dx) {
-                    const f32x4_t v = wv[q] * ds;
-                    *reinterpret_cast<f32x4_t*>(a.wide_dx + r * a.ld_wide_dx + 4 * (lane + 64 * q)) = rmw ? ov[q] + v : v;
-                }
-            }
-            dbv += ds;
+        for (int i0 = wave; i0 < n_own; i0 += 4 * TW_WNB) {
+            if (i0 != wave) tw_wide_load(wr, a.wide_x, a.ld_wide, own_s, dsum_s, n_own, i0, row0, K4, lane);   // (the first round is in registers)
+            if (rmw) tw_wide_apply<true>(wr, a.wide_dx, a.ld_wide_dx, dsum_s, row0, n_own, i0, K4, wv, dwv, dbv, lane);
+            else tw_wide_apply<false>(wr, a.wide_dx, a.ld_wide_dx, dsum_s, row0, n_own, i0, K4, wv, dwv, dbv, lane);
         }
         // rows nobody owns here still need their wide_dx written when this launch is the first writer: every row has exactly one
         // owner (its own tower's workgroup of the same block), so nothing is left out
@@ -762,27 +891,63 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
         if (lane == 0) mine[wide_K] = dbv;
         __syncthreads();
         float* wd = reinterpret_cast<float*>(wsb + L.wd) + ((int64_t)t * G + jb) * L.wd_ld;
-        for (int k = tid; k <= wide_K; k += TW_THREADS)
-            tw_st(wd + k, ((wdw_s[k] + wdw_s[520 + k]) + wdw_s[2 * 520 + k]) + wdw_s[3 * 520 + k]);
+        for (int k = 2 * tid; k <= wide_K; k += 2 * TW_THREADS) {            // 8-byte write-through stores (a 4-byte one costs as much)
+            union { float f[2]; unsigned long long u; } pk;
+            pk.f[0] = ((wdw_s[k] + wdw_s[520 + k]) + wdw_s[2 * 520 + k]) + wdw_s[3 * 520 + k];
+            pk.f[1] = k + 1 <= wide_K ? ((wdw_s[k + 1] + wdw_s[520 + k + 1]) + wdw_s[2 * 520 + k + 1]) + wdw_s[3 * 520 + k + 1] : 0.f;
+            tw_st(reinterpret_cast<unsigned long long*>(wd + k), pk.u);
+        }
     }
+    // layer 1's saved pre-normalisation values and hidden activations of this thread's pieces: in flight under the exchange
+    constexpr int L1P = TW_ROWS / (TW_THREADS / (H1 / 8));
+    f32x4_t pzl[L1P], pzh[L1P];
+    bf16x8_t pm8[L1P];
+    {
+        constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+        const int c = (tid % C8) * 8, lr0 = tid / C8;
+        const float* z1 = T.l1.z; const int64_t ldz = T.l1.ldz;
+        const __bf16* a1h = reinterpret_cast<const __bf16*>(T.a1h); const int64_t lda = T.lda1h;
+#pragma unroll
+        for (int i = 0; i < L1P; ++i) {
+            const int lr = min(lr0 + i * RPP, rows - 1);
+            pzl[i] = *reinterpret_cast<const f32x4_t*>(z1 + (int64_t)(row0 + lr) * ldz + c);
+            pzh[i] = *reinterpret_cast<const f32x4_t*>(z1 + (int64_t)(row0 + lr) * ldz + c + 4);
+            pm8[i] = *reinterpret_cast<const bf16x8_t*>(a1h + (int64_t)(row0 + lr) * lda + c);
+        }
+    }
+    TW_STAMP(19);
     if (tid == 0) (void)tw_wait(hdr, TW_B3(t), G, err);
     __syncthreads();
+    TW_STAMP(20);
     tw_gather_sums<H2>(reinterpret_cast<const double*>(wsb + L.b2), G, n_tower * H2, t * H2, part, sums, tid);
     if (writer) {
         if (tid < H2) {
             if (T.l2.dbeta) T.l2.dbeta[tid] = (float)sums[tid];
             if (T.l2.dgamma) T.l2.dgamma[tid] = (float)sums[H2 + tid];
         }
-        // the tower's head gradient: block partials in block order
-        if (tid >= 64 && tid < 64 + H2 + 1) {
-            const int k = tid - 64;
+    }
+    if (writer) {
+        // the tower's head gradient: eight lanes per column take block partials l, l + 8, ... (their loads in flight together), a butterfly
+        // adds the eight
+        for (int k = tid >> 3; k <= H2; k += TW_THREADS / 8) {
+            const int p8 = tid & 7;
             const float* hd = reinterpret_cast<const float*>(wsb + L.hd) + (int64_t)t * (H2 + 4) + k;
             float s = 0.f;
-            for (int b = 0; b < G; ++b) s += tw_ld(hd + (int64_t)b * n_tower * (H2 + 4));
-            if (k < H2) { if (T.dwo) T.dwo[k] = s; }
-            else if (T.dbo) T.dbo[0] = s;
+            for (int b0 = p8; b0 < G; b0 += 64) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (b0 + 8 * q) < G ? tw_ld(hd + (int64_t)(b0 + 8 * q) * n_tower * (H2 + 4)) : 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += v[q];
+            }
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            if (p8 == 0) {
+                if (k < H2) { if (T.dwo) T.dwo[k] = s; }
+                else if (T.dbo) T.dbo[0] = s;
+            }
         }
     }
+    TW_STAMP(21);
     // ---- (3) dZ2 = gamma invstd (dz - (db + xhat dg) / M) -> A operand image + global bf16 copy (grad-weight launch)
     {
         constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
@@ -790,7 +955,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
         float k1[8], db[8], dg[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            k1[q] = T.l2.gamma[c + q] * T.l2.save_invstd[c + q];
+            k1[q] = par_s[TW_PAR_G2 + c + q];
             db[q] = (float)sums[c + q]; dg[q] = (float)sums[H2 + c + q];
         }
         __bf16* dzh = reinterpret_cast<__bf16*>(T.l2.dzh); const int64_t ldd = T.l2.lddzh;
@@ -810,6 +975,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     }
     tw_drain();                                                          // (also: the W^T tiles have landed)
     __syncthreads();
+    TW_STAMP(22);
     // ---- (4) dA1 = dZ2 W2 -> tile; dz1 = mask(a1) * dA1, xhat1 -> tiles (dz1 in place)
     float* DZ1 = P;
     float* XH1 = P + TW_ROWS * Cfg::CS1;
@@ -822,27 +988,19 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     {
         constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
         const int c = (tid % C8) * 8, lr0 = tid / C8;
-        const float* z1 = T.l1.z; const int64_t ldz = T.l1.ldz;
-        const __bf16* a1h = reinterpret_cast<const __bf16*>(T.a1h); const int64_t lda = T.lda1h;
         float mean[8], inv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { mean[q] = T.l1.save_mean[c + q]; inv[q] = T.l1.save_invstd[c + q]; }
+        for (int q = 0; q < 8; ++q) { mean[q] = par_s[TW_PAR_B1 + c + q]; inv[q] = par_s[TW_PAR_BE1 + c + q]; }
 #pragma unroll
-        for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
-            f32x4_t zl = {0.f, 0.f, 0.f, 0.f}, zh = zl;
-            bf16x8_t m8 = {};
-            if (lr < rows) {
-                zl = *reinterpret_cast<const f32x4_t*>(z1 + (int64_t)(row0 + lr) * ldz + c);
-                zh = *reinterpret_cast<const f32x4_t*>(z1 + (int64_t)(row0 + lr) * ldz + c + 4);
-                m8 = *reinterpret_cast<const bf16x8_t*>(a1h + (int64_t)(row0 + lr) * lda + c);
-            }
+        for (int i = 0; i < L1P; ++i) {
+            const int lr = lr0 + i * RPP;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float dz = DZ1[lr * Cfg::CS1 + c + q];
-                if (masked) dz = (float)m8[q] > 0.f ? dz * mask_scale : 0.f;
+                if (masked) dz = (float)pm8[i][q] > 0.f ? dz * mask_scale : 0.f;
                 if (lr >= rows) dz = 0.f;
                 DZ1[lr * Cfg::CS1 + c + q] = dz;
-                XH1[lr * Cfg::CS1 + c + q] = ((q < 4 ? zl[q] : zh[q - 4]) - mean[q]) * inv[q];
+                XH1[lr * Cfg::CS1 + c + q] = ((q < 4 ? pzl[i][q] : pzh[i][q - 4]) - mean[q]) * inv[q];
             }
         }
     }
@@ -854,12 +1012,15 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     }
     tw_drain();
     __syncthreads();
+    TW_STAMP(23);
     if (tid == 0) {
         tw_arrive(hdr, TW_B4);                                           // ALL towers: the wide gradient's partials come from all of them
         (void)tw_wait(hdr, TW_B4, n_wg, err);
     }
     __syncthreads();
+    TW_STAMP(24);
     tw_gather_sums<H1>(reinterpret_cast<const double*>(wsb + L.b1), G, n_tower * H1, t * H1, part, sums, tid);
+    TW_STAMP(25);
     if (writer && tid < H1) {
         if (T.l1.dbeta) T.l1.dbeta[tid] = (float)sums[tid];
         if (T.l1.dgamma) T.l1.dgamma[tid] = (float)sums[H1 + tid];
@@ -871,7 +1032,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
         float k1[8], db[8], dg[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            k1[q] = T.l1.gamma[c + q] * T.l1.save_invstd[c + q];
+            k1[q] = par_s[TW_PAR_G1 + c + q];
             db[q] = (float)sums[c + q]; dg[q] = (float)sums[H1 + c + q];
         }
         __bf16* dzh = reinterpret_cast<__bf16*>(T.l1.dzh); const int64_t ldd = T.l1.lddzh;
@@ -890,6 +1051,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
         }
     }
     __syncthreads();
+    TW_STAMP(26);
     // ---- (6) dX = dZ1 W1 -> tile -> global
     {
         f32x4_t acc[2][H0 / 16];
@@ -913,6 +1075,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
             *reinterpret_cast<f32x4_t*>(dst + 4) = hi;
         }
     }
+    TW_STAMP(27);
     // ---- (7) sums over ALL workgroups (published before the last exchange): the wide term's weight gradient (a wave per
     // column: lanes take partials l, l + 64, ... in order, then a butterfly) and the loss
     if (has_wide) {
@@ -934,6 +1097,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
         s = wave_sum_d(s);
         if (lane == 0) *a.bce_loss = (float)(s * (double)a.bce_inv_count);
     }
+    TW_STAMP(28);
     if (tid == 0) tw_finish(hdr, TW_BDONE, n_wg, TW_B3(0), TW_BDONE);
 }
 
