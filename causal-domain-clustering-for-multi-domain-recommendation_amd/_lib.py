@@ -355,6 +355,7 @@ _SIGNATURES = {
     "cdc_gate_pool_fwd": (c_i32, [C.POINTER(PoolFwdArgs), c_p]),
     "cdc_cgc_mid_fwd": (c_i32, [C.POINTER(CgcMidFwdArgs), c_p]),
     "cdc_cgc_mid_bwd": (c_i32, [C.POINTER(CgcMidBwdArgs), c_p]),
+    "cdc_cgc_mid_fits": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "cdc_expert_pair_fwd": (c_i32, [C.POINTER(ExpertPairArgs), c_p]),
     "cdc_gate_pool_bwd": (c_i32, [C.POINTER(PoolBwdArgs), c_p]),
     "cdc_bn_fwd": (c_i32, [C.POINTER(BnFwdArgs), c_p]),

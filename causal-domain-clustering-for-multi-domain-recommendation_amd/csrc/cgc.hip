@@ -655,3 +655,11 @@ extern "C" int cdc_cgc_mid_bwd(const cdc_cgc_mid_bwd_args* a, void* stream) {
     CDC_LAUNCH_CHECK("cgc_mid_bwd");
     return 0;
 }
+
+// Does the fused boundary fit?  1 = both launches' LDS needs are within the 150 KB they may ask for, 0 = not (the caller keeps the
+// three launches per direction: plan.CGCMid.match), < 0 = counts outside the supported range.
+extern "C" int cdc_cgc_mid_fits(int32_t n_exp1, int32_t n_gate1, int32_t n_exp2, int32_t n_gate2) {
+    if (n_exp1 <= 0 || n_exp1 > MID_E || n_exp2 <= 0 || n_exp2 > MID_E || n_gate1 <= 0 || n_gate1 > MID_G || n_gate2 <= 0 || n_gate2 > MID_G)
+        return CDC_E_BADARG;
+    return mid_fwd_lds<128, 64>(n_gate1, n_gate2, n_exp1, n_exp2) <= 150 * 1024 && mid_bwd_lds<128, 64>(n_gate1, n_gate2, n_exp2) <= 150 * 1024 ? 1 : 0;
+}

@@ -1339,7 +1339,7 @@ template <bool FAST, int VEC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) k_lazy_flush(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                                                     int32_t* __restrict__ last, int64_t R, int32_t D, cdc_adam_hp hp,
                                                     const int32_t* __restrict__ step_dev, int32_t step_bias, int32_t period,
-                                                    int32_t own_mod, int32_t own_rem, int32_t mark) {
+                                                    int32_t own_mod, int32_t own_rem, int32_t mark, int64_t win_lo, int64_t win_n) {
     const int target = *step_dev + step_bias;
     // period > 1: this call handles one slice of the table, slice (target mod period) — every row is brought up to date
     // once per `period` steps, a 1/period share of the work in every step instead of a burst
@@ -1350,6 +1350,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
         row_hi = row_lo + rps < R ? row_lo + rps : R;
         if (row_lo >= row_hi) return;
     }
+    // the launcher's row window [win_lo, win_lo + win_n): a launch's work items are counted in 32 bits (below), so a table of more
+    // than ~2^31 items (rows x 16-byte chunks) is flushed window by window
+    if (win_lo > row_lo) row_lo = win_lo;
+    if (win_lo + win_n < row_hi) row_hi = win_lo + win_n;
+    if (row_lo >= row_hi) return;
     const AdamConsts c = make_consts(hp);
     // row-sharded table: only the rows this rank owns (row % own_mod == own_rem) are visited
     const int64_t stride = own_mod > 1 ? own_mod : 1;
@@ -1364,7 +1369,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))
     // its start step are carried across the iteration; its row and element offset are recomputed from the index where they
     // are needed (register budget: 64 VGPRs, so that two background waves sit beside four waves of a 96-VGPR kernel on a SIMD)
     typedef float f4v __attribute__((ext_vector_type(4)));
-    const int32_t itotal = (int32_t)total;                              // (R * chunks < 2^31: checked by the launcher)
+    const int32_t itotal = (int32_t)total;                              // (items of a launch + its grid stride < 2^31: lazy_flush_launch's windows)
     auto row_of = [&](int32_t i) -> int64_t { return first + (int64_t)(i / chunks) * stride; };
     auto fetch = [&](int32_t i, int& from, float (&wv)[VEC], float (&mv)[VEC], float (&vv)[VEC]) __attribute__((always_inline)) {
         const bool in = i < itotal;
@@ -1455,12 +1460,24 @@ static int lazy_flush_launch(float* w, float* m, float* v, int32_t* last, int64_
     hipStream_t st = (hipStream_t)stream;
     const int32_t chunks = vec ? D / 4 : D;
     const int32_t mark = (64 % chunks == 0) ? 1 : 0;             // last[] advanced inside the kernel; else by k_lazy_set_last
-    if (hp.fast_replay) {
-        if (vec) hipLaunchKernelGGL((k_lazy_flush<true, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark);
-        else     hipLaunchKernelGGL((k_lazy_flush<true, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark);
-    } else {
-        if (vec) hipLaunchKernelGGL((k_lazy_flush<false, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark);
-        else     hipLaunchKernelGGL((k_lazy_flush<false, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark);
+    // the kernel counts a launch's work items (rows x chunks) and its grid-stride index in 32 bits (its 64-VGPR budget): rows per
+    // launch are capped so that items + one grid stride stay below 2^31.  A whole-table flush (period <= 1: flush_table,
+    // state_dict, evaluation) of a larger table goes out as several launches over consecutive row windows; a slice launch
+    // (its rows are chosen on the device from the step counter) that large is refused.
+    const int64_t max_items = ((int64_t)1 << 31) - 1 - (int64_t)blocks * 256 - 256;
+    const int64_t win_rows = std::max<int64_t>(1, max_items / chunks);
+    CDC_CHECK_ARG(period <= 1 || rows_call <= win_rows, CDC_E_TOOBIG,
+                  "embed_lazy_flush: a slice of %lld rows x %d chunks exceeds the 2^31 work items of one launch (raise flush_every)",
+                  (long long)rows_call, (int)chunks);
+    for (int64_t lo = 0; lo < R; lo += (period > 1 ? R : win_rows)) {
+        const int64_t n = period > 1 ? R : std::min<int64_t>(win_rows, R - lo);
+        if (hp.fast_replay) {
+            if (vec) hipLaunchKernelGGL((k_lazy_flush<true, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark, lo, n);
+            else     hipLaunchKernelGGL((k_lazy_flush<true, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark, lo, n);
+        } else {
+            if (vec) hipLaunchKernelGGL((k_lazy_flush<false, 4>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark, lo, n);
+            else     hipLaunchKernelGGL((k_lazy_flush<false, 1>), dim3(blocks), dim3(256), 0, st, w, m, v, last, R, D, hp, step_dev, step_bias, period, own_mod, own_rem, mark, lo, n);
+        }
     }
     CDC_LAUNCH_CHECK("embed_lazy_flush");
     if (!mark) {

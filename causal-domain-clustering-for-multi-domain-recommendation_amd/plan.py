@@ -1101,6 +1101,10 @@ class CGCMid:
         for _, sel in list(p1.gates) + list(p2.gates):
             if list(sel) != sorted(set(sel)):
                 return None
+        # the fused launches keep a workgroup's expert rows, pooled vectors and gradients in LDS: more domains than that holds
+        # (e.g. PLE with 6 domains x 2 specific + 2 shared experts: 160 KB) keep the three launches per direction
+        if plan.lib.cdc_cgc_mid_fits(p1.n_expert, len(p1.gates), ne2, ng2) != 1:
+            return None
 
         def src_of(x):
             for i, o in enumerate(p1.outs):

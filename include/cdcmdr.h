@@ -523,6 +523,9 @@ typedef struct {
     cdc_mid_bgate2 g2[CDC_MID_MAX_GATE];
 } cdc_cgc_mid_bwd_args;
 int cdc_cgc_mid_bwd(const cdc_cgc_mid_bwd_args* a, void* stream);
+/* 1 if both fused launches fit their LDS budget (150 KB) for these expert / gate counts, 0 if not (use the three launches per
+ * direction), CDC_E_BADARG for counts outside [1, CDC_MID_MAX_*]. */
+int cdc_cgc_mid_fits(int32_t n_exp1, int32_t n_gate1, int32_t n_exp2, int32_t n_gate2);
 
 /* ------------------------------------------------------------------------------------------
  * Two consecutive BatchNorm-free expert layers as ONE forward launch (csrc/pair.hip; reference: the experts'

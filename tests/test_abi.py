@@ -195,6 +195,16 @@ def test_entry_points_reject_bad_arguments_without_touching_the_device():
     assert lib.cdc_bce_fwd_bwd(None, 1, None, None, None, None, None, 1, 4, 1, 1.0, None) < 0
     assert lib.cdc_eval_metrics(one, one, None, 0, 10, 3, one, one, None, one, 1 << 20, None) < 0      # n_domain > 1 needs the domain column
     assert lib.cdc_shard_bucket(one, one, one, one, one, 64, 3, 99, 8, None) < 0                       # more ranks than supported
+    # a replay SLICE (rows chosen on the device) beyond the 2^31 work items one launch counts is refused (CDC_E_TOOBIG), not wrapped;
+    # a whole-table flush of that size goes out as row windows (tests/test_gpu_configs.py)
+    hp = _lib.AdamHP()
+    hp.step_scalars, hp.n_scalars = 16, 4
+    rc = lib.cdc_embed_lazy_flush(one, one, one, one, 1 << 40, 4, hp, one, 0, 2, 0, 0, None)
+    assert rc == -2 and b"exceeds the 2^31 work items" in lib.cdc_last_error()
+    # the fused PLE level boundary's LDS budget, as plan.CGCMid.match asks it: 3 domains fit, 6 and 7 domains (2 + 2 experts) do not
+    assert lib.cdc_cgc_mid_fits(8, 4, 8, 3) == 1 and lib.cdc_cgc_mid_fits(12, 6, 12, 5) == 1
+    assert lib.cdc_cgc_mid_fits(14, 7, 14, 6) == 0 and lib.cdc_cgc_mid_fits(16, 8, 16, 7) == 0
+    assert lib.cdc_cgc_mid_fits(0, 1, 1, 1) == -1 and lib.cdc_cgc_mid_fits(17, 1, 1, 1) == -1
     with pytest.raises(RuntimeError):
         _lib.check(-1, "probe")
 

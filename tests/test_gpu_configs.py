@@ -179,6 +179,54 @@ def test_c4_full_size_table_properties(cuda):
     assert frac > 0.99, f"only {frac:.3f} of the untouched elements moved by ~3 lr"
 
 
+def test_whole_table_flush_beyond_2_31_work_items(cuda):
+    """The replay kernel counts a launch's work items (rows x 16-byte chunks) in 32 bits.  134 218 728 rows x emb_dim 64 =
+    2^31 + 16 000 items: the whole-table flush (flush_table / state_dict / evaluation) has to go out as consecutive row windows.
+    Every element starts from the same state, so every row must end at the value a small table reaches through the same
+    entry point; a skipped window shows as untouched rows, a wrapped index as a fault or as stale stamps."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    from cdcmdr_amd.model.dcn import DCN
+    from cdcmdr_amd.optim import FusedAdam
+    R, D, Rs, target = (1 << 27) + 1000, 64, 4096, 5
+    free, _ = torch.cuda.mem_get_info()
+    need = 3 * R * D * 4 + R * 4 + (6 << 30)
+    if free < need:
+        pytest.skip(f"needs {need / 2**30:.0f} GiB of device memory, {free / 2**30:.0f} GiB free")
+    assert R * (D // 4) > 2 ** 31
+    with torch.device(cuda):
+        small_model = DCN([16] * 3, 4, 2, (8,), dropout=0.0)
+    opt = FusedAdam(small_model, table_mode="lazy")                     # (its hyper-parameter block and step-scalar tables)
+    lib = L.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    step = torch.full((1,), target, dtype=torch.int32, device=cuda)
+    res = {}
+    for rows in (Rs, R):
+        w = torch.full((rows, D), 0.05, dtype=torch.float32, device=cuda)
+        m = torch.full((rows, D), 1e-7, dtype=torch.float32, device=cuda)
+        v = torch.full((rows, D), 1e-12, dtype=torch.float32, device=cuda)
+        last = torch.zeros(rows, dtype=torch.int32, device=cuda)
+        L.check(lib.cdc_embed_lazy_flush(w.data_ptr(), m.data_ptr(), v.data_ptr(), last.data_ptr(), rows, D, opt._hp(), step.data_ptr(), 0, 0,
+                                         0, 0, st), "flush")
+        torch.cuda.synchronize()
+        if rows == Rs:
+            res = {"w": w[0].clone(), "m": m[0].clone(), "v": v[0].clone()}
+            assert float((w[0] - 0.05).abs().max()) > 1e-3               # five L2-only Adam steps moved it by ~5 lr
+            assert torch.equal(w, res["w"].expand_as(w))
+            continue
+        assert int(last.min()) == target and int(last.max()) == target
+        for name, t in (("w", w), ("m", m), ("v", v)):
+            want = res[name]
+            for lo in range(0, rows, 1 << 23):                           # 8 M rows per comparison
+                blk = t[lo:lo + (1 << 23)]
+                assert bool((blk == want).all()), f"{name}: rows in [{lo}, {lo + blk.shape[0]}) differ from the small table's result"
+        del w, m, v, last
+    # a SLICE launch (rows chosen on the device) of that size is refused, not wrapped
+    one = C.c_void_p(256)
+    rc = lib.cdc_embed_lazy_flush(one, one, one, one, C.c_int64(1 << 40), 4, opt._hp(), step.data_ptr(), 0, 2, 0, 0, st)
+    assert rc == -2 and b"exceeds" in lib.cdc_last_error()
+
+
 def test_c5_star30_bf16_grouped_training_step(cuda):
     """STAR, 30 towers, bf16 contractions, GROUPED mode: one TrainStep(mode='star') on a batch whose rows are partitioned by domain
     into ragged groups — domain 7 is absent (empty group: the tower is skipped and BatchNorm keeps its statistics, star.py:94),
