@@ -304,7 +304,7 @@ def main():
         elapsed_local = timed(ts_local, args.steps)
 
     # ---- roofline of the dominant kernel, HIP events on the launch stream (instrumented eager steps) ----------
-    roof = measure_roofline(args, ts, opt, Xd, yd, gd)
+    roof = measure_roofline(args, ts, opt, Xd, yd, gd, depth, elapsed / args.steps * 1e3)
 
     cpu = None
     if args.cpu_baseline and world == 1 and rank == 0 and sim is None:
@@ -402,11 +402,108 @@ def event_pair_floor_ms(ts, n=64):
     return times[len(times) // 2]
 
 
-def measure_roofline(args, ts, opt, Xd, yd, gd):
-    """Per-launch HIP-event timing of instrumented eager steps, every launch with the chip to itself (the timed region replays the
-    same launches as a graph, where events cannot be placed, with the replay slice in the background; the rocprofv3 tables under
-    profiles/ give the in-step durations).  `roofline` is for the step's dominant kernel; the north-star figures (contractions
-    against the bf16 MFMA peak, gather against the HBM peak) ride along, with the event pair's own latency subtracted."""
+def back_to_back(ts, reps=100):
+    """Every launch of the plan's forward and backward sequences issued `reps` times in a row on the idle chip, ONE event pair around
+    the run: microseconds per launch without an event pair's own latency in it (tools/step_probe.py's method; what
+    profiles/roundN/asymptote.txt lists).  Returns [(name, us, flops)].  The launches are re-runs of the last step's (idempotent
+    up to the BatchNorm running statistics, which are put back afterwards)."""
+    import ctypes as C
+    from cdcmdr_amd import _lib as L
+    plan = ts.plan
+    keep = {k: v.clone() for k, v in ts.model.state_dict().items() if "running_" in k or "num_batches" in k}
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = []
+    try:
+        for fn in list(plan.fwd_steps) + list(plan.bwd_steps):
+            if getattr(fn, "is_comm", False):
+                continue
+            rec = []
+            L.PROFILE = rec
+            fn(st)
+            torch.cuda.synchronize()
+            L.PROFILE = None
+            if not rec:
+                continue
+            name, _, _, fl, _ = rec[0]
+            for _ in range(5):
+                fn(st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                fn(st)
+            e1.record()
+            torch.cuda.synchronize()
+            out.append((name, e0.elapsed_time(e1) * 1e3 / reps, fl))
+    finally:
+        L.PROFILE = None
+        sd = ts.model.state_dict()
+        for k, v in keep.items():
+            sd[k].copy_(v)
+    return out
+
+
+def valu_issue_prices():
+    """ns a SIMD needs per wave instruction (packed fp32, transcendental) at the slice's occupancy, from the newest committed
+    profiles/roundN/valu_issue_probe.txt (tools/valu_issue_probe.hip: chains of one instruction kind on every SIMD, the whole launch
+    timed by events — the shader clock moves with the instruction mix, so the prices are kept in ns, not cycles).  Fallback: the
+    guide's one-wave issue costs at 2.4 GHz."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    if os.path.isdir(root):
+        for rnd in sorted((d for d in os.listdir(root) if d.startswith("round")), reverse=True):
+            path = os.path.join(root, rnd, "valu_issue_probe.txt")
+            if not os.path.exists(path):
+                continue
+            ns = {}
+            for line in open(path):
+                parts = line.split()
+                if len(parts) > 3 and parts[1] == "W=8" and "by the launch's event time" in line:
+                    ns[parts[0]] = float(line.split(";")[1].split("ns")[0])
+            if all(k in ns for k in ("v_pk_fma_f32", "v_pk_mul_f32", "v_sqrt_f32", "v_rcp_f32")):
+                return {"pk_fma": ns["v_pk_fma_f32"], "pk_mul": ns["v_pk_mul_f32"], "sqrt": ns["v_sqrt_f32"], "rcp": ns["v_rcp_f32"],
+                        "source": f"profiles/{rnd}/valu_issue_probe.txt (8 waves per SIMD, ns per wave instruction and SIMD by the launch's event time)"}
+    c = 1.0 / 2.4
+    return {"pk_fma": 8 * c, "pk_mul": 8 * c, "sqrt": 8 * c, "rcp": 8 * c, "source": "MI355X_MICROARCH.md one-wave issue costs at 2.4 GHz (no probe table committed)"}
+
+
+def in_step_figures():
+    """what the newest committed rocprofv3 kernel trace of this command says about one REPLAYED step (profiles/roundN/step_timeline.txt):
+    durations beside the background slice, which no event inside the timed region can give.  Not measured in this run."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    if not os.path.isdir(root):
+        return None
+    for rnd in sorted((d for d in os.listdir(root) if d.startswith("round")), reverse=True):
+        path = os.path.join(root, rnd, "step_timeline.txt")
+        if not os.path.exists(path):
+            continue
+        slice_us = gather_us = None
+        gemm_us, tower_us, n_kernels = 0.0, 0.0, 0
+        for line in open(path):
+            if line.startswith("#"):
+                continue
+            parts = line.split()
+            if len(parts) < 6:
+                continue
+            dur, name = float(parts[4]), " ".join(parts[5:])
+            n_kernels += 1
+            if "k_lazy_flush" in name:
+                slice_us = dur
+            elif "k_gather_fwd" in name:
+                gather_us = dur
+            if any(t in name for t in ("k_g2_", "k_pair_fwd", "k_cgc_mid", "k_tower")):
+                gemm_us += dur
+            if "k_tower" in name:
+                tower_us += dur
+        return {"slice_us": slice_us, "gather_us": gather_us, "contraction_launches_us": gemm_us, "tower_launches_us": tower_us,
+                "kernels_per_step": n_kernels, "source": f"profiles/{rnd}/step_timeline.txt", "measured_in_run": False}
+    return None
+
+
+def measure_roofline(args, ts, opt, Xd, yd, gd, depth, ms_per_step):
+    """`roofline` = the step's dominant kernel (the lazy table's replay slice) from HIP events around every launch of 64 instrumented
+    eager steps, each launch alone on the chip; the north-star figures (contractions against the bf16 MFMA peak, gather against the
+    HBM peak) from back-to-back re-runs of each launch (no event latency in them); `roofline.step` = the whole step against its
+    algorithmic HBM/MFMA time; the in-step figures of the committed kernel trace ride along, marked as not measured here."""
     batches = [(Xd[i], yd[i], gd[i]) for i in range(len(Xd))]
     prof = ts.profile(batches, n_steps=2 + 64, skip=2, overlap=False)      # 64 steps: exactly one period of the lazy table's whole-table flush
     floor_ms = event_pair_floor_ms(ts)
@@ -427,26 +524,30 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
         roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "algorithmic_flops_per_step": d["flops_per_step"], "traffic": traffic}
     elif "lazy_flush" in name:
-        # The replay slice reads and writes each of its elements once and advances it flush_every Adam steps in between (64 replayed
-        # steps per 24 bytes moved): its bound is VALU ISSUE, not HBM.  Per element and step the scaled replay (csrc/common.h
-        # adam_scaled_step_pk) issues 5 plain fp32 operations + v_sqrt_f32 + v_rcp_f32; a wave instruction occupies its SIMD for
-        # 4 cycles (plain) / 8 cycles (transcendental) per 64 lanes (MI355X_MICROARCH.md, instruction issue costs): 36 cycles per 64
-        # element-steps.  peak = 256 CUs x 4 SIMDs x 2.4 GHz x 64 / 36.
-        es = opt.table.numel() * 1.0 / max(opt.own_mod, 1)                  # element-steps per training step (every owned element, one step)
-        peak = 256 * 4 * 2.4e9 * 64 / 36.0 / 1e9
+        # The replay slice reads and writes each of its elements once and advances it up to flush_every Adam steps in between: its bound
+        # is VALU ISSUE, not HBM.  Per element PAIR and step the scaled replay (csrc/common.h adam_scaled_step_pk) issues 4 v_pk_fma_f32,
+        # 1 v_pk_mul_f32, 2 v_sqrt_f32 and 2 v_rcp_f32; a wave instruction covers 64 pairs = 128 element-steps.  The prices are MEASURED
+        # (tools/valu_issue_probe.hip; ns per wave instruction and SIMD with the SIMD kept busy).  Counted are the EXECUTED element-steps:
+        # a row looked up since its slice's last flush replays fewer than flush_every steps (mean_replay_depth).
+        price = valu_issue_prices()
+        ns_per_128 = 4 * price["pk_fma"] + price["pk_mul"] + 2 * price["sqrt"] + 2 * price["rcp"]
+        es_nominal = opt.table.numel() * 1.0 / max(opt.own_mod, 1)          # every owned element, one step per training step
+        share = min(1.0, depth / args.flush_every) if (depth and args.flush_every) else 1.0
+        es = es_nominal * share
+        peak = 256 * 4 * 128 / ns_per_128                                   # G element-steps/s
         achieved = es / (net_ms(d) * 1e-3) / 1e9
         nbytes = d["bytes_per_step"]
         hbm = nbytes / (net_ms(d) * 1e-3) / 1e9 if nbytes else None
         roof = {"bound": "valu", "kernel": name, "achieved": achieved, "peak": peak, "unit": "G element-steps/s", "frac": achieved / peak,
-                "algorithmic_element_steps_per_step": es, "valu_cycles_per_64_element_steps": 36,
+                "algorithmic_element_steps_per_step": es, "nominal_element_steps_per_step": es_nominal, "executed_share": share,
+                "valu_ns_per_128_element_steps_per_simd": ns_per_128, "valu_cycles_per_64_element_steps_at_2p4GHz": ns_per_128 * 2.4 / 2,
+                "valu_prices_ns": {k: v for k, v in price.items() if k != "source"}, "valu_prices_source": price["source"],
                 "hbm": {"achieved_GBps": hbm, "peak_GBps": HBM_PEAK_GBPS, "frac": None if hbm is None else hbm / HBM_PEAK_GBPS,
                         "algorithmic_bytes_per_step": nbytes, "traffic": traffic, "traffic_source": traffic_src,
                         "measured_in_run": False if traffic is not None else None},
                 "traffic": traffic,
-                "note": "VALU-issue bound: element_steps is the nominal R*D per step (rows looked up since their slice's last flush replay "
-                        "fewer); in the timed region this launch runs in the background beside the forward/backward (two waves per SIMD, "
-                        "lowest issue priority) and lasts ~1.8x as long while costing the step ~0.6x of its stand-alone time "
-                        "(profiles/round3/README.md)"}
+                "note": "stand-alone launch (instrumented eager steps).  In the timed region this launch is NOT on the critical path: it runs in "
+                        "the background beside the forward/backward (two waves per SIMD, lowest issue priority) — see in_step and step below"}
     else:
         nbytes = d["bytes_per_step"]
         achieved = nbytes / (net_ms(d) * 1e-3) / 1e9 if nbytes else None
@@ -454,28 +555,46 @@ def measure_roofline(args, ts, opt, Xd, yd, gd):
                 "frac": None if achieved is None else achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": nbytes, "traffic": traffic}
     roof.update({"avg_launch_ms": per_launch_ms, "launches_per_step": d["launches_per_step"],
                  "traffic_source": traffic_src, "traffic_measured_in_run": False if traffic is not None else None,
-                 # what the same event pair reads around a one-element fill launch (~2 us of kernel): the part of avg_launch_ms that is
-                 # the events' own dispatch latency, not the kernel — rocprofv3's per-kernel average has no such term
                  "event_pair_floor_ms": floor_ms, "avg_launch_ms_less_event_floor": max(per_launch_ms - floor_net, 0.0),
                  "kernel_ms_per_step_sum": total, "breakdown_ms_per_step": breakdown, "breakdown_all": breakdown_all,
-                 "timing": "HIP events around every launch of 64 eager steps, each launch alone on the chip"})
-    # the north star's two figures: all contraction launches against the dense bf16 MFMA peak, the gather against the HBM peak
-    gm = [v for k, v in prof.items() if "glinear" in k or "cgc_mid" in k]
+                 "timing": "dominant kernel: HIP events around every launch of 64 eager steps, each launch alone on the chip; "
+                           "contraction / gather figures: the launch re-issued 100 times back to back, one event pair around the run"})
+    # ---- the north star's two figures, from back-to-back re-runs (no event latency inside; = the B = 4096 rows of asymptote.txt)
+    b2b = back_to_back(ts)
+    roof["back_to_back_us"] = {f"{i:02d} {n}": round(us, 2) for i, (n, us, _) in enumerate(b2b)}
+    gm = [(n, us, fl) for n, us, fl in b2b if fl > 0]
     if gm:
-        fl = sum(v["flops_per_step"] for v in gm)
-        ms = sum(net_ms(v) for v in gm)
-        roof["all_gemm_tflops"] = fl / (ms * 1e-3) / 1e12
-        roof["all_gemm_ms_per_step"] = ms
+        fl = sum(f for _, _, f in gm)
+        us = sum(u for _, u, _ in gm)
+        roof["all_gemm_tflops"] = fl / (us * 1e-6) / 1e12
+        roof["all_gemm_ms_per_step"] = us * 1e-3
+        roof["all_gemm_flops_per_step"] = fl
         roof["gemm_frac_of_mfma_peak"] = roof["all_gemm_tflops"] / MFMA_BF16_PEAK_TFLOPS
-        big = [v for k, v in prof.items() if "glinear" in k]
+        big = [(u, f) for n, u, f in gm if "glinear" in n]
         if big:
-            roof["grouped_linear_tflops"] = sum(v["flops_per_step"] for v in big) / (sum(net_ms(v) for v in big) * 1e-3) / 1e12
-    g = prof.get("cdc_embed_gather_fwd")
+            roof["grouped_linear_tflops"] = sum(f for _, f in big) / (sum(u for u, _ in big) * 1e-6) / 1e12
+    B, F, D = ts.B, ts.emb.F, ts.emb.D
+    gb = B * F * (D * 4 + 4 + D * 4)                                        # row read + id + fp32 row written (the bf16 shadow not counted)
+    g = [us for n, us, _ in b2b if n == "cdc_embed_gather_fwd"]
     if g:
-        B, F, D = ts.B, ts.emb.F, ts.emb.D
-        gb = B * F * (D * 4 + 4 + D * 4)                                    # row read + id + fp32 row written (the bf16 shadow not counted)
-        roof["gather_GBps"] = gb / (net_ms(g) * 1e-3) / 1e9
+        roof["gather_GBps"] = gb / (g[0] * 1e-6) / 1e9
         roof["gather_frac_of_hbm_peak"] = roof["gather_GBps"] / HBM_PEAK_GBPS
+    # ---- the step as a whole against its algorithmic HBM / MFMA time
+    flops = roof.get("all_gemm_flops_per_step", 0.0)
+    n_dense = sum(p.numel() for p in ts.model.parameters() if p is not opt.table)
+    touched = B * F * 7 * D * 4                                            # w, m, v read + written and the row gradient, per looked-up row (upper bound: all distinct)
+    alg_us = flops / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e6 + (gb + touched + 28.0 * n_dense) / (HBM_PEAK_GBPS * 1e9) * 1e6
+    roof["step"] = {"algorithmic_us": alg_us, "ms_per_step": ms_per_step, "frac": alg_us * 1e-3 / ms_per_step,
+                    "terms": {"contraction_flops": flops, "gather_bytes": gb, "touched_row_bytes": touched, "dense_param_bytes": 28.0 * n_dense},
+                    "note": "sum of (flops / 2.5 PFLOP/s) and (bytes / 8 TB/s) over the step's algorithmic work, divided by the timed ms_per_step; "
+                            "the replay arithmetic of the lazy table (VALU work, hidden in the background) is not in the numerator"}
+    ins = in_step_figures()
+    if ins:
+        if ins.get("contraction_launches_us") and flops:
+            ins["gemm_frac_in_step"] = flops / (ins["contraction_launches_us"] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS
+        if ins.get("gather_us"):
+            ins["gather_frac_in_step"] = gb / (ins["gather_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+        roof["in_step"] = ins
     return roof
 
 
