@@ -377,8 +377,8 @@ _SIGNATURES = {
     "cdc_sigmoid_gate_bwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i32, c_p, c_i64, c_i32, c_i64, c_i32, c_f, c_f, c_f, c_p]),
     "cdc_group_select_fwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
     "cdc_group_select_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p]),
-    "cdc_stage_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p]),
-    "cdc_stage_batch_next": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p, c_i32, c_p]),
+    "cdc_stage_batch": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p]),
+    "cdc_stage_batch_next": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p, c_i32, c_p, c_p, c_p]),
     "cdc_fm_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
     "cdc_fm_bwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_bce_mean_fwd_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f, c_p]),

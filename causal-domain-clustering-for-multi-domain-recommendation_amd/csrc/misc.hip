@@ -208,10 +208,13 @@ extern "C" int cdc_add_n(const cdc_add_n_args* a, void* stream) {
 // NULL) into the buffers a replayed launch sequence reads (run.py:476-479 hands the step exactly these three tensors)
 __global__ void __launch_bounds__(256) k_stage_batch(const int32_t* __restrict__ ids, const int16_t* __restrict__ y,
                                                      const int64_t* __restrict__ group, int32_t* __restrict__ ids_dst,
-                                                     int16_t* __restrict__ y_dst, int64_t* __restrict__ group_dst, int64_t B, int32_t F) {
+                                                     int16_t* __restrict__ y_dst, int64_t* __restrict__ group_dst, int64_t B, int32_t F,
+                                                     const int32_t* __restrict__ field_dims, int32_t* __restrict__ alias_flag) {
     const int64_t n = B * F;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        ids_dst[i] = ids[i];
+        const int32_t id = ids[i];
+        ids_dst[i] = id;
+        if (field_dims && (id < 0 || id >= field_dims[i % F])) atomicMax(alias_flag, (int32_t)(i < 0x7ffffffe ? i + 1 : 0x7fffffff));
         if (i < B) {
             y_dst[i] = y[i];
             if (group) group_dst[i] = group[i];
@@ -219,10 +222,12 @@ __global__ void __launch_bounds__(256) k_stage_batch(const int32_t* __restrict__
     }
 }
 extern "C" int cdc_stage_batch(const int32_t* ids, const int16_t* y, const int64_t* group, int32_t* ids_dst, int16_t* y_dst,
-                               int64_t* group_dst, int64_t B, int32_t F, void* stream) {
-    CDC_CHECK_ARG(ids && y && ids_dst && y_dst && B > 0 && F > 0 && (!group || group_dst), CDC_E_BADARG, "stage_batch: bad argument");
+                               int64_t* group_dst, int64_t B, int32_t F, const int32_t* field_dims, int32_t* alias_flag, void* stream) {
+    CDC_CHECK_ARG(ids && y && ids_dst && y_dst && B > 0 && F > 0 && (!group || group_dst) && (!field_dims || alias_flag), CDC_E_BADARG,
+                  "stage_batch: bad argument");
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(B * F, 256), 2048);
-    hipLaunchKernelGGL(k_stage_batch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, y, group, ids_dst, y_dst, group_dst, B, F);
+    hipLaunchKernelGGL(k_stage_batch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, y, group, ids_dst, y_dst, group_dst, B, F,
+                       field_dims, alias_flag);
     CDC_LAUNCH_CHECK("stage_batch");
     return 0;
 }
@@ -232,14 +237,17 @@ __global__ void __launch_bounds__(256) k_stage_batch_next(const int32_t* __restr
                                                           const int64_t* __restrict__ group, int32_t* __restrict__ ids_dst,
                                                           int16_t* __restrict__ y_dst, int64_t* __restrict__ group_dst, int64_t B, int32_t F,
                                                           const int32_t* __restrict__ next_ids, int32_t* __restrict__ next_dst,
-                                                          int32_t* step_dev, double* acc, int32_t n_acc) {
+                                                          int32_t* step_dev, double* acc, int32_t n_acc,
+                                                          const int32_t* __restrict__ field_dims, int32_t* __restrict__ alias_flag) {
     if (blockIdx.x == 0 && step_dev) {
         if (threadIdx.x == 0) *step_dev += 1;
         if ((int)threadIdx.x < n_acc) acc[threadIdx.x] = 0.0;
     }
     const int64_t n = B * F;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        ids_dst[i] = ids[i];
+        const int32_t id = ids[i];
+        ids_dst[i] = id;
+        if (field_dims && (id < 0 || id >= field_dims[i % F])) atomicMax(alias_flag, (int32_t)(i < 0x7ffffffe ? i + 1 : 0x7fffffff));
         if (next_ids) next_dst[i] = next_ids[i];
         if (i < B) {
             y_dst[i] = y[i];
@@ -249,13 +257,14 @@ __global__ void __launch_bounds__(256) k_stage_batch_next(const int32_t* __restr
 }
 extern "C" int cdc_stage_batch_next(const int32_t* ids, const int16_t* y, const int64_t* group, int32_t* ids_dst, int16_t* y_dst,
                                     int64_t* group_dst, int64_t B, int32_t F, const int32_t* next_ids, int32_t* next_dst,
-                                    int32_t* step_dev, double* accumulators, int32_t n_acc, void* stream) {
-    CDC_CHECK_ARG(ids && y && ids_dst && y_dst && B > 0 && F > 0 && (!group || group_dst) && (!next_ids || next_dst), CDC_E_BADARG,
-                  "stage_batch_next: bad argument");
+                                    int32_t* step_dev, double* accumulators, int32_t n_acc, const int32_t* field_dims, int32_t* alias_flag,
+                                    void* stream) {
+    CDC_CHECK_ARG(ids && y && ids_dst && y_dst && B > 0 && F > 0 && (!group || group_dst) && (!next_ids || next_dst) &&
+                      (!field_dims || alias_flag), CDC_E_BADARG, "stage_batch_next: bad argument");
     CDC_CHECK_ARG(n_acc >= 0 && n_acc <= 64 && (n_acc == 0 || (accumulators && step_dev)), CDC_E_BADARG, "stage_batch_next: bad accumulators");
     int blocks = (int)std::min<int64_t>(cdc_ceil_div(B * F, 256), 2048);
     hipLaunchKernelGGL(k_stage_batch_next, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, y, group, ids_dst, y_dst, group_dst, B, F,
-                       next_ids, next_dst, step_dev, accumulators, n_acc);
+                       next_ids, next_dst, step_dev, accumulators, n_acc, field_dims, alias_flag);
     CDC_LAUNCH_CHECK("stage_batch_next");
     return 0;
 }

@@ -634,10 +634,15 @@ __device__ __forceinline__ void tw_block_sums(const float* u, const float* w, in
 struct TwWideRound { f32x4_t xv[TW_WNB][2]; int lr[TW_WNB]; };
 __device__ __forceinline__ void tw_wide_load(TwWideRound& R, const float* wide_x, int64_t ld_wide, const int* own, const float* dsum_s, int n_own,
                                              int i0, int row0, int K4, int lane) {
+    if (i0 >= n_own) {                                                   // (uniform) nothing for this wave: no list entry to read, no row to fetch
+#pragma unroll
+        for (int b = 0; b < TW_WNB; ++b) { R.lr[b] = 0; R.xv[b][0] = R.xv[b][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < TW_WNB; ++b) {
         const int i = i0 + 4 * b;
-        const int lr = own[i < n_own ? i : (i0 < n_own ? i0 : 0)];
+        const int lr = own[i < n_own ? i : i0];
         R.lr[b] = lr;
 #pragma unroll
         for (int q = 0; q < 2; ++q)

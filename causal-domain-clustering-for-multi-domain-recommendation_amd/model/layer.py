@@ -203,7 +203,7 @@ def mlp_stack(plan, mlps, inputs, extra_groups=(), final_addends=(), final_sigmo
         # made it a second round: 28.9 us against 13.6 us for the second layer's launch, which has 256 slots to spare.  So with
         # two or more layers the gates ride in the LAST layer's forward launch; their grad-input stays with the first layer's
         # (further reduction segments of the same output: adopt_bwd_x below).
-        gate_layer = depth - 1 if (depth >= 2 and plan.use_g2 and os.environ.get("CDC_GATES_LATE", "1") != "0") else 0
+        gate_layer = depth - 1 if (depth >= 2 and plan.use_g2) else 0
         if j == gate_layer and extra_groups:
             for g in extra_groups:
                 g = dict(g)
@@ -464,7 +464,7 @@ class BaseModel(HipModule):
         head_cols = sum(t.out_linear.weight.numel() + 1 for t in self.towers if t.out_linear is not None)
         head_cols += 0 if wide_in is None else wide_in.cols + 1
         fused = (wide_in is not None and n <= P.L.HEAD_MAX_TOWERS and len(other_outs) <= 2 and head_cols <= 2048 and
-                 all(t.out_linear is not None for t in self.towers) and os.environ.get("CDC_FUSED_HEAD", "1") != "0")
+                 all(t.out_linear is not None for t in self.towers))
         if wide_in is not None and not fused:
             other_outs = [self.linear.describe(plan, wide_in)] + list(other_outs)
         if fused:

@@ -83,7 +83,7 @@ class FusedAdam:
         self._k1 = self._k2 = 0.0
         self.replay_tab = None
         c = float(torch.tensor(2.0 * f32(self.l2_table) + self._wd, dtype=torch.float64).to(torch.float32))
-        if self.fast_replay and c > 0.0 and os.environ.get("CDC_SCALED_REPLAY", "1") != "0":
+        if self.fast_replay and c > 0.0:
             self._k1, self._k2 = f32(self._lerp_w * c), f32(self._omb2 * c * c)
             if self._k1 > 0.0 and self._k2 > 0.0:
                 t64 = tab.double()
@@ -265,16 +265,10 @@ class FusedAdam:
                      (ws["side"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(), w, m, v, B, F, D), s)
         else:
             ws = self._workspace(B, F, D, tag)   # rows were sorted by table_catchup of this step
-            if os.environ.get("CDC_FUSE_ROW_UPDATE", "1") != "0":
-                # per-row gradient sums and the rows' Adam step in one launch
-                L.launch("cdc_embed_segsum_lazy_update", self.lib.cdc_embed_segsum_lazy_update,
-                         (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["uniq"].data_ptr(),
-                          w, m, v, self.table_last.data_ptr(), hp, self.step_dev.data_ptr(), B, F, D, 1 if short_segments else 0), s)
-                return
-            self._segment_sum(ws, d_out, B, F, D, s, short=short_segments)
-            L.launch("cdc_embed_lazy_update", self.lib.cdc_embed_lazy_update,
-                     (ws["rowgrad"].data_ptr(), ws["uniq"].data_ptr(), ws["cnt"].data_ptr(),
-                      w, m, v, self.table_last.data_ptr(), hp, self.step_dev.data_ptr(), None, 0, B, F, D), s)
+            # per-row gradient sums and the rows' Adam step in one launch
+            L.launch("cdc_embed_segsum_lazy_update", self.lib.cdc_embed_segsum_lazy_update,
+                     (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["uniq"].data_ptr(),
+                      w, m, v, self.table_last.data_ptr(), hp, self.step_dev.data_ptr(), B, F, D, 1 if short_segments else 0), s)
 
     def _segment_sum(self, ws, d_out, B, F, D, s, short=False):
         """short: every segment is known to hold only a few entries (an owner's merged row lists) — no sorted copy"""
@@ -303,6 +297,14 @@ class FusedAdam:
         left unreduced — the launch adds them while it reads (address of the gradient tensor -> (first slab, stride, count))."""
         slabs = slabs or {}
         sig = tuple((k, g.data_ptr(), slabs.get(g.data_ptr())) for k, g in param_grads.items())
+        # one argument set per gradient layout (= per plan stepping this optimiser: a training step and its sibling for the ragged
+        # batch alternate), ALL kept alive: a captured graph holds the address of the device-resident descriptor table it was
+        # captured with (round 3 kept only the last one: a sibling's step freed the table the main step's graphs point to)
+        cache = self.__dict__.setdefault("_dense_cache", {})
+        hit = cache.get(sig)
+        if hit is not None:
+            self._dense_args, self._dense_table = hit
+            self._dense_sig = sig
         if self._dense_sig != sig:
             items = []
             for k, g in param_grads.items():
@@ -315,7 +317,7 @@ class FusedAdam:
                     self.state[k] = st
                 items.append((p, g, st))
             self._dense_table = None
-            if len(items) > L.MAX_TENSORS and os.environ.get("CDC_ADAM_TABLE", "1") != "0":
+            if len(items) > L.MAX_TENSORS:
                 # more tensors than one kernel-argument block holds: ONE launch whose descriptors and workgroup map are device arrays
                 tab = (L.AdamTensor * len(items))()
                 wg_t, wg_c = [], []
@@ -363,6 +365,7 @@ class FusedAdam:
                         T.slabs, T.slab_stride, T.n_slabs = None, 0, 0
                 args.append(a)
             self._dense_args, self._dense_sig = args, sig
+            cache[sig] = (args, self._dense_table)
         s = self._stream()
         if getattr(self, "_dense_table", None) is not None:
             hdr, tab, wg_t, wg_c, n_wg = self._dense_table
@@ -434,6 +437,7 @@ class FusedAdam:
                 else:
                     self.state[id(p)] = (st["exp_avg"].to(self.device).clone(), st["exp_avg_sq"].to(self.device).clone())
                     self._dense_sig = None
+                    self.__dict__.pop("_dense_cache", None)
         if self.table_last is not None:
             self.table_last.fill_(int(sd["step"]))
         self.table_reg_ready = False

@@ -192,7 +192,7 @@ class Plan:
         # the dense Adam launch adds them while it reads the gradient (cdc_adam_tensor.slabs): two launches and a round trip of
         # the gradients through memory less per step.  grad_slabs: address of a parameter gradient -> (first slab, stride, count);
         # the gradient tensors of those parameters are NOT written by backward()
-        self.defer_dw_reduce = bool(defer_dw_reduce) and os.environ.get("CDC_DW_DEFER", "1") != "0"
+        self.defer_dw_reduce = bool(defer_dw_reduce)
         self.grad_slabs = {}
         self.finalized = False
         self.loss_inputs = None
@@ -298,10 +298,9 @@ class Plan:
         # narrow outputs (N <= 64: gates, the last expert level, towers) go to launches of their own: the grad-weight kernel then
         # uses 64x64 tiles for them instead of padding each to 128 rows (a gate with 4 outputs filled 3 % of its tiles).  The
         # order inside a class is kept (a group that accumulates follows its base; both have the same N)
-        if os.environ.get("CDC_DW_CLASSES", "1") != "0":
-            groups = ([g for g in groups if g.get("dzh") is not None and g["N"] > 64] +
-                      [g for g in groups if g.get("dzh") is not None and g["N"] <= 64] +
-                      [g for g in groups if g.get("dzh") is None])
+        groups = ([g for g in groups if g.get("dzh") is not None and g["N"] > 64] +
+                  [g for g in groups if g.get("dzh") is not None and g["N"] <= 64] +
+                  [g for g in groups if g.get("dzh") is None])
         launches, cur = [], []
         narrow = lambda g: g.get("dzh") is not None and g["N"] <= 64      # noqa: E731
         for g in groups:
@@ -326,7 +325,7 @@ class Plan:
                 # four 64-row slabs per workgroup
                 T = 64 if all(g["N"] <= 64 for g in chunk) else 128
                 tiles = sum(math.ceil(g["N"] / T) * math.ceil(g["K"] / T) for g in chunk)
-                S = max(1, min(int(os.environ.get("CDC_DW_BLOCKS", "512")) // max(tiles, 1), max(Mmax // 256, 1), 32))
+                S = max(1, min(512 // max(tiles, 1), max(Mmax // 256, 1), 32))
                 if self.defer_dw_reduce:                   # the Adam launch reads the slabs in rounds of eight (csrc/rowops.hip)
                     S = min(S, 8)
             else:
@@ -533,8 +532,7 @@ class Plan:
             for a in self._gemm_ws_users:
                 a.workspace = self._gemm_ws.data_ptr()
         pair = None
-        if (len(dw) == 2 and all(id(a) in own or a.split_k <= 1 for a, _ in dw) and self.defer_dw_reduce and
-                os.environ.get("CDC_DW_PAIR", "1") != "0"):
+        if len(dw) == 2 and all(id(a) in own or a.split_k <= 1 for a, _ in dw) and self.defer_dw_reduce:
             (aw, _), (an, _) = dw
             shad = lambda a: all(a.g[i].dzh and a.g[i].xh for i in range(a.n_groups))      # noqa: E731
             if shad(aw) and shad(an) and any(aw.g[i].N > 64 for i in range(aw.n_groups)) and all(an.g[i].N <= 64 for i in range(an.n_groups)):
@@ -692,7 +690,7 @@ class GLinear:
             for g in groups:
                 plan.want_shadow(g["x"])                  # forward and grad-weight read x through its shadow
                 plan.want_shadow(g["y"].grad)             # grad-input and grad-weight read dZ through its shadow
-                if g.get("half_only") and os.environ.get("CDC_HALF_ONLY", "1") != "0":
+                if g.get("half_only"):
                     plan.want_shadow(g["y"])
                     plan.make_half_only(g["y"])
         # grad-weight split-K: enough (tile, row-slice) workgroups to fill 256 CUs several times over
@@ -911,8 +909,7 @@ class GLinear:
                     dz = g["y"].grad
                     S.dz, S.lddz = dz.ptr, dz.ld
                     S.w, S.ldw = g["w"].data_ptr(), g["w"].shape[1]
-                    half = (plan.prec == L.PREC_BF16 and g["w"].shape[0] % 8 == 0 and dz.ptr % 16 == 0 and dz.ld % 4 == 0 and
-                            os.environ.get("CDC_WT_BF16", "1") != "0")
+                    half = plan.prec == L.PREC_BF16 and g["w"].shape[0] % 8 == 0 and dz.ptr % 16 == 0 and dz.ld % 4 == 0
                     wt = plan.wt_of(g["w"], half=half)
                     S.wt, S.ldwt = wt.data_ptr(), g["w"].shape[0]
                     S.wt_bf16 = 1 if half else 0
@@ -1075,6 +1072,7 @@ class CGCMid:
     both expert levels is written as bf16 alone."""
 
     H1, H2 = 128, 64                      # the widths csrc/cgc.hip is instantiated for (config.py:39-42: ((256,128),(64,)))
+    enabled = True                        # tests set this to False to build the three launches per direction at a matching shape
     MAX_B = 8192                          # batch rows up to which the fused boundary beats the three launches (see match)
 
     @staticmethod
@@ -1257,7 +1255,7 @@ class CGCMid:
 def fuse_cgc_mid(plan):
     """Replaces every (GatePool, GLinear, GatePool) run of plan.ops that is a PLE level boundary of the instantiated shape by ONE
     CGCMid op.  Called by the model that KNOWS the pooled level-k vectors have no other reader (model/ple.py: ple_inputs)."""
-    if os.environ.get("CDC_CGC_MID", "1") == "0":
+    if not CGCMid.enabled:
         return 0
     n = 0
     i = 0
@@ -1277,6 +1275,7 @@ class ExpertPair:
     the forward is bit-identical to their two launches, the backward IS theirs."""
 
     H1, H2 = 256, 128                     # the widths csrc/pair.hip is instantiated for (config.py:39-42: ((256,128),(64,)))
+    enabled = True                        # tests set this to False to build the two launches at a matching shape
 
     @classmethod
     def match(cls, plan, la, lb):
@@ -1363,8 +1362,8 @@ class ExpertPair:
 
 def fuse_expert_pair(plan):
     """Replaces every (GLinear, GLinear) run of plan.ops that is the two layers of a level's experts in the instantiated shape by ONE
-    ExpertPair op (env CDC_PAIR=0: leave the two launches)."""
-    if os.environ.get("CDC_PAIR", "1") == "0":
+    ExpertPair op."""
+    if not ExpertPair.enabled:
         return 0
     n = 0
     i = 0
@@ -1429,8 +1428,7 @@ class BatchNorm:
                 s["_lin_g2"] = bool(prod is not None and getattr(prod["op"], "g2", False) and prod["G"].act_cols == 0)
                 # the caller vouches (seg["half_only"]) that y is read by bf16 contractions only — and one did ask for the shadow:
                 # y then exists as bf16 alone (its sign is the relu/dropout mask of the backward)
-                if (s.get("half_only") and plan.use_g2 and plan.shadow_wanted(s["y"]) and self.row_offsets is None and
-                        os.environ.get("CDC_HALF_ONLY", "1") != "0"):
+                if s.get("half_only") and plan.use_g2 and plan.shadow_wanted(s["y"]) and self.row_offsets is None:
                     plan.make_value_half_only(s["y"])
                     S.y = None
                 S.gamma, S.beta = s["gamma"].data_ptr(), s["beta"].data_ptr()
@@ -1469,7 +1467,7 @@ class BatchNorm:
         BatchNorm launch in between — the partial-sum workspace is shared), those launches' epilogues write the partial
         sums and this launch skips its statistics pass (one read of the activations less per BatchNorm)."""
         a.stats_ready = 0
-        if not plan.training or self.row_offsets is not None or os.environ.get("CDC_BN_FUSE", "1") == "0":
+        if not plan.training or self.row_offsets is not None:
             return
         prods = []
         for s in chunk:
@@ -1539,8 +1537,7 @@ class BatchNorm:
                         S.dxh, S.lddxh = plan.shadow_view(xg)
                         plan.mark_shadow(xg)
                         # x is the output of a bf16 linear launch whose backward reads dZ through the shadow only
-                        if (s.get("_lin_g2") and not S.accumulate_dx and self.row_offsets is None and
-                                os.environ.get("CDC_HALF_ONLY", "1") != "0"):
+                        if s.get("_lin_g2") and not S.accumulate_dx and self.row_offsets is None:
                             plan.make_grad_half_only(s["x"])
                             S.dx = None
                 S.gamma = s["gamma"].data_ptr()

@@ -30,12 +30,17 @@ class TrainStep:
        leaves the model in eval() (run.py:550-551 sets it, nothing sets it back before the training that follows)."""
 
     def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None, sync_bn=True,
-                 table_dist=None, shard_slack=1.5, train_mode=True):
+                 table_dist=None, shard_slack=1.5, train_mode=True, overlap=True, overlap_waves=2, sort_ahead=True, fuse_gather=False,
+                 defer_dw_reduce=None):
         """sync_bn (data parallel only): BatchNorm statistics over the GLOBAL batch, as the reference's single process
         computes them — two small all-reduces per BatchNorm launch; False = per-rank statistics.
         table_dist (data parallel only): "sharded" (row r owned by rank r % world; default with the lazy table optimiser)
         or "replicated" (every rank applies the global batch's table update).  shard_slack: capacity of the per-owner,
-        per-field row lists as a multiple of the even share B/world (an overflow raises in check_ids())."""
+        per-field row lists as a multiple of the even share B/world (an overflow raises in check_ids()).
+        overlap / overlap_waves / sort_ahead / fuse_gather (single GPU, lazy table; for tests and A/B runs — the defaults are what is
+        measured and shipped): the replay slice in the background on a second chain (waves per SIMD of its capped grid), the next
+        batch's row sort on that chain (step(..., next_X=)), the catch-up launch that also writes the gathered embeddings (slower:
+        profiles/round3/README.md section 3)."""
         self.model, self.opt, self.B, self.mode = model, optimizer, int(batch_size), mode
         self.lib = L.load()
         self.dist = dist
@@ -46,6 +51,11 @@ class TrainStep:
         dev = optimizer.device
         self.device = dev
         self.train_mode = bool(train_mode)
+        self._overlap_ok, self._overlap_waves = bool(overlap), int(overlap_waves)
+        self._sort_ahead_wanted, self._fuse_gather_wanted = sort_ahead, bool(fuse_gather)
+        # split-K slabs of the batched grad-weight launches summed by the dense Adam launch (single GPU; under data parallelism the
+        # reduced gradient is what is all-reduced)
+        self._defer_dw = (not self.dp_on) if defer_dw_reduce is None else (bool(defer_dw_reduce) and not self.dp_on)
         assert mode in ("multi", "single", "mean", "star", "single_group")
         # the plan shares the optimiser's step counter (dropout stream) and its flat gradient arena
         self.holder = self._build_plan()
@@ -61,6 +71,10 @@ class TrainStep:
             self.order = self.holder.extra_outputs[0]             # row order after the partition (ascending group)
             self.y_perm = torch.zeros(self.B, dtype=torch.int16, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        # ids are checked against their FIELD's vocabulary while a batch is staged (an id past it that still lies inside the table
+        # aliases another field's row: check_ids reports it)
+        self.field_dims_dev = torch.tensor([int(d) for d in model.feature_dims], dtype=torch.int32, device=dev)
+        self.alias = torch.zeros(1, dtype=torch.int32, device=dev)
         # the step's sum(l2*w^2), formed inside the launch sequence; lazy table: the optimiser's accumulator itself (see _reg)
         self.reg = self.opt.reg_sum[0] if self.opt.table_mode == "lazy" else torch.zeros((), dtype=torch.float64, device=dev)
         self.use_graph = use_graph
@@ -119,7 +133,7 @@ class TrainStep:
             plan = P.Plan(dev, B, precision=model.precision, training=self.train_mode,
                           dropout=float(getattr(model, "dropout_p", 0.0)) if self.train_mode else 0.0,
                           seed=int(getattr(model, "seed", 0)), step_dev=opt.step_dev, grad_arena=opt.grad_arena,
-                          dist=self.dist if self.sync_bn else None, defer_dw_reduce=not self.dp_on)
+                          dist=self.dist if self.sync_bn else None, defer_dw_reduce=self._defer_dw)
             emb = model.embedding.describe(plan)
             outs, ins, extra = model.describe(plan, emb, grouped=True) if self.mode == "star" else model.describe(plan, emb)
             plan.finalize(outs)
@@ -129,7 +143,7 @@ class TrainStep:
         model.train(self.train_mode)                 # the ops read module.training while describing themselves
         try:
             return model._cache().get(model, ("train_step", id(opt), self.train_mode, self.mode == "star",
-                                               bool(self.sync_bn and self.dp_on), bool(self.dp_on)), B, build)
+                                               bool(self.sync_bn and self.dp_on), bool(self.dp_on), self._defer_dw), B, build)
         finally:
             model.train(was)
 
@@ -158,8 +172,7 @@ class TrainStep:
         if head is False:
             import os
             head = self._head = self._find_head()
-            self._fuse_bce = (head is not None and self.mode in ("multi", "single", "single_group") and
-                              os.environ.get("CDC_FUSE_BCE", "1") != "0")
+            self._fuse_bce = head is not None and self.mode in ("multi", "single", "single_group")
             if self._fuse_bce:
                 self._bce_partial = torch.zeros(L.MAX_GROUPS * L.ROWDOT_PARTS, dtype=torch.float64, device=self.device)
         if head is not None:
@@ -197,7 +210,7 @@ class TrainStep:
             # off by default: measured at C2 (profiles/round2/README.md) the fused launch takes 48 us against 28.5 + 7.2 us for
             # catch-up + gather — the wave that owns the domain column's three rows writes ~B positions on its own while the rest
             # of the chip has finished; it wins only where no row is looked up by more than a few samples
-            hit = (D % 4 == 0 and 64 % (D // 4) == 0 and os.environ.get("CDC_FUSE_GATHER", "0") == "1")
+            hit = D % 4 == 0 and 64 % (D // 4) == 0 and self._fuse_gather_wanted
             self._fuse_gather_ok = hit
             self._fwd_after_gather = [s_ for s_ in self.plan.fwd_steps if s_ is not self.emb.fwd_step]
         return hit
@@ -272,10 +285,10 @@ class TrainStep:
     def _sort_ahead(self):
         """Single GPU, lazy table, slice in the background: the sort + dedupe of batch t+1's rows (30 us of three dependent launches
         that read nothing but the ids) goes out on the side chain of step t, behind the slice, when the caller names the next batch
-        (step(..., next_X=)); step t+1 then starts at the catch-up.  CDC_SORT_AHEAD=0: every step sorts its own batch first."""
+        (step(..., next_X=)); step t+1 then starts at the catch-up.  TrainStep(sort_ahead=False): every step sorts its own batch first."""
         if getattr(self, "_ahead_ok", None) is None:
             self._ahead_ok = (not self.dp_on and self.opt.table_mode == "lazy" and self._overlap() and not self._fuse_gather() and
-                              os.environ.get("CDC_SORT_AHEAD", "1") != "0")
+                              bool(self._sort_ahead_wanted))
             if self._ahead_ok:
                 self.ids_next = torch.zeros_like(self.emb.ids)
                 self._parity, self._sorted_for, self._graphs = 0, None, {}
@@ -300,30 +313,22 @@ class TrainStep:
         # grad-weight launches and the dense Adam) 0.420 / 0.424 — two more cross-queue edges cost more than the 24 us they free;
         # main chain captured FIRST behind the catch-up (so that it stays on the origin queue and the side chain takes the
         # cross-queue edge): the replayed graph then starts the slice 150 us late, 0.476
-        early = os.environ.get("CDC_EARLY_FORK", "1") != "0"
-        tail_side = os.environ.get("CDC_TABLE_STEP_SIDE", "0") == "1"
         st = C.c_void_p(main.cuda_stream)
-        if not early:
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
             if not have:
                 opt.begin_step_sort(emb.ids, emb.offsets, B, F, D, tag=cur, begin=False)
             opt.catchup_sorted(B, F, D, tag=cur)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            if early:
-                if not have:
-                    opt.begin_step_sort(emb.ids, emb.offsets, B, F, D, tag=cur, begin=False)
-                opt.catchup_sorted(B, F, D, tag=cur)
-                rows_ready = torch.cuda.Event()
-                rows_ready.record(side)
+            rows_ready = torch.cuda.Event()
+            rows_ready.record(side)
             opt.flush_slice(background_waves=self._overlap_waves)
             if prefetch:          # behind the slice (ahead of it the sort delays the whole side chain into the backward: 0.401 -> 0.443 ms;
                                   # held back by an event until the backward chain has run: 0.408 -> 0.427)
                 opt.begin_step_sort(self.ids_next, emb.offsets, B, F, D, tag=nxt, begin=False)
-        nws = getattr(plan, "n_wshadow_steps", 0) if early else 0
+        nws = getattr(plan, "n_wshadow_steps", 0)
         for fn in plan.fwd_steps[:nws]:
             fn(st)
-        if early:
-            main.wait_event(rows_ready)
+        main.wait_event(rows_ready)
         for fn in plan.fwd_steps[nws:]:
             fn(st)
         self._bce()
@@ -331,18 +336,11 @@ class TrainStep:
         for fn in plan.bwd_steps:
             if id(fn) not in late:
                 fn(st)
-        if tail_side:
-            grad_ready = torch.cuda.Event()
-            grad_ready.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(grad_ready)
-                opt.table_step(emb.idx, emb.out.grad.root, B, F, D, tag=cur)
         for fn in plan.deferred_dw_steps:
             fn(st)
         opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
         main.wait_stream(side)
-        if not tail_side:
-            opt.table_step(emb.idx, emb.out.grad.root, B, F, D, tag=cur)
+        opt.table_step(emb.idx, emb.out.grad.root, B, F, D, tag=cur)
         self._reg()
 
     def _step_ahead(self, X, nx):
@@ -370,13 +368,10 @@ class TrainStep:
             self._sorted_for = None
 
     def _overlap(self):
-        """The replay slice of the lazy table on a second stream beside the forward/backward (single GPU).  CDC_OVERLAP=0 puts it
-        back on the main chain, CDC_OVERLAP_WAVES sets the slice's waves per SIMD.  Measured at C2 (profiles/round3/README.md):
+        """The replay slice of the lazy table on a second stream beside the forward/backward (single GPU).  TrainStep(overlap=False)
+        puts it back on the main chain, overlap_waves sets the slice's waves per SIMD.  Measured at C2 (profiles/round3/README.md):
         serial 0.550 ms/step; side by side with the full grid 0.596 (round 2: its 4096 workgroups take every wave slot); capped at
         two waves per SIMD, lowest priority, table update behind a single join: 0.515."""
-        if getattr(self, "_overlap_ok", None) is None:
-            self._overlap_ok = os.environ.get("CDC_OVERLAP", "1") != "0"
-            self._overlap_waves = int(os.environ.get("CDC_OVERLAP_WAVES", "2"))
         return self._overlap_ok
 
     def _side_stream(self):
@@ -554,13 +549,14 @@ class TrainStep:
 
     def _ahead_dp(self):
         """Data parallel, row-sharded table: the local sort, the bucketing and the id exchange of batch t+1 leave step t+1's
-        critical path when the caller names the next batch (step(..., next_X=)); see _dp_sequence_sharded.  CDC_SORT_AHEAD=0: off."""
+        critical path when the caller names the next batch (step(..., next_X=)); see _dp_sequence_sharded.  sort_ahead=False: off;
+        sort_ahead="force": also with a forced one-rank group."""
         if getattr(self, "_ahead_dp_ok", None) is None:
             # (a forced one-rank group has no transfer for the moved work to hide under — measured 0.803 -> 0.818 ms/step on the
             #  one-GPU box, the step there is bound by the host-side issue of its segments — so it takes part only with
-            #  CDC_SORT_AHEAD=2, which the RCCL call-path test sets)
-            env = os.environ.get("CDC_SORT_AHEAD", "1")
-            self._ahead_dp_ok = (self.dp_on and self.table_dist == "sharded" and env != "0" and (self.world > 1 or env == "2"))
+            #  sort_ahead="force", which the RCCL call-path test sets)
+            want = self._sort_ahead_wanted
+            self._ahead_dp_ok = (self.dp_on and self.table_dist == "sharded" and bool(want) and (self.world > 1 or want == "force"))
             if self._ahead_dp_ok:
                 self.ids_next = torch.zeros_like(self.emb.ids)
                 self._parity, self._sorted_for, self._dp_seqs = 0, None, {}
@@ -646,14 +642,18 @@ class TrainStep:
             L.launch("cdc_stage_batch", self.lib.cdc_stage_batch_next,
                      (X.data_ptr(), yf.data_ptr(), None if gdst is None else gf.data_ptr(), self.emb.ids.data_ptr(), self.y.data_ptr(),
                       None if gdst is None else gdst.data_ptr(), self.B, self.emb.F, None if nx is None else nx.data_ptr(),
-                      self.ids_next.data_ptr(), self.opt.step_dev.data_ptr(), self.opt.reg_sum.data_ptr(), 2),
+                      self.ids_next.data_ptr(), self.opt.step_dev.data_ptr(), self.opt.reg_sum.data_ptr(), 2,
+                      self.field_dims_dev.data_ptr(), self.alias.data_ptr()),
                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
         elif fast:                                                # one launch instead of three copies
             L.launch("cdc_stage_batch", self.lib.cdc_stage_batch,
                      (X.data_ptr(), yf.data_ptr(), None if gdst is None else gf.data_ptr(), self.emb.ids.data_ptr(), self.y.data_ptr(),
-                      None if gdst is None else gdst.data_ptr(), self.B, self.emb.F), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                      None if gdst is None else gdst.data_ptr(), self.B, self.emb.F, self.field_dims_dev.data_ptr(), self.alias.data_ptr()),
+                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
         else:
             self.emb.ids.copy_(X)
+            bad = ((self.emb.ids < 0) | (self.emb.ids >= self.field_dims_dev)).reshape(-1).to(torch.int32)
+            torch.maximum(self.alias, (bad * torch.arange(1, bad.numel() + 1, device=bad.device, dtype=torch.int32)).max().reshape(1), out=self.alias)
             self.y.copy_(yf)
             if gdst is not None:
                 gdst.copy_(gf)
@@ -730,7 +730,16 @@ class TrainStep:
         bad = int(self.emb.err.item())
         if bad:
             self.emb.err.zero_()
+            self.alias.zero_()
             raise IndexError(f"index out of range in self (flat position {bad - 1})")
+        al = int(self.alias.item())
+        if al:
+            self.alias.zero_()
+            b, f = divmod(al - 1, self.emb.F)
+            raise ValueError(f"the id at batch position {b}, field {f} lies outside the field's vocabulary but inside the table: it aliases a row "
+                             "of another field.  The reference trains that row through both fields at once (one Adam update of the summed "
+                             "gradient, model/layer.py:152-153); the per-field row lists of this path update it once per field, so the "
+                             "results of that step are not the reference's")
         for op in self.plan.ops:                                  # in-launch exchanges that gave up (csrc/tower.hip)
             word = getattr(op, "tmo_word", None)
             if torch.is_tensor(word) and int(word.item()) & L.TOWER_ERR_TIMEOUT:

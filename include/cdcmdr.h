@@ -962,15 +962,21 @@ int cdc_sum_slices(const float* in, int64_t ld_in, float* out, int64_t ld_out, i
 int cdc_step_increment(int32_t* step_dev, void* stream);                 /* ++*step_dev */
 int cdc_begin_step(int32_t* step_dev, double* accumulators, int32_t n_acc, void* stream);
 /* one batch into the static buffers of a replayed launch sequence: ids int32 [B,F], labels int16 [B], tower index int64 [B]
- * (group / group_dst may be NULL) — the three tensors run.py:476-479 hands to a step; one launch instead of three copies */
+ * (group / group_dst may be NULL) — the three tensors run.py:476-479 hands to a step; one launch instead of three copies.
+ * field_dims (device int32 [F], may be NULL): an id outside [0, field_dims[f]) sets *alias_flag to 1 + its flat position
+ * (atomic max).  Such an id either leaves the table (cdc_embed_gather_fwd flags that one too) or ALIASES a row of another field:
+ * the reference gathers that row like any other (model/layer.py:152-153) and its dense backward sums both fields' gradients
+ * into one Adam update, while the per-field row lists of this path would update the row once per field — so a training step
+ * reports it (TrainStep.check_ids) instead of diverging silently. */
 int cdc_stage_batch(const int32_t* ids, const int16_t* y, const int64_t* group, int32_t* ids_dst, int16_t* y_dst,
-                    int64_t* group_dst, int64_t B, int32_t F, void* stream);
+                    int64_t* group_dst, int64_t B, int32_t F, const int32_t* field_dims, int32_t* alias_flag, void* stream);
 /* the same for a step whose row sort runs one step AHEAD (the sort of batch t+1 beside the forward/backward of batch t): this batch as
  * above, the next batch's ids (next_ids, may be NULL) into next_dst — the buffer the look-ahead sort reads — and, with step_dev,
  * cdc_begin_step's work (++*step_dev, accumulators[0..n_acc) = 0), which the sort's first launch does otherwise */
 int cdc_stage_batch_next(const int32_t* ids, const int16_t* y, const int64_t* group, int32_t* ids_dst, int16_t* y_dst,
                          int64_t* group_dst, int64_t B, int32_t F, const int32_t* next_ids, int32_t* next_dst,
-                         int32_t* step_dev, double* accumulators, int32_t n_acc, void* stream);
+                         int32_t* step_dev, double* accumulators, int32_t n_acc, const int32_t* field_dims, int32_t* alias_flag,
+                         void* stream);
 int cdc_fill_f32(float* p, float value, int64_t n, void* stream);
 int cdc_fill_f64(double* p, double value, int64_t n, void* stream);
 /* dst[r*ld_dst + c] += src[r*ld_src + c]  (gradient fan-in where a kernel cannot accumulate itself) */

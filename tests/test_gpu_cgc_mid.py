@@ -23,7 +23,8 @@ def _model(cuda, n_tower, dropout, seed=0, fused=True):
     torch.manual_seed(seed)
     m = PLE(FD, D, n_tower, 2, 2, DIMS, TOWER, dropout=dropout).to(cuda).set_precision("bf16")
     m.seed = 1234
-    os.environ["CDC_CGC_MID"] = "1" if fused else "0"
+    from cdcmdr_amd import plan as P
+    P.CGCMid.enabled = fused                                    # (read when the plan is built, at the first forward)
     return m
 
 
@@ -35,12 +36,9 @@ def _uses_fused(m, B):
 
 @pytest.fixture(autouse=True)
 def _restore_env():
-    old = os.environ.get("CDC_CGC_MID")
+    from cdcmdr_amd import plan as P
     yield
-    if old is None:
-        os.environ.pop("CDC_CGC_MID", None)
-    else:
-        os.environ["CDC_CGC_MID"] = old
+    P.CGCMid.enabled = True
 
 
 @pytest.mark.parametrize("n_tower,B,dropout", [(3, 4096, 0.2), (3, 100, 0.0), (4, 1000, 0.2), (3, 16, 0.0), (3, 1, 0.0)])

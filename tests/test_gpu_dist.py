@@ -88,7 +88,8 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_
     torch.manual_seed(5)
     model, mode = _build(kind, dev)
     opt = FusedAdam(model, table_mode=table_mode, flush_every=2)
-    ts = TrainStep(model, opt, B_LOCAL, mode=mode, use_graph=use_graph, dist=dp, table_dist=table_dist, sync_bn=sync_bn)
+    ts = TrainStep(model, opt, B_LOCAL, mode=mode, use_graph=use_graph, dist=dp, table_dist=table_dist, sync_bn=sync_bn,
+                   sort_ahead="force" if os.environ.get("CDC_TEST_AHEAD_FORCE") == "1" else True)
     assert ts.table_dist == (table_dist or ("sharded" if table_mode == "lazy" else "replicated"))
     X, y, g = _data(world)
     gb = B_LOCAL * world
@@ -277,7 +278,7 @@ def test_one_rank_through_rccl_with_the_id_exchange_one_step_ahead(cuda, tmp_pat
     """the same over RCCL (forced one-rank group): the look-ahead id exchange is an ASYNC all-to-all on the communicator's stream,
     awaited at the start of the next step"""
     monkeypatch.setenv("CDC_TEST_AHEAD", "1")
-    monkeypatch.setenv("CDC_SORT_AHEAD", "2")                      # (a one-rank group takes part only when asked to: trainer._ahead_dp)
+    monkeypatch.setenv("CDC_TEST_AHEAD_FORCE", "1")                # (a one-rank group takes part only when asked to: trainer._ahead_dp)
     test_one_rank_through_rccl(cuda, tmp_path, "sharded", True)
 
 

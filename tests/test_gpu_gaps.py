@@ -134,9 +134,18 @@ def test_star30_bf16_against_the_bf16_restatement(cuda):
 
 @pytest.mark.parametrize("name", ["g2_ple3", "g2_mmoe8", "g2_star30_all", "g2_dcnv2_mix", "g2_dcn13"])
 def test_bf16_path_against_the_references_fp32_goldens(cuda, name):
-    """bf16-input / fp32-accumulate kernels against the fp32 REFERENCE itself, atol 5e-3 on probabilities (train and
-    eval mode), BCE within 5e-3 — the golden vectors captured from /root/reference, not a restatement."""
+    """bf16-input / fp32-accumulate kernels against the fp32 REFERENCE itself (the golden vectors captured from
+    /root/reference, not a restatement), probabilities in train and eval mode and the BCE.  The bound is MEASURED, not SURVEY's
+    round 5e-3 (which PLE-3's train-mode check used 0.98 of in round 3): tests/golden/bf16_entitled.json holds, per model, the worst
+    probability difference between the oracle's bf16 restatement — the CPU statement of this arithmetic, operands rounded where the
+    kernels round them, fp32 and exact accumulation — and the fp32 oracle over the golden's inputs and three re-draws
+    (tools/bf16_bound_report.py, profiles/round4/bf16_bounds.txt).  A correct bf16 path is entitled to that much; the test allows
+    2 x it (never less than 2e-4: accumulation-order noise of a sigmoid output).  Train mode: PLE-3 1.05e-2 (64 rows through two
+    BatchNorms: a bf16 rounding moves the batch statistics), MMoE-8 7.1e-3, DCN / DCNv2 1.2e-3, STAR-30 5.2e-4; eval mode 2e-4."""
+    import json
     from test_gpu_models_golden import build, load, sd_of
+    ent = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_entitled.json")))["worst"][name]
+    tol_train, tol_eval = max(2.0 * ent["train"], 2e-4), max(2.0 * ent["eval"], 2e-4)
     d = load(name)
     model = build(name).to(cuda).set_precision("bf16")
     model.load_state_dict(sd_of(d))
@@ -147,11 +156,11 @@ def test_bf16_path_against_the_references_fp32_goldens(cuda, name):
     with torch.no_grad():
         pred = model(x)
     pred = pred.gather(1, group).squeeze(1) if group is not None else pred
-    assert_close(pred, d["train_pred"], 0.0, 5e-3, "train_pred (bf16 vs the fp32 reference)")
+    assert_close(pred, d["train_pred"], 0.0, tol_train, "train_pred (bf16 vs the fp32 reference)")
     bce = torch.nn.BCELoss()(pred, y)
-    assert abs(float(bce) - float(d["bce"])) < 5e-3
+    assert abs(float(bce) - float(d["bce"])) < tol_train
     model.eval()
     with torch.no_grad():
         ev = model(x)
     ev = ev.gather(1, group).squeeze(1) if group is not None else ev
-    assert_close(ev, d["eval_pred"], 0.0, 5e-3, "eval_pred (bf16 vs the fp32 reference)")
+    assert_close(ev, d["eval_pred"], 0.0, tol_eval, "eval_pred (bf16 vs the fp32 reference)")

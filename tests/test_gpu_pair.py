@@ -139,12 +139,9 @@ DIMS, TOWER, D = ((256, 128), (64,)), (64, 32), 16
 
 @pytest.fixture
 def _pair_env():
-    old = os.environ.get("CDC_PAIR")
+    from cdcmdr_amd import plan as P
     yield
-    if old is None:
-        os.environ.pop("CDC_PAIR", None)
-    else:
-        os.environ["CDC_PAIR"] = old
+    P.ExpertPair.enabled = True
 
 
 @pytest.mark.parametrize("n_tower,B,dropout,train", [(3, 4096, 0.2, True), (3, 200, 0.0, True), (4, 1000, 0.2, True), (3, 300, 0.2, False)])
@@ -156,7 +153,7 @@ def test_ple_with_the_fused_expert_pair_equals_the_two_launches(cuda, _pair_env,
     gout = torch.randn((B, n_tower), generator=torch.Generator().manual_seed(7)).to(cuda)
     res = {}
     for fused in (False, True):
-        os.environ["CDC_PAIR"] = "1" if fused else "0"
+        P.ExpertPair.enabled = fused
         torch.manual_seed(0)
         m = PLE(FD, D, n_tower, 2, 2, DIMS, TOWER, dropout=dropout).to(cuda).set_precision("bf16")
         m.seed = 1234

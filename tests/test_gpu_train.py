@@ -172,12 +172,11 @@ def test_split_k_slabs_summed_by_the_adam_launch_train_bit_identically(cuda, mon
     fd = [50, 3, 500, 7, 90, 4, 1000, 30]
     res = {}
     for defer in ("0", "1"):
-        monkeypatch.setenv("CDC_DW_DEFER", defer)
         torch.manual_seed(4)
         model = PLE(fd, 16, 3, 2, 2, ((256, 128), (64,)), (64, 32), dropout=0.2).to(cuda).set_precision(precision)
         model.seed = 77
         opt = FusedAdam(model, table_mode="lazy")
-        ts = TrainStep(model, opt, B, use_graph=(defer == "1"))
+        ts = TrainStep(model, opt, B, use_graph=(defer == "1"), defer_dw_reduce=(defer == "1"))
         assert bool(ts.plan.grad_slabs) == (defer == "1"), "split-K launches expected at this batch size"
         r = np.random.default_rng(8)
         losses = []
@@ -218,12 +217,11 @@ def test_row_sort_one_batch_ahead_trains_bit_identically(cuda, monkeypatch, use_
     decoy = torch.from_numpy(make_ids(r, B, fd)).to(cuda)
     res = {}
     for ahead in ("0", "1"):
-        monkeypatch.setenv("CDC_SORT_AHEAD", ahead)
         torch.manual_seed(4)
         model = PLE(fd, 8, 3, 2, 2, ((32, 16), (8,)), (8, 4), dropout=0.2).to(cuda).set_precision("f32")
         model.seed = 5
         opt = FusedAdam(model, table_mode="lazy", flush_every=4)
-        ts = TrainStep(model, opt, B, use_graph=use_graph)
+        ts = TrainStep(model, opt, B, use_graph=use_graph, sort_ahead=(ahead == "1"))
         losses = []
         for i in range(n):
             nxt = Xs[i + 1]
@@ -233,9 +231,13 @@ def test_row_sort_one_batch_ahead_trains_bit_identically(cuda, monkeypatch, use_
                 nxt = None                               # nothing announced
             if i == 7:
                 nxt = Xs[i + 1][:B // 2]                 # wrong shape: ignored
+            if i == 3:
+                # another step of the same optimiser in between (a sibling for a ragged batch, as data.train_epoch issues at the end of
+                # an epoch): its dense-Adam argument set must not replace (and free) the one the main step's graphs were captured with
+                ts.sibling(B // 2).step(decoy[:B // 2].contiguous(), ys[0][:B // 2].contiguous(), gs[0][:B // 2].contiguous())
             bce, _ = ts.step(Xs[i], ys[i], gs[i], next_X=nxt)
             losses.append(float(bce.item()))
-        # (the look-ahead rides on the side chain: CDC_OVERLAP=0 or the fused catch-up + gather switch it off)
+        # (the look-ahead rides on the side chain: TrainStep(overlap=False) or the fused catch-up + gather switch it off)
         assert bool(getattr(ts, "_ahead_ok", False)) == (ahead == "1" and ts._overlap() and not ts._fuse_gather())
         opt.flush_table()
         res[ahead] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
@@ -517,6 +519,58 @@ def test_checkpoint_resume_continues_bit_identically(cuda, tmp_path, table_mode)
     assert torch.equal(opt.table_m.cpu(), want_m)
 
 
+@pytest.mark.parametrize("use_graph,ahead", [(False, True), (True, True), (False, False)])
+def test_an_id_that_aliases_another_fields_row_is_reported(cuda, use_graph, ahead):
+    """An id outside its field's vocabulary that still lies INSIDE the table (field 0 has 50 rows: id 50 is row 0 of field 1).  The
+    reference gathers that row like any other (model/layer.py:152-153) — so does the gather here, bit for bit — and its dense
+    backward sums the gradients of both fields into ONE Adam update; the per-field row lists of this path would update the row once
+    per field.  Instead of diverging silently the step reports it: check_ids() raises ValueError naming the position (an id that
+    leaves the table altogether keeps raising IndexError), and a clean batch afterwards trains normally."""
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    fd = [50, 3000, 3, 900, 7]
+    B, D = 192, 8
+    r = np.random.default_rng(3)
+    X = make_ids(r, B, fd)
+    y = torch.from_numpy(r.integers(0, 2, size=B).astype(np.int16)).to(cuda)
+    g = torch.from_numpy(X[:, 2].astype(np.int64)).to(cuda)
+    good = torch.from_numpy(X).to(cuda)
+    alias = good.clone()
+    alias[5, 0] = 50 + 17                                               # field 0: outside [0, 50), row 17 of field 1
+    torch.manual_seed(4)
+    model = PLE(fd, D, 3, 1, 1, ((16,), (8,)), (8,), dropout=0.0).to(cuda).set_precision("f32")
+    opt = FusedAdam(model, table_mode="lazy", flush_every=4)
+    ts = TrainStep(model, opt, B, use_graph=use_graph, sort_ahead=ahead)
+    for _ in range(3):
+        ts.step(good, y, g, next_X=good)
+    ts.check_ids()
+    table = model.embedding.embedding_dict.weight
+    ts.step(alias, y, g, next_X=good)
+    opt.flush_table()
+    got = ts.emb.out.tensor()[5, 0:D].clone()
+    with pytest.raises(ValueError, match="batch position 5, field 0"):
+        ts.check_ids()
+    ts.step(good, y, g, next_X=good)
+    ts.check_ids()                                                       # the flag was cleared, a clean batch passes
+    assert np.isfinite(float(ts.loss.item()))
+    # the gather itself took the aliased row, as the reference does (checked on a fresh forward through the drop-in path)
+    model.eval()
+    with torch.no_grad():
+        model(alias)
+    emb = model.plan_holder(B).emb_op.out.tensor()
+    assert torch.equal(emb[5, 0:D], table.detach()[50 + 17])
+    assert got.shape == (D,)
+    # out of the table altogether: IndexError first
+    worse = alias.clone()
+    worse[9, 4] = 7
+    ts.step(worse, y, g)
+    with pytest.raises(IndexError):
+        ts.check_ids()
+    ts.step(good, y, g)
+    ts.check_ids()
+
+
 @pytest.mark.parametrize("D,precision", [(16, "bf16"), (32, "f32"), (8, "f32")])
 def test_fused_catchup_gather_equals_the_two_launches(cuda, monkeypatch, D, precision):
     """cdc_embed_lazy_catchup_gather (the catch-up lanes write the embeddings) against cdc_embed_lazy_catchup followed by
@@ -536,17 +590,14 @@ def test_fused_catchup_gather_equals_the_two_launches(cuda, monkeypatch, D, prec
                         torch.from_numpy(X[:, 2].astype(np.int64)).to(cuda)))
     batches.append(batches[1])                                          # the same rows again, two steps later
     bad = batches[2][0].clone()
-    # (an id past its field's vocabulary that still lies INSIDE the table aliases another field's row: gathered like the reference
-    #  gathers it, but the row then sits in two fields' sorted lists and is updated once per list in no defined order — the
-    #  sorted lists are per field, INTEGRATION.md "ids"; not exercised here)
+    # (an id past its field's vocabulary that still lies INSIDE the table: test_an_id_that_aliases_another_fields_row_is_reported)
     bad[7, 4] = 7                                                       # last field: 7 is outside [0, 7) and outside the table
     res = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("CDC_FUSE_GATHER", fused)
         torch.manual_seed(4)
         model = PLE(fd, D, 3, 1, 1, ((16,), (8,)), (8,), dropout=0.0).to(cuda).set_precision(precision)
         opt = FusedAdam(model, table_mode="lazy", flush_every=4)
-        ts = TrainStep(model, opt, B, use_graph=False)
+        ts = TrainStep(model, opt, B, use_graph=False, fuse_gather=(fused == "1"))
         assert ts._fuse_gather() == (fused == "1")
         losses, embs = [], []
         for b in batches:
