@@ -46,11 +46,14 @@ class DeviceLoader:
         self.tensors, self.batch_size, self.shuffle = tuple(tensors), int(batch_size), bool(shuffle)
         self.rank, self.world, self.generator = int(rank), int(world), generator
         self.n = n
-        self.dropped_rows = 0             # data parallel: rows of the ragged last global batch of the last epoch (not trained on)
+        self.dropped_rows = 0             # data parallel: rows of a last global batch with fewer rows than ranks (not trained on)
+        self.last_global_rows = 0         # data parallel: true size of the ragged last global batch this epoch yielded shares of
 
     def __len__(self):
         g = self.batch_size * self.world
-        return self.n // g if self.world > 1 else (self.n + g - 1) // g
+        if self.world > 1:                # the ragged last global batch is yielded when every rank gets at least one row of it
+            return self.n // g + (1 if self.n % g >= self.world else 0)
+        return (self.n + g - 1) // g
 
     def _order(self):
         if not self.shuffle:
@@ -76,12 +79,22 @@ class DeviceLoader:
         for lo in range(0, self.n, step):
             hi = min(lo + step, self.n)
             if self.world > 1:
-                # the rank's contiguous share of the global batch.  A ragged last global batch is not yielded at all: split
-                # unevenly, some ranks would hold a full local batch and run the step's collectives while others skip it
+                # the rank's contiguous share of the global batch.  The ragged last global batch (run.py:476 trains it like any other)
+                # is split as evenly as its rows allow — rank r gets base + (r < rem) rows — and yielded with its true global size in
+                # `last_global_rows`: train_epoch runs it through TrainStep.sibling(rows, global_rows=, cap_rows=), whose loss mean and
+                # BatchNorm statistics are those of the whole ragged batch.  Fewer rows than ranks: not yielded (a rank without a row
+                # cannot build a step), counted in dropped_rows
                 if hi - lo < step:
-                    self.dropped_rows = hi - lo
-                    return
-                a, b = lo + self.rank * self.batch_size, lo + (self.rank + 1) * self.batch_size
+                    n = hi - lo
+                    if n < self.world:
+                        self.dropped_rows = n
+                        return
+                    base, rem = divmod(n, self.world)
+                    a = lo + self.rank * base + min(self.rank, rem)
+                    b = a + base + (1 if self.rank < rem else 0)
+                    self.last_global_rows = n
+                else:
+                    a, b = lo + self.rank * self.batch_size, lo + (self.rank + 1) * self.batch_size
             else:
                 a, b = lo, hi
             if perm is None:
@@ -144,7 +157,8 @@ def train_epoch(step, loader, log_interval=None, log=None):
     """`Run.train` (run.py:470-497) on a TrainStep: one pass over the loader; every `log_interval` batches (reference:
     204800 // bs) the mean of loss + regularisation term is reported through `log(mean)` — the only host synchronisation.
     The ragged last batch of an epoch is trained on like any other (a sibling step of that size on the same model and
-    optimiser state); under data parallelism the loader does not yield it (every rank skips the same global batch).
+    optimiser state); under data parallelism every rank gets its share of it (DeviceLoader) and the sibling step is told the
+    batch's global size: loss mean, BatchNorm statistics and row-list capacities are those of the whole ragged batch.
     Out-of-range ids and row-list overflows are surfaced at the logging synchronisations and at the end of the epoch
     (`step.check_ids()`: IndexError like nn.Embedding's).  Returns (batches run, batches skipped)."""
     if log_interval is None:
@@ -159,11 +173,16 @@ def train_epoch(step, loader, log_interval=None, log=None):
         X = batch[0]
         ts = step
         if X.shape[0] != step.B:
-            if step.world > 1 or X.shape[0] == 0:
+            if X.shape[0] == 0:
                 skipped += 1
                 batch = nxt
                 continue
-            ts = step.sibling(X.shape[0])
+            if step.world > 1:
+                n = int(getattr(loader, "last_global_rows", 0))
+                assert n > 0, "a ragged local batch under data parallelism needs the loader's last_global_rows"
+                ts = step.sibling(X.shape[0], global_rows=n, cap_rows=-(-n // step.world))
+            else:
+                ts = step.sibling(X.shape[0])
         ahead = nxt[0] if (nxt is not None and ts is step and nxt[0].shape[0] == step.B) else None
         bce, reg = ts.step(*batch, next_X=ahead) if ahead is not None else ts.step(*batch)
         batch = nxt

@@ -31,13 +31,16 @@ class TrainStep:
 
     def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None, sync_bn=True,
                  table_dist=None, shard_slack=1.5, train_mode=True, overlap=True, overlap_waves=2, sort_ahead=True, fuse_gather=False,
-                 defer_dw_reduce=None):
+                 defer_dw_reduce=None, global_rows=None, cap_rows=None):
         """sync_bn (data parallel only): BatchNorm statistics over the GLOBAL batch, as the reference's single process
         computes them — two small all-reduces per BatchNorm launch; False = per-rank statistics.
         table_dist (data parallel only): "sharded" (row r owned by rank r % world; default with the lazy table optimiser)
         or "replicated" (every rank applies the global batch's table update).  shard_slack: capacity of the per-owner,
         per-field row lists as a multiple of the even share B/world (an overflow raises in check_ids()).
         overlap / overlap_waves / sort_ahead / fuse_gather (single GPU, lazy table; for tests and A/B runs — the defaults are what is
+        global_rows / cap_rows (data parallel, the ragged last global batch of an epoch: TrainStep.sibling): the batch's true global
+        size (the BCE mean runs over it; this rank's share is batch_size) and the largest share any rank holds (row-list capacities
+        are a property of the exchange, equal on every rank).
         measured and shipped): the replay slice in the background on a second chain (waves per SIMD of its capped grid), the next
         batch's row sort on that chain (step(..., next_X=)), the catch-up launch that also writes the gathered embeddings (slower:
         profiles/round3/README.md section 3)."""
@@ -47,7 +50,8 @@ class TrainStep:
         self.sync_bn = bool(sync_bn)
         self.world = 1 if dist is None else dist.world_size
         self.dp_on = self.world > 1 or bool(getattr(dist, "force", False))     # force: the collective path with one rank
-        self.global_B = self.B * self.world
+        self.global_B = self.B * self.world if global_rows is None else int(global_rows)
+        self._shard_slack = float(shard_slack)
         dev = optimizer.device
         self.device = dev
         self.train_mode = bool(train_mode)
@@ -96,7 +100,9 @@ class TrainStep:
             if optimizer.table_mode != "lazy":
                 raise ValueError("the row-sharded table needs table_mode='lazy'")
             F, D, N = self.emb.F, self.emb.D, self.world
-            cap = min(self.B, int(-(-self.B // N) * float(shard_slack)) + 16)
+            Bc = self.B if cap_rows is None else int(cap_rows)           # the largest local batch of the step over the ranks
+            assert Bc >= self.B
+            cap = min(Bc, int(-(-Bc // N) * float(shard_slack)) + 16)
             if N * cap > L.SORT_MAX_ROWS:
                 raise ValueError(f"world {N} x list capacity {cap} exceeds the per-field sort limit {L.SORT_MAX_ROWS}")
             self.cap, self.Bv = cap, N * cap                          # Bv: rows of the owner-side batch
@@ -713,16 +719,27 @@ class TrainStep:
             self._overlap_ok = was_overlap
         return out
 
-    def sibling(self, batch_size):
+    def sibling(self, batch_size, global_rows=None, cap_rows=None):
         """A TrainStep for another batch size on the SAME model and optimiser state (the ragged last batch of an epoch,
-        which the reference trains on like any other: run.py:476).  Single GPU only; runs eagerly."""
-        if self.world > 1:
-            raise NotImplementedError("ragged batches under data parallelism")
+        which the reference trains on like any other: run.py:476); runs eagerly.  Data parallel: batch_size is THIS rank's share
+        of the ragged global batch, global_rows its true size, cap_rows the largest share (ceil(global_rows / world)); every rank
+        must call it (the step's collectives).  Row-sharded table, or equal shares with the replicated one."""
+        key = (int(batch_size), None if global_rows is None else int(global_rows), None if cap_rows is None else int(cap_rows))
         sib = self.__dict__.setdefault("_siblings", {})
-        ts = sib.get(int(batch_size))
+        ts = sib.get(key)
         if ts is None:
-            ts = TrainStep(self.model, self.opt, int(batch_size), mode=self.mode, use_graph=False, train_mode=self.train_mode)
-            sib[int(batch_size)] = ts
+            if self.world > 1:
+                if global_rows is None or cap_rows is None:
+                    raise ValueError("a ragged batch under data parallelism needs global_rows and cap_rows (data.train_epoch passes them)")
+                if self.table_dist != "sharded" and int(global_rows) != int(batch_size) * self.world:
+                    raise NotImplementedError("uneven shares of a ragged batch need the row-sharded table (the replicated table's "
+                                              "all-gathers are equal-sized)")
+                ts = TrainStep(self.model, self.opt, int(batch_size), mode=self.mode, use_graph=False, dist=self.dist, sync_bn=self.sync_bn,
+                               table_dist=self.table_dist, shard_slack=self._shard_slack, train_mode=self.train_mode, sort_ahead=False,
+                               global_rows=int(global_rows), cap_rows=int(cap_rows))
+            else:
+                ts = TrainStep(self.model, self.opt, int(batch_size), mode=self.mode, use_graph=False, train_mode=self.train_mode)
+            sib[key] = ts
         return ts
 
     def check_ids(self):

@@ -60,9 +60,10 @@ def test_rank_shards_partition_every_global_batch():
 
 
 @pytest.mark.parametrize("n", [2 * 3 * 64 - 1, 2 * 3 * 64 + 3 * 64 - 1, 7])
-def test_every_rank_runs_the_same_number_of_full_batches(n):
-    """The ragged last GLOBAL batch (here one row short of world*B, the case where ceil-splitting gave every rank but the last a
-    full batch) must be skipped by all ranks alike: a rank that runs the step issues collectives the others never join."""
+def test_every_rank_runs_the_same_number_of_batches(n):
+    """Every rank must run the same number of steps (a rank that runs a step issues collectives the others have to join): the
+    ragged last GLOBAL batch — here one row short of world*B, the case where ceil-splitting gave every rank but the last a full
+    batch — is shared out over ALL ranks (round 4; round 3 skipped it on all ranks), unless it has fewer rows than there are ranks."""
     from cdcmdr_amd.data import DeviceLoader
     X, y = _data(n=n)
     world, bs = 3, 64
@@ -71,11 +72,17 @@ def test_every_rank_runs_the_same_number_of_full_batches(n):
         torch.manual_seed(3)
         dl = DeviceLoader((X, y), bs, shuffle=True, rank=r, world=world)
         batches = list(dl)
-        assert all(b[0].shape[0] == bs for b in batches)
-        assert len(batches) == len(dl) == n // (world * bs)
-        assert dl.dropped_rows == n % (world * bs)
-        counts.append(len(batches))
-    assert len(set(counts)) == 1
+        tail = n % (world * bs)
+        full = n // (world * bs)
+        assert all(b[0].shape[0] == bs for b in batches[:full])
+        assert len(batches) == len(dl) == full + (1 if tail >= world else 0)
+        if tail >= world:
+            assert dl.last_global_rows == tail and batches[-1][0].shape[0] in (tail // world, tail // world + 1)
+        else:
+            assert dl.dropped_rows == tail
+        counts.append((len(batches), sum(b[0].shape[0] for b in batches)))
+    assert len(set(c for c, _ in counts)) == 1
+    assert sum(r for _, r in counts) == n - (n % (world * bs) if n % (world * bs) < world else 0)
 
 
 def test_split_files_round_trip_and_make_loader(tmp_path):
@@ -103,3 +110,33 @@ def test_split_files_round_trip_and_make_loader(tmp_path):
     np.testing.assert_allclose(w2, cnt / len(X))
     with pytest.raises(ValueError):
         make_loader(X, y, 128, "cpu", domain_idx=2, domain2group={0: 0, 1: 1})     # domains 2, 3 have no tower
+
+
+def test_ragged_last_global_batch_is_split_over_the_ranks():
+    """Data parallel: the ragged last global batch (run.py:476 trains it) reaches every rank — shares differ by at most one row, cover
+    the batch exactly once in order, and the loader reports its true global size; with fewer rows than ranks it is dropped."""
+    from cdcmdr_amd.data import DeviceLoader
+    n, bs = 75, 16
+    X = torch.arange(n, dtype=torch.int32).reshape(-1, 1)
+    y = torch.zeros(n, 1, dtype=torch.int16)
+    for world in (2, 3, 4):
+        got, last = [], None
+        per_rank = []
+        for rank in range(world):
+            ld = DeviceLoader((X, y), bs, shuffle=False, rank=rank, world=world)
+            batches = [b[0].reshape(-1).tolist() for b in ld]
+            per_rank.append(batches)
+            last = getattr(ld, "last_global_rows", None)
+        full = n // (bs * world)
+        tail = n - full * bs * world
+        assert all(len(b) == full + (1 if tail >= world else 0) for b in per_rank)
+        if tail >= world:
+            assert last == tail
+            shares = [b[-1] for b in per_rank]
+            assert max(map(len, shares)) - min(map(len, shares)) <= 1
+            assert sum(shares, []) == list(range(full * bs * world, n))
+        for step in range(full):
+            rows = sum((per_rank[r][step] for r in range(world)), [])
+            assert rows == list(range(step * bs * world, (step + 1) * bs * world))
+    ld = DeviceLoader((X[:66], y[:66]), 16, shuffle=False, rank=0, world=4)     # 66 = 64 + 2 rows: fewer rows than ranks in the tail
+    assert len(list(ld)) == 1 and ld.dropped_rows == 2

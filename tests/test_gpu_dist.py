@@ -38,6 +38,14 @@ def _data(world):
     return X, y, g
 
 
+def _ragged_batch(world):
+    """one more, RAGGED global batch (run.py:476 trains the tail of an epoch like any other batch): world * B_LOCAL - 5 rows"""
+    rng = np.random.default_rng(23)
+    n = B_LOCAL * world - 5
+    X = np.stack([rng.integers(0, d, size=n) for d in FD], axis=1).astype(np.int32)
+    return X, rng.integers(0, 2, size=n).astype(np.int16), X[:, 4].astype(np.int64)
+
+
 def _build(kind, dev):
     D = int(os.environ.get("CDC_TEST_EMB_DIM", "8"))            # (spawned workers inherit the environment)
     if kind == "cdcple":
@@ -71,6 +79,10 @@ def _single_process_reference(table_mode, kind="mmoe", world=2):
     for s in range(STEPS):
         sl = slice(s * gb, (s + 1) * gb)
         bce, _ = ts.step(torch.from_numpy(X[sl]).to(dev), torch.from_numpy(y[sl]).to(dev), torch.from_numpy(g[sl]).to(dev))
+        losses.append(float(bce.item()))
+    if os.environ.get("CDC_TEST_RAGGED") == "1":
+        Xr, yr, gr = _ragged_batch(world)
+        bce, _ = ts.sibling(Xr.shape[0]).step(torch.from_numpy(Xr).to(dev), torch.from_numpy(yr).to(dev), torch.from_numpy(gr).to(dev))
         losses.append(float(bce.item()))
     opt.flush_table()
     return {k: v.cpu() for k, v in model.state_dict().items()}, losses
@@ -111,6 +123,17 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_
         losses.append(float(bce.item()))
     if ahead and table_dist == "sharded" and table_mode == "lazy":
         assert ts._ahead_dp_ok and len(ts._dp_seqs) >= 3, "the look-ahead sequences were not used"
+    if os.environ.get("CDC_TEST_RAGGED") == "1":
+        # the epoch's ragged tail, split as data.DeviceLoader splits it: rank r gets base + (r < rem) rows
+        Xr, yr, gr = _ragged_batch(world)
+        n = Xr.shape[0]
+        base, rem = divmod(n, world)
+        a = rank * base + min(rank, rem)
+        b = a + base + (1 if rank < rem else 0)
+        sib = ts.sibling(b - a, global_rows=n, cap_rows=-(-n // world))
+        bce, _ = sib.step(torch.from_numpy(Xr[a:b]).to(dev), torch.from_numpy(yr[a:b]).to(dev), torch.from_numpy(gr[a:b]).to(dev))
+        losses.append(float(bce.item()))
+        sib.check_ids()
     ts.check_ids()
     ts.gather_table()                 # flush + (row-sharded table) every owner's rows to every rank
     torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "m": opt.table_m.cpu(), "losses": losses},
@@ -162,6 +185,32 @@ def test_two_ranks_stay_identical(cuda, tmp_path, table_mode, use_graph, table_d
     moved = (w - w0).abs()
     big = w0.abs() > 0.1
     assert float(moved[big].min()) > 0.9e-3 * STEPS and float(moved[big].max()) < 1.1e-3 * STEPS
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_train_the_ragged_last_batch_like_one_rank(cuda, tmp_path, monkeypatch, world):
+    """The ragged last global batch of an epoch under data parallelism (run.py:476 trains it like any other batch; round 3 dropped
+    it): world * 64 - 5 rows split unevenly over the ranks (data.DeviceLoader's split), trained through TrainStep.sibling(rows,
+    global_rows=, cap_rows=) — BCE mean over the true global size, global BatchNorm statistics over unequal shares, row lists of a
+    common capacity.  Replicas identical, and equal to ONE rank training the same rows as one ragged batch."""
+    monkeypatch.setenv("CDC_TEST_RAGGED", "1")
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "lazy", False, "sharded"), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    assert len(rs[0]["losses"]) == STEPS + 1
+    for r in rs[1:]:
+        assert r["losses"] == rs[0]["losses"]
+        for k in rs[0]["sd"]:
+            assert torch.equal(rs[0]["sd"][k], r["sd"][k]), f"replicas diverged in {k}"
+    from helpers import assert_close, is_pre_bn_bias
+    ref_sd, ref_losses = _single_process_reference("lazy", world=world)
+    for a, b in zip(rs[0]["losses"], ref_losses):
+        assert abs(a - b) < 2e-5, (rs[0]["losses"], ref_losses)
+    names = set(ref_sd)
+    for k, v in ref_sd.items():
+        if is_pre_bn_bias(k, names) or "num_batches" in k:
+            continue
+        atol = 6e-4 if k.endswith("running_mean") else 2e-5
+        assert_close(rs[0]["sd"][k], v, 5e-4, atol, f"{world}-rank vs 1-rank with a ragged last batch: {k}")
 
 
 def test_two_ranks_cdc_ple_row_sharded_equals_one_rank(cuda, tmp_path, monkeypatch):
