@@ -283,7 +283,7 @@ class TowerLayer(C.Structure):
 class TowerDesc(C.Structure):
     _fields_ = [("xh", c_p), ("ldxh", c_i64), ("dx", c_p), ("lddx", c_i64), ("accumulate_dx", c_i32), ("pad_", c_i32),
                 ("l1", TowerLayer), ("l2", TowerLayer), ("a1h", c_p), ("lda1h", c_i64), ("a2", c_p), ("lda2", c_i64),
-                ("wo", c_p), ("bo", c_p), ("dwo", c_p), ("dbo", c_p)]
+                ("wo", c_p), ("bo", c_p), ("dwo", c_p), ("dbo", c_p), ("dy2", c_p), ("lddy2", c_i64), ("dy1", c_p), ("lddy1", c_i64)]
 
 
 class TowerArgs(C.Structure):
@@ -293,7 +293,7 @@ class TowerArgs(C.Structure):
                 ("wide_x", c_p), ("ld_wide", c_i64), ("wide_w", c_p), ("wide_bias", c_p), ("wide_dx", c_p), ("ld_wide_dx", c_i64),
                 ("wide_dw", c_p), ("wide_dbias", c_p), ("wide_K", c_i32), ("accumulate_wide_dx", c_i32),
                 ("bce_group", c_p), ("bce_y_i16", c_p), ("bce_y_f32", c_p), ("bce_loss", c_p), ("bce_inv_count", c_f), ("pad2_", c_i32),
-                ("workspace", c_p), ("err", c_p), ("t", TowerDesc * TOWER_MAX)]
+                ("workspace", c_p), ("err", c_p), ("exchange", c_p * 4), ("t", TowerDesc * TOWER_MAX)]
 
 
 class StarFuseArgs(C.Structure):
@@ -368,6 +368,7 @@ _SIGNATURES = {
     "cdc_tower_fwd": (c_i32, [C.POINTER(TowerArgs), c_p]),
     "cdc_tower_bwd": (c_i32, [C.POINTER(TowerArgs), c_p]),
     "cdc_tower_workspace_bytes": (c_i64, [C.POINTER(TowerArgs)]),
+    "cdc_tower_dp": (c_i32, [C.POINTER(TowerArgs), c_i32, c_p]),
     "cdc_bce_fwd_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f, c_p]),
     "cdc_attn_fwd": (c_i32, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),
     "cdc_attn_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_f, C.c_uint64, c_p, c_p]),

@@ -41,7 +41,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define TW_GLOBAL __attribute__((address_space(1)))
 #define TW_SLAB (TW_ROWS * 128)              /* one 64-column bf16 slab of a 128-row operand tile */
 #define TW_SPIN_LIMIT 200000u                /* polls of ~1 us: a wait gives up after ~0.2 s */
-#define TW_HDR_BYTES 4096
+#define TW_HDR_BYTES 8192
 #define TW_LINE 32                           /* ints per 128-byte line: every counter on a line of its own */
 // header lines
 #define TW_F1(t) (t)
@@ -51,12 +51,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define TW_B4 13
 #define TW_BDONE 14
 #define TW_POISON 15
+// the split form (data parallel, cdc_tower_dp): one arrival counter per tower and exchange — the LAST workgroup to arrive adds the
+// tower's partials up and puts the counter back to zero (nobody waits)
+#define TW_S(e, t) (16 + 4 * (e) + (t))
 #ifndef TW_TRACE
 #define TW_TRACE 0          /* 1 (probe builds only): thread 0 of workgroup 0 stamps the 100 MHz wall clock at every phase boundary
-                               into header bytes [2048, 4096): forward stamps [0, 16), backward stamps [16, 32) */
+                               into header bytes [4096, 8192): forward stamps [0, 16), backward stamps [16, 32) */
 #endif
 #if TW_TRACE
-#define TW_STAMP(i) do { if (blockIdx.x == TW_TRACE - 1 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.workspace) + 2048)[(i)] = wall_clock64(); } while (0)
+#define TW_STAMP(i) do { if (blockIdx.x == TW_TRACE - 1 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.workspace) + 4096)[(i)] = wall_clock64(); } while (0)
 #else
 #define TW_STAMP(i) do { } while (0)
 #endif
@@ -1107,13 +1110,634 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
 }
 
 // =================================================================================================
+// the split form (data parallel with global-batch BatchNorm statistics): cdc_tower_dp, phases 1..6
+// =================================================================================================
+// A phase that ends in front of an exchange: the workgroups of tower t have published their partial records (write-through stores,
+// drained, behind a workgroup barrier); the LAST one to arrive (the value its add returned says so) adds them up in the fixed order
+// of tw_gather_sums and writes the tower's local sums and row count into the exchange buffer; it also puts the counter back to zero.
+// All threads call.  Returns (uniformly per workgroup) whether this workgroup was the last.
+template <int C>
+__device__ __forceinline__ bool tw_last_sums(int* hdr, int line, int G, const double* ws, int n_parts, int total_c, int col0, double* part,
+                                             double* sums, int* flag_s, double* ex, int t, int n_tower, int M, int tid) {
+    if (tid == 0) {
+        const int old = tw_add(hdr + line * TW_LINE, 1);
+        *flag_s = old == G - 1;
+        if (old == G - 1) tw_st(hdr + line * TW_LINE, 0);
+    }
+    __syncthreads();
+    if (!*flag_s) return false;
+    tw_gather_sums<C>(ws, n_parts, total_c, col0, part, sums, tid);
+    if (tid < C) {
+        ex[2 * (t * C + tid)] = sums[tid];
+        ex[2 * (t * C + tid) + 1] = sums[C + tid];
+    }
+    if (tid == 0) ex[2 * n_tower * C + t] = (double)M;
+    return true;
+}
+// global sums -> mean / invstd in LDS (forward) from an all-reduced exchange buffer
+template <int C>
+__device__ __forceinline__ void tw_stats_from_exchange(const double* ex, int t, int n_tower, float eps, float momentum, bool writer, float* save_mean,
+                                                       float* save_invstd, float* running_mean, float* running_var, int64_t* nbt, float* col_mean,
+                                                       float* col_inv, double* sums, int tid) {
+    const int Ms = (int)(ex[2 * n_tower * C + t] + 0.5);
+    if (tid < C) { sums[tid] = ex[2 * (t * C + tid)]; sums[C + tid] = ex[2 * (t * C + tid) + 1]; }
+    __syncthreads();
+    tw_finish_stats<C>(sums, Ms, eps, momentum, writer, save_mean, save_invstd, running_mean, running_var, nbt, col_mean, col_inv, tid);
+}
+
+struct TwDpCfg {                                                     // LDS of every phase (H0 <= 128, H1 = 64, H2 = 32)
+    static constexpr int OPA = 0;                                    // A operand tile: up to two 64-column slabs of [128][64] bf16
+    static constexpr int OPB = OPA + 2 * TW_SLAB;                    // B operand tile: up to 128 rows x 64 columns bf16 (x 2 slabs of 64 rows)
+    static constexpr int CT = OPB + 128 * 128;                       // fp32 tiles: [128][132] (dX) / 2 x [128][68] / 3 x [128][36]
+    static constexpr int PART = CT + TW_ROWS * 136 * 4;
+    static constexpr int SUMS = PART + 2 * 8 * 64 * 8;
+    static constexpr int CMEAN = SUMS + 2 * 64 * 8;
+    static constexpr int CINV = CMEAN + 256;
+    static constexpr int PAR = CINV + 256;
+    static constexpr int DS = PAR + TW_PAR_FLOATS * 4;               // d[128], dsum[128] floats, own list + flags, loss
+    static constexpr int DSUM = DS + 512;
+    static constexpr int OWN = DSUM + 512;
+    static constexpr int LOSS = OWN + (2 * TW_ROWS + 4) * 4;
+    static constexpr int WDW = LOSS + TW_ROWS * 8;
+    static constexpr int FLAG = WDW + 4 * 520 * 4;
+    static constexpr int SMEM = FLAG + 16;
+    static_assert(SMEM <= 150 * 1024, "one workgroup per CU with room to spare");
+};
+
+template <int NK0, int H1, int H2, int PHASE>
+__global__ void __launch_bounds__(TW_THREADS) k_tower_dp(const cdc_tower_args a_by_value) {
+    CDC_PRIO_MAIN();
+    (void)a_by_value;
+    const TW_KARG cdc_tower_args& a = *(const TW_KARG cdc_tower_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef TwDpCfg Cfg;
+    constexpr int H0 = NK0 * 64;
+    constexpr int CS1 = H1 + 4, CS2 = H2 + 4, CSX = H0 + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = (int)a.M, n_tower = a.n_tower;
+    const int G = (M + TW_ROWS - 1) / TW_ROWS;
+    const int n_wg = n_tower * G;
+    const int t = (int)blockIdx.x / G, jb = (int)blockIdx.x - t * G;
+    const int row0 = jb * TW_ROWS, rows = min(TW_ROWS, M - row0);
+    const TW_KARG cdc_tower_desc& T = a.t[t];
+    int* hdr = reinterpret_cast<int*>(a.workspace);
+    const bool has_wide = a.wide_x != nullptr;
+    const int wide_K = has_wide ? a.wide_K : 0;
+    const TwLayout L = tw_layout(n_tower, H1, H2, M, wide_K);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(a.workspace);
+    const bool writer = jb == 0;
+    unsigned char* OPA = smem + Cfg::OPA;
+    unsigned char* OPB = smem + Cfg::OPB;
+    float* ct = reinterpret_cast<float*>(smem + Cfg::CT);
+    double* part = reinterpret_cast<double*>(smem + Cfg::PART);
+    double* sums = reinterpret_cast<double*>(smem + Cfg::SUMS);
+    float* col_mean = reinterpret_cast<float*>(smem + Cfg::CMEAN);
+    float* col_inv = reinterpret_cast<float*>(smem + Cfg::CINV);
+    float* par_s = reinterpret_cast<float*>(smem + Cfg::PAR);
+    float* d_s = reinterpret_cast<float*>(smem + Cfg::DS);
+    float* dsum_s = reinterpret_cast<float*>(smem + Cfg::DSUM);
+    int* own_s = reinterpret_cast<int*>(smem + Cfg::OWN);
+    int* mine_s = own_s + TW_ROWS + 4;
+    double* loss_s = reinterpret_cast<double*>(smem + Cfg::LOSS);
+    float* wdw_s = reinterpret_cast<float*>(smem + Cfg::WDW);
+    int* flag_s = reinterpret_cast<int*>(smem + Cfg::FLAG);
+    (void)d_s; (void)dsum_s; (void)own_s; (void)mine_s; (void)loss_s; (void)wdw_s; (void)col_mean; (void)col_inv; (void)n_wg; (void)CSX;
+    const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+    const uint32_t thr16 = (uint32_t)(a.drop_p * 65536.f + 0.5f);
+    const bool relu = a.relu != 0;
+    const float drop_p = a.drop_p;
+    const bool masked = relu || keep_scale != 1.f;
+
+    if constexpr (PHASE == 1) {
+        // ---- Z1 = X W1^T + b1 -> z1; local chunk sums -> exchange[0]; the wide term of ALL this block's rows of tower 0's share...
+        const __bf16* xh = reinterpret_cast<const __bf16*>(T.xh) + (int64_t)row0 * T.ldxh;
+#pragma unroll
+        for (int s = 0; s < NK0; ++s) {
+            tw_load_tile(xh, T.ldxh, s, TW_ROWS, rows, OPA + s * TW_SLAB, wave, lane);
+            tw_load_tile(reinterpret_cast<const __bf16*>(T.l1.wh), T.l1.ldwh, s, H1, H1, OPB + s * H1 * 128, wave, lane);
+        }
+        if (tid < H1) par_s[TW_PAR_B1 + tid] = T.l1.bias[tid];
+        tw_drain();
+        __syncthreads();
+        {
+            f32x4_t acc[2][H1 / 16];
+            tw_mfma<H1 / 16, NK0 * 2>(OPA, OPB, H1 * 128, acc, wave, lane);
+            tw_acc_to_tile<H1 / 16>(acc, ct, CS1, wave, lane);
+        }
+        __syncthreads();
+        {
+            constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+            const int c = (tid % C8) * 8, lr0 = tid / C8;
+            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(par_s + TW_PAR_B1 + c), b1 = *reinterpret_cast<const f32x4_t*>(par_s + TW_PAR_B1 + c + 4);
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(ct + lr * CS1 + c) + b0, hi = *reinterpret_cast<const f32x4_t*>(ct + lr * CS1 + c + 4) + b1;
+                *reinterpret_cast<f32x4_t*>(ct + lr * CS1 + c) = lo;
+                *reinterpret_cast<f32x4_t*>(ct + lr * CS1 + c + 4) = hi;
+                if (lr < rows) {
+                    *reinterpret_cast<f32x4_t*>(T.l1.z + (int64_t)(row0 + lr) * T.l1.ldz + c) = lo;
+                    *reinterpret_cast<f32x4_t*>(T.l1.z + (int64_t)(row0 + lr) * T.l1.ldz + c + 4) = hi;
+                }
+            }
+        }
+        __syncthreads();
+        tw_fwd_chunk_sums<H1>(ct, CS1, row0, M, part, reinterpret_cast<double*>(wsb + L.st1), n_tower * H1, t * H1, wave, lane);
+        // the wide term of the block's rows t, t + n_tower, ... (read by phase 3 of every tower: a later launch)
+        if (has_wide) {
+            const int K4 = wide_K >> 2;
+            float* pub = reinterpret_cast<float*>(wsb + L.wide);
+            f32x4_t wv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wv[q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(a.wide_w + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const float wb = a.wide_bias ? a.wide_bias[0] : 0.f;
+            const int n_mine = (rows - t + n_tower - 1) / n_tower;
+            for (int i0 = wave; i0 < n_mine; i0 += 4 * 12) {             // twelve rows per round, their loads in flight together
+                f32x4_t xv[12][2];
+#pragma unroll
+                for (int b = 0; b < 12; ++b) {
+                    const int i = i0 + 4 * b;
+                    const int64_t gr = row0 + t + (int64_t)n_tower * (i < n_mine ? i : i0);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        xv[b][q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(a.wide_x + gr * a.ld_wide + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+                float sv[12];
+#pragma unroll
+                for (int b = 0; b < 12; ++b) {
+                    float s_ = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) s_ += (xv[b][q][0] * wv[q][0] + xv[b][q][1] * wv[q][1]) + (xv[b][q][2] * wv[q][2] + xv[b][q][3] * wv[q][3]);
+                    sv[b] = s_;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                    for (int b = 0; b < 12; ++b) sv[b] += __shfl_xor(sv[b], o, 64);
+#pragma unroll
+                for (int b = 0; b < 12; ++b) {
+                    const int i = i0 + 4 * b;
+                    if (lane == 0 && i < n_mine) pub[row0 + t + n_tower * i] = sv[b] + wb;
+                }
+            }
+        }
+        (void)tw_last_sums<H1>(hdr, TW_S(0, t), G, reinterpret_cast<const double*>(wsb + L.st1), (M + 63) / 64, n_tower * H1, t * H1, part, sums,
+                               flag_s, a.exchange[0], t, n_tower, M, tid);
+    }
+
+    if constexpr (PHASE == 2) {
+        // ---- global statistics of layer 1 -> A1 (bf16: operand image + global copy); Z2 = A1 W2^T + b2 -> z2; local sums -> exchange[1]
+        tw_load_tile(reinterpret_cast<const __bf16*>(T.l2.wh), T.l2.ldwh, 0, H2, H2, OPB, wave, lane);
+        if (tid < H1) { par_s[TW_PAR_G1 + tid] = T.l1.gamma[tid]; par_s[TW_PAR_BE1 + tid] = T.l1.beta[tid]; }
+        if (tid >= 64 && tid < 64 + H2) par_s[TW_PAR_B2 + tid - 64] = T.l2.bias[tid - 64];
+        tw_stats_from_exchange<H1>(a.exchange[0], t, n_tower, a.eps, a.momentum, writer, T.l1.save_mean, T.l1.save_invstd, T.l1.running_mean,
+                                   T.l1.running_var, T.l1.num_batches_tracked, col_mean, col_inv, sums, tid);
+        {
+            constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+            const int c8 = tid % C8, c = c8 * 8, lr0 = tid / C8;
+            const uint32_t seed32 = drop_p > 0.f ? g2_seed32(a.seed1, a.seed_offset_dev, 64 + t) : 0u;
+            __bf16* a1h = reinterpret_cast<__bf16*>(T.a1h);
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                const int lrc = min(lr, rows - 1);
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(T.l1.z + (int64_t)(row0 + lrc) * T.l1.ldz + c);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(T.l1.z + (int64_t)(row0 + lrc) * T.l1.ldz + c + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                tw_bn_apply8(v, col_mean, col_inv, par_s + TW_PAR_G1, par_s + TW_PAR_BE1, c, relu, drop_p, keep_scale, thr16, seed32, row0 + lr);
+                tw_put8(OPA, lr, c8, v);
+                if (lr < rows) {
+                    bf16x8_t h;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) h[q] = (__bf16)v[q];
+                    *reinterpret_cast<bf16x8_t*>(a1h + (int64_t)(row0 + lr) * T.lda1h + c) = h;
+                }
+            }
+        }
+        tw_drain();
+        __syncthreads();
+        {
+            f32x4_t acc[2][H2 / 16];
+            tw_mfma<H2 / 16, H1 / 32>(OPA, OPB, H2 * 128, acc, wave, lane);
+            tw_acc_to_tile<H2 / 16>(acc, ct, CS2, wave, lane);
+        }
+        __syncthreads();
+        {
+            constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+            const int c = (tid % C8) * 8, lr0 = tid / C8;
+            const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(par_s + TW_PAR_B2 + c), b1 = *reinterpret_cast<const f32x4_t*>(par_s + TW_PAR_B2 + c + 4);
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(ct + lr * CS2 + c) + b0, hi = *reinterpret_cast<const f32x4_t*>(ct + lr * CS2 + c + 4) + b1;
+                *reinterpret_cast<f32x4_t*>(ct + lr * CS2 + c) = lo;
+                *reinterpret_cast<f32x4_t*>(ct + lr * CS2 + c + 4) = hi;
+                if (lr < rows) {
+                    *reinterpret_cast<f32x4_t*>(T.l2.z + (int64_t)(row0 + lr) * T.l2.ldz + c) = lo;
+                    *reinterpret_cast<f32x4_t*>(T.l2.z + (int64_t)(row0 + lr) * T.l2.ldz + c + 4) = hi;
+                }
+            }
+        }
+        __syncthreads();
+        tw_fwd_chunk_sums<H2>(ct, CS2, row0, M, part, reinterpret_cast<double*>(wsb + L.st2), n_tower * H2, t * H2, wave, lane);
+        (void)tw_last_sums<H2>(hdr, TW_S(1, t), G, reinterpret_cast<const double*>(wsb + L.st2), (M + 63) / 64, n_tower * H2, t * H2, part, sums,
+                               flag_s, a.exchange[1], t, n_tower, M, tid);
+    }
+
+    if constexpr (PHASE == 3) {
+        // ---- global statistics of layer 2 -> A2 (fp32, written out); head + wide term + sigmoid -> out
+        if (tid < H2) { par_s[TW_PAR_G2 + tid] = T.l2.gamma[tid]; par_s[TW_PAR_BE2 + tid] = T.l2.beta[tid]; par_s[TW_PAR_WO + tid] = T.wo[tid]; }
+        if (tid == H2) par_s[TW_PAR_WO + H2] = T.bo ? T.bo[0] : 0.f;
+        tw_stats_from_exchange<H2>(a.exchange[1], t, n_tower, a.eps, a.momentum, writer, T.l2.save_mean, T.l2.save_invstd, T.l2.running_mean,
+                                   T.l2.running_var, T.l2.num_batches_tracked, col_mean, col_inv, sums, tid);
+        {
+            constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+            const int c = (tid % C8) * 8, lr0 = tid / C8;
+            const uint32_t seed32 = drop_p > 0.f ? g2_seed32(a.seed2, a.seed_offset_dev, 64 + t) : 0u;
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                const int lrc = min(lr, rows - 1);
+                const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(T.l2.z + (int64_t)(row0 + lrc) * T.l2.ldz + c);
+                const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(T.l2.z + (int64_t)(row0 + lrc) * T.l2.ldz + c + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                tw_bn_apply8(v, col_mean, col_inv, par_s + TW_PAR_G2, par_s + TW_PAR_BE2, c, relu, drop_p, keep_scale, thr16, seed32, row0 + lr);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ct[lr * CS2 + c + q] = v[q];
+                if (lr < rows) {
+                    *reinterpret_cast<f32x4_t*>(T.a2 + (int64_t)(row0 + lr) * T.lda2 + c) = f32x4_t{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4_t*>(T.a2 + (int64_t)(row0 + lr) * T.lda2 + c + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int lr = tid >> 1, hf = tid & 1;
+            const float* arow = ct + lr * CS2 + hf * (H2 / 2);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < H2 / 2; k += 4) {
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(arow + k);
+                const f32x4_t w = *reinterpret_cast<const f32x4_t*>(par_s + TW_PAR_WO + hf * (H2 / 2) + k);
+                acc += v[0] * w[0]; acc += v[1] * w[1]; acc += v[2] * w[2]; acc += v[3] * w[3];
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            if (hf == 0 && lr < rows) {
+                if (T.bo) acc += par_s[TW_PAR_WO + H2];
+                if (has_wide) acc += reinterpret_cast<const float*>(wsb + L.wide)[row0 + lr];
+                if (a.sigmoid) acc = 1.f / (1.f + expf(-acc));
+                a.out[(int64_t)(row0 + lr) * a.ld_out + t] = acc;
+            }
+        }
+    }
+
+    const bool bce = a.bce_y_i16 != nullptr || a.bce_y_f32 != nullptr;
+    if constexpr (PHASE == 4) {
+        // ---- logit gradients (BCE over the GLOBAL batch: bce_inv_count), dy2 = mask(a2) * d * wo -> scratch; local sums -> exchange[2];
+        //      head / wide weight-gradient partials and the wide term's input gradient (local sums: the arena all-reduce adds the ranks)
+        if (tid < H2) { par_s[TW_PAR_WO + tid] = T.wo[tid]; par_s[TW_PAR_B2 + tid] = T.l2.save_mean[tid]; par_s[TW_PAR_BE2 + tid] = T.l2.save_invstd[tid]; }
+        if (tid < TW_ROWS) {
+            float d_t = 0.f, dsum = 0.f;
+            int mine = 0;
+            double lp = 0.0;
+            if (tid < rows) {
+                const int64_t r = row0 + tid;
+                int own = 0;
+                float tgt = 0.f;
+                if (bce) {
+                    int64_t c = a.bce_group ? a.bce_group[r] : 0;
+                    if (c < 0 || c >= n_tower) c = 0;
+                    own = (int)c;
+                    tgt = a.bce_y_i16 ? (float)a.bce_y_i16[r] : a.bce_y_f32[r];
+                }
+                for (int tt = 0; tt < n_tower; ++tt) {
+                    const float o = a.out[r * a.ld_out + tt];
+                    float dout;
+                    if (bce) {
+                        if (tt == own) {
+                            lp = (double)((tgt - 1.f) * fmaxf(log1pf(-o), -100.f) - tgt * fmaxf(logf(o), -100.f));
+                            dout = a.bce_inv_count * (o - tgt) / fmaxf((1.f - o) * o, 1e-12f);
+                        } else dout = 0.f;
+                    } else dout = a.d_out[r * a.ld_dout + tt];
+                    const float d = a.sigmoid ? dout * o * (1.f - o) : dout;
+                    dsum += d;
+                    if (tt == t) d_t = d;
+                }
+                mine = (bce ? own : (int)(r % n_tower)) == t;
+            }
+            d_s[tid] = d_t; dsum_s[tid] = dsum;
+            loss_s[tid] = (t == 0) ? lp : 0.0;
+            mine_s[tid] = mine;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int base = 0;
+#pragma unroll
+            for (int h = 0; h < TW_ROWS / 64; ++h) {
+                const int flag = mine_s[h * 64 + lane];
+                const unsigned long long bal = __ballot(flag != 0);
+                if (flag) own_s[base + __popcll(bal & ((1ull << lane) - 1ull))] = h * 64 + lane;
+                base += __popcll(bal);
+            }
+            if (lane == 0) own_s[TW_ROWS] = base;
+        }
+        __syncthreads();
+        float* DZ2 = ct;
+        float* XH2 = ct + TW_ROWS * CS2;
+        float* A2T = ct + 2 * TW_ROWS * CS2;
+        {
+            constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+            const int c = (tid % C8) * 8, lr0 = tid / C8;
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                const int lrc = min(lr, rows - 1);
+                const bool live = lr < rows;
+                const f32x4_t zl = *reinterpret_cast<const f32x4_t*>(T.l2.z + (int64_t)(row0 + lrc) * T.l2.ldz + c);
+                const f32x4_t zh = *reinterpret_cast<const f32x4_t*>(T.l2.z + (int64_t)(row0 + lrc) * T.l2.ldz + c + 4);
+                const f32x4_t al = *reinterpret_cast<const f32x4_t*>(T.a2 + (int64_t)(row0 + lrc) * T.lda2 + c);
+                const f32x4_t ah = *reinterpret_cast<const f32x4_t*>(T.a2 + (int64_t)(row0 + lrc) * T.lda2 + c + 4);
+                const float d = d_s[lr];
+                float dzv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float zv = q < 4 ? zl[q] : zh[q - 4], av = live ? (q < 4 ? al[q] : ah[q - 4]) : 0.f;
+                    float dz = d * par_s[TW_PAR_WO + c + q];
+                    if (masked) dz = av > 0.f ? dz * keep_scale : 0.f;
+                    dzv[q] = dz;
+                    DZ2[lr * CS2 + c + q] = dz;
+                    XH2[lr * CS2 + c + q] = (zv - par_s[TW_PAR_B2 + c + q]) * par_s[TW_PAR_BE2 + c + q];
+                    A2T[lr * CS2 + c + q] = av;
+                }
+                if (live) {
+                    *reinterpret_cast<f32x4_t*>(T.dy2 + (int64_t)(row0 + lr) * T.lddy2 + c) = f32x4_t{dzv[0], dzv[1], dzv[2], dzv[3]};
+                    *reinterpret_cast<f32x4_t*>(T.dy2 + (int64_t)(row0 + lr) * T.lddy2 + c + 4) = f32x4_t{dzv[4], dzv[5], dzv[6], dzv[7]};
+                }
+            }
+        }
+        __syncthreads();
+        tw_block_sums<H2>(DZ2, XH2, CS2, rows, part, sums, tid);
+        {
+            double* b2 = reinterpret_cast<double*>(wsb + L.b2) + ((int64_t)jb * n_tower * H2 + t * H2) * 2;
+            if (tid < H2) { tw_st(b2 + 2 * tid, sums[tid]); tw_st(b2 + 2 * tid + 1, sums[H2 + tid]); }
+        }
+        {
+            constexpr int NPT = TW_THREADS / H2, RPP = TW_ROWS / NPT;
+            const int j = tid % H2, pt = tid / H2;
+            double s_ = 0.0, sb = 0.0;
+            for (int r = pt * RPP; r < min((pt + 1) * RPP, rows); ++r) { s_ += (double)(d_s[r] * A2T[r * CS2 + j]); sb += (double)d_s[r]; }
+            part[(0 * NPT + pt) * H2 + j] = s_; part[(1 * NPT + pt) * H2 + j] = sb;
+            __syncthreads();
+            float* hd = reinterpret_cast<float*>(wsb + L.hd) + ((int64_t)jb * n_tower + t) * (H2 + 4);
+            if (tid < H2) {
+                double b = 0.0;
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) b += part[(0 * NPT + q) * H2 + tid];
+                tw_st(hd + tid, (float)b);
+            } else if (tid == H2) {
+                double b = 0.0;
+#pragma unroll
+                for (int q = 0; q < NPT; ++q) b += part[(1 * NPT + q) * H2 + 0];
+                tw_st(hd + H2, (float)b);
+            }
+            if (t == 0 && wave == 1) {
+                double l_ = (lane < rows ? loss_s[lane] : 0.0) + (lane + 64 < rows ? loss_s[lane + 64] : 0.0);
+                l_ = wave_sum_d(l_);
+                if (lane == 0) reinterpret_cast<double*>(wsb + L.loss)[jb] = l_;         // read by phase 6 (a later launch)
+            }
+        }
+        if (has_wide) {
+            const int K4 = wide_K >> 2;
+            const int n_own = own_s[TW_ROWS];
+            f32x4_t wv[2], dwv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                wv[q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(a.wide_w + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                dwv[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            float dbv = 0.f;
+            const bool rmw = a.wide_dx && a.accumulate_wide_dx;
+            TwWideRound wr;
+            for (int i0 = wave; i0 < n_own; i0 += 4 * TW_WNB) {
+                tw_wide_load(wr, a.wide_x, a.ld_wide, own_s, dsum_s, n_own, i0, row0, K4, lane);
+                if (rmw) tw_wide_apply<true>(wr, a.wide_dx, a.ld_wide_dx, dsum_s, row0, n_own, i0, K4, wv, dwv, dbv, lane);
+                else tw_wide_apply<false>(wr, a.wide_dx, a.ld_wide_dx, dsum_s, row0, n_own, i0, K4, wv, dwv, dbv, lane);
+            }
+            float* mine = wdw_s + wave * 520;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if ((lane + 64 * q) < K4) *reinterpret_cast<f32x4_t*>(mine + 4 * (lane + 64 * q)) = dwv[q];
+            if (lane == 0) mine[wide_K] = dbv;
+            __syncthreads();
+            float* wd = reinterpret_cast<float*>(wsb + L.wd) + ((int64_t)t * G + jb) * L.wd_ld;
+            for (int k = tid; k <= wide_K; k += TW_THREADS)                                // plain stores: summed by phase 6, a later launch
+                wd[k] = ((wdw_s[k] + wdw_s[520 + k]) + wdw_s[2 * 520 + k]) + wdw_s[3 * 520 + k];
+        }
+        tw_drain();
+        __syncthreads();
+        if (tw_last_sums<H2>(hdr, TW_S(2, t), G, reinterpret_cast<const double*>(wsb + L.b2), G, n_tower * H2, t * H2, part, sums, flag_s,
+                             a.exchange[2], t, n_tower, M, tid)) {
+            // the tower's LOCAL parameter gradients: BatchNorm 2 (the sums just formed) and the head (block partials in block order)
+            if (tid < H2) {
+                if (T.l2.dbeta) T.l2.dbeta[tid] = (float)sums[tid];
+                if (T.l2.dgamma) T.l2.dgamma[tid] = (float)sums[H2 + tid];
+            }
+            for (int k = tid >> 3; k <= H2; k += TW_THREADS / 8) {
+                const int p8 = tid & 7;
+                const float* hd = reinterpret_cast<const float*>(wsb + L.hd) + (int64_t)t * (H2 + 4) + k;
+                float s_ = 0.f;
+                for (int b0 = p8; b0 < G; b0 += 8) s_ += tw_ld(hd + (int64_t)b0 * n_tower * (H2 + 4));
+                s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64);
+                if (p8 == 0) {
+                    if (k < H2) { if (T.dwo) T.dwo[k] = s_; }
+                    else if (T.dbo) T.dbo[0] = s_;
+                }
+            }
+        }
+    }
+
+    if constexpr (PHASE == 5) {
+        // ---- global sums of layer 2 -> dZ2 (bf16: operand image + global copy); dA1 = dZ2 W2; dy1 = mask(a1) * dA1 -> scratch;
+        //      local sums -> exchange[3]
+        tw_load_tile(reinterpret_cast<const __bf16*>(T.l2.wt), T.l2.ldwt, 0, H1, H1, OPB, wave, lane);
+        const double* ex = a.exchange[2];
+        const int Ms = (int)(ex[2 * n_tower * H2 + t] + 0.5);
+        const float invM = Ms > 0 ? 1.f / (float)Ms : 0.f;
+        if (tid < H2) {
+            const float inv = T.l2.save_invstd[tid];
+            par_s[TW_PAR_B2 + tid] = T.l2.save_mean[tid]; par_s[TW_PAR_G2 + tid] = T.l2.gamma[tid] * inv; par_s[TW_PAR_BE2 + tid] = inv;
+            col_mean[tid] = (float)ex[2 * (t * H2 + tid)]; col_inv[tid] = (float)ex[2 * (t * H2 + tid) + 1];     // db, dg of the global batch
+        }
+        if (tid >= 64 && tid < 64 + H1) { par_s[TW_PAR_B1 + tid - 64] = T.l1.save_mean[tid - 64]; par_s[TW_PAR_BE1 + tid - 64] = T.l1.save_invstd[tid - 64]; }
+        __syncthreads();
+        {
+            constexpr int C8 = H2 / 8, RPP = TW_THREADS / C8;
+            const int c8 = tid % C8, c = c8 * 8, lr0 = tid / C8;
+            __bf16* dzh = reinterpret_cast<__bf16*>(T.l2.dzh);
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                const int lrc = min(lr, rows - 1);
+                const f32x4_t zl = *reinterpret_cast<const f32x4_t*>(T.l2.z + (int64_t)(row0 + lrc) * T.l2.ldz + c);
+                const f32x4_t zh = *reinterpret_cast<const f32x4_t*>(T.l2.z + (int64_t)(row0 + lrc) * T.l2.ldz + c + 4);
+                const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(T.dy2 + (int64_t)(row0 + lrc) * T.lddy2 + c);
+                const f32x4_t dh = *reinterpret_cast<const f32x4_t*>(T.dy2 + (int64_t)(row0 + lrc) * T.lddy2 + c + 4);
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float xh = ((q < 4 ? zl[q] : zh[q - 4]) - par_s[TW_PAR_B2 + c + q]) * par_s[TW_PAR_BE2 + c + q];
+                    const float dz = lr < rows ? (q < 4 ? dl[q] : dh[q - 4]) : 0.f;
+                    v[q] = par_s[TW_PAR_G2 + c + q] * (dz - invM * (col_mean[c + q] + xh * col_inv[c + q]));
+                }
+                tw_put8(OPA, lr, c8, v);
+                if (lr < rows) {
+                    bf16x8_t h;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) h[q] = (__bf16)v[q];
+                    *reinterpret_cast<bf16x8_t*>(dzh + (int64_t)(row0 + lr) * T.l2.lddzh + c) = h;
+                }
+            }
+        }
+        tw_drain();
+        __syncthreads();
+        float* DZ1 = ct;
+        float* XH1 = ct + TW_ROWS * CS1;
+        {
+            f32x4_t acc[2][H1 / 16];
+            tw_mfma<H1 / 16, H2 / 32>(OPA, OPB, 0, acc, wave, lane);
+            tw_acc_to_tile<H1 / 16>(acc, DZ1, CS1, wave, lane);
+        }
+        __syncthreads();
+        {
+            constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+            const int c = (tid % C8) * 8, lr0 = tid / C8;
+            const __bf16* a1h = reinterpret_cast<const __bf16*>(T.a1h);
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                const int lrc = min(lr, rows - 1);
+                const f32x4_t zl = *reinterpret_cast<const f32x4_t*>(T.l1.z + (int64_t)(row0 + lrc) * T.l1.ldz + c);
+                const f32x4_t zh = *reinterpret_cast<const f32x4_t*>(T.l1.z + (int64_t)(row0 + lrc) * T.l1.ldz + c + 4);
+                const bf16x8_t m8 = *reinterpret_cast<const bf16x8_t*>(a1h + (int64_t)(row0 + lrc) * T.lda1h + c);
+                float dzv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float dz = DZ1[lr * CS1 + c + q];
+                    if (masked) dz = (float)m8[q] > 0.f ? dz * keep_scale : 0.f;
+                    if (lr >= rows) dz = 0.f;
+                    dzv[q] = dz;
+                    DZ1[lr * CS1 + c + q] = dz;
+                    XH1[lr * CS1 + c + q] = ((q < 4 ? zl[q] : zh[q - 4]) - par_s[TW_PAR_B1 + c + q]) * par_s[TW_PAR_BE1 + c + q];
+                }
+                if (lr < rows) {
+                    *reinterpret_cast<f32x4_t*>(T.dy1 + (int64_t)(row0 + lr) * T.lddy1 + c) = f32x4_t{dzv[0], dzv[1], dzv[2], dzv[3]};
+                    *reinterpret_cast<f32x4_t*>(T.dy1 + (int64_t)(row0 + lr) * T.lddy1 + c + 4) = f32x4_t{dzv[4], dzv[5], dzv[6], dzv[7]};
+                }
+            }
+        }
+        __syncthreads();
+        tw_block_sums<H1>(DZ1, XH1, CS1, rows, part, sums, tid);
+        {
+            double* b1 = reinterpret_cast<double*>(wsb + L.b1) + ((int64_t)jb * n_tower * H1 + t * H1) * 2;
+            if (tid < H1) { tw_st(b1 + 2 * tid, sums[tid]); tw_st(b1 + 2 * tid + 1, sums[H1 + tid]); }
+        }
+        tw_drain();
+        __syncthreads();
+        if (tw_last_sums<H1>(hdr, TW_S(3, t), G, reinterpret_cast<const double*>(wsb + L.b1), G, n_tower * H1, t * H1, part, sums, flag_s,
+                             a.exchange[3], t, n_tower, M, tid)) {
+            if (tid < H1) {
+                if (T.l1.dbeta) T.l1.dbeta[tid] = (float)sums[tid];
+                if (T.l1.dgamma) T.l1.dgamma[tid] = (float)sums[H1 + tid];
+            }
+        }
+    }
+
+    if constexpr (PHASE == 6) {
+        // ---- global sums of layer 1 -> dZ1 (bf16: operand image + global copy); dX = dZ1 W1 -> dx; the wide term's weight gradient and
+        //      the loss: sums over this rank's workgroups (partials of phase 4)
+        tw_load_tile(reinterpret_cast<const __bf16*>(T.l1.wt), T.l1.ldwt, 0, H0, H0, OPB, wave, lane);
+        const double* ex = a.exchange[3];
+        const int Ms = (int)(ex[2 * n_tower * H1 + t] + 0.5);
+        const float invM = Ms > 0 ? 1.f / (float)Ms : 0.f;
+        if (tid < H1) {
+            const float inv = T.l1.save_invstd[tid];
+            par_s[TW_PAR_B1 + tid] = T.l1.save_mean[tid]; par_s[TW_PAR_G1 + tid] = T.l1.gamma[tid] * inv; par_s[TW_PAR_BE1 + tid] = inv;
+            col_mean[tid] = (float)ex[2 * (t * H1 + tid)]; col_inv[tid] = (float)ex[2 * (t * H1 + tid) + 1];
+        }
+        __syncthreads();
+        {
+            constexpr int C8 = H1 / 8, RPP = TW_THREADS / C8;
+            const int c8 = tid % C8, c = c8 * 8, lr0 = tid / C8;
+            __bf16* dzh = reinterpret_cast<__bf16*>(T.l1.dzh);
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                const int lrc = min(lr, rows - 1);
+                const f32x4_t zl = *reinterpret_cast<const f32x4_t*>(T.l1.z + (int64_t)(row0 + lrc) * T.l1.ldz + c);
+                const f32x4_t zh = *reinterpret_cast<const f32x4_t*>(T.l1.z + (int64_t)(row0 + lrc) * T.l1.ldz + c + 4);
+                const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(T.dy1 + (int64_t)(row0 + lrc) * T.lddy1 + c);
+                const f32x4_t dh = *reinterpret_cast<const f32x4_t*>(T.dy1 + (int64_t)(row0 + lrc) * T.lddy1 + c + 4);
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float xh = ((q < 4 ? zl[q] : zh[q - 4]) - par_s[TW_PAR_B1 + c + q]) * par_s[TW_PAR_BE1 + c + q];
+                    const float dz = lr < rows ? (q < 4 ? dl[q] : dh[q - 4]) : 0.f;
+                    v[q] = par_s[TW_PAR_G1 + c + q] * (dz - invM * (col_mean[c + q] + xh * col_inv[c + q]));
+                }
+                tw_put8(OPA, lr, c8, v);
+                if (lr < rows) {
+                    bf16x8_t h;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) h[q] = (__bf16)v[q];
+                    *reinterpret_cast<bf16x8_t*>(dzh + (int64_t)(row0 + lr) * T.l1.lddzh + c) = h;
+                }
+            }
+        }
+        tw_drain();
+        __syncthreads();
+        {
+            f32x4_t acc[2][H0 / 16];
+            tw_mfma<H0 / 16, H1 / 32>(OPA, OPB, 0, acc, wave, lane);
+            tw_acc_to_tile<H0 / 16>(acc, ct, CSX, wave, lane);
+        }
+        __syncthreads();
+        if (T.dx) {
+            constexpr int C8 = H0 / 8, RPP = TW_THREADS / C8;
+            const int c = (tid % C8) * 8, lr0 = tid / C8;
+            const bool accx = T.accumulate_dx != 0;
+#pragma unroll
+            for (int lr = lr0; lr < TW_ROWS; lr += RPP) {
+                if (lr >= rows) break;
+                f32x4_t lo = *reinterpret_cast<const f32x4_t*>(ct + lr * CSX + c), hi = *reinterpret_cast<const f32x4_t*>(ct + lr * CSX + c + 4);
+                float* dst = T.dx + (int64_t)(row0 + lr) * T.lddx + c;
+                if (accx) { lo = *reinterpret_cast<const f32x4_t*>(dst) + lo; hi = *reinterpret_cast<const f32x4_t*>(dst + 4) + hi; }
+                *reinterpret_cast<f32x4_t*>(dst) = lo;
+                *reinterpret_cast<f32x4_t*>(dst + 4) = hi;
+            }
+        }
+        if (has_wide) {
+            const float* wd = reinterpret_cast<const float*>(wsb + L.wd);
+            for (int k = (int)blockIdx.x * 4 + wave; k <= wide_K; k += n_wg * 4) {
+                float s_ = 0.f;
+                for (int p = lane; p < n_wg; p += 64) s_ += wd[(int64_t)p * L.wd_ld + k];
+                s_ = wave_sum(s_);
+                if (lane == 0) {
+                    if (k < wide_K) { if (a.wide_dw) a.wide_dw[k] = s_; }
+                    else if (a.wide_dbias) a.wide_dbias[0] = s_;
+                }
+            }
+        }
+        if (bce && blockIdx.x == 0 && wave == 1 && a.bce_loss) {
+            const double* lp = reinterpret_cast<const double*>(wsb + L.loss);
+            double s_ = 0.0;
+            for (int b = lane; b < G; b += 64) s_ += lp[b];
+            s_ = wave_sum_d(s_);
+            if (lane == 0) *a.bce_loss = (float)(s_ * (double)a.bce_inv_count);
+        }
+    }
+}
+
+// =================================================================================================
 // host
 // =================================================================================================
-static int tower_check(const cdc_tower_args* a, const char* who, bool bwd) {
+static int tower_check(const cdc_tower_args* a, const char* who, bool bwd, int min_rows = 2) {
     CDC_CHECK_ARG(a && a->n_tower > 0 && a->n_tower <= CDC_TOWER_MAX, CDC_E_BADARG, "%s: bad tower count", who);
     CDC_CHECK_ARG((a->H0 == 64 || a->H0 == 128) && a->H1 == 64 && a->H2 == 32, CDC_E_BADARG,
                   "%s: instantiated for H0 in {64,128}, H1 = 64, H2 = 32 (got %d, %d, %d)", who, a->H0, a->H1, a->H2);
-    CDC_CHECK_ARG(a->M >= 2, CDC_E_BADARG, "%s: needs at least two rows (a batch of one skips BatchNorm: use the unfused launches)", who);
+    CDC_CHECK_ARG(a->M >= min_rows, CDC_E_BADARG, "%s: needs at least two rows (a batch of one skips BatchNorm: use the unfused launches)", who);
     const int64_t G = cdc_ceil_div(a->M, TW_ROWS);
     CDC_CHECK_ARG(a->n_tower * G <= 256, CDC_E_TOOBIG, "%s: %lld workgroups cannot all be resident (one per CU)", who, (long long)(a->n_tower * G));
     CDC_CHECK_ARG(a->drop_p >= 0.f && a->drop_p < 1.f, CDC_E_BADARG, "%s: dropout p out of range", who);
@@ -1185,5 +1809,34 @@ extern "C" int cdc_tower_bwd(const cdc_tower_args* a, void* stream) {
     if (a->H0 == 64) hipLaunchKernelGGL((k_tower_bwd<1, 64, 32>), dim3(grid), dim3(TW_THREADS), lds1, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((k_tower_bwd<2, 64, 32>), dim3(grid), dim3(TW_THREADS), lds2, (hipStream_t)stream, *a);
     CDC_LAUNCH_CHECK("tower_bwd");
+    return 0;
+}
+
+template <int NK0, int PHASE>
+static void tower_dp_launch(const cdc_tower_args* a, unsigned grid, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) { tower_attr(k_tower_dp<NK0, 64, 32, PHASE>, TwDpCfg::SMEM); attr_done = true; }
+    constexpr int lds = TwDpCfg::SMEM;
+    hipLaunchKernelGGL((k_tower_dp<NK0, 64, 32, PHASE>), dim3(grid), dim3(TW_THREADS), lds, st, *a);
+}
+extern "C" int cdc_tower_dp(const cdc_tower_args* a, int32_t phase, void* stream) {
+    CDC_CHECK_ARG(phase >= 1 && phase <= 6, CDC_E_BADARG, "tower_dp: phase must be 1..6");
+    const int rc = tower_check(a, "tower_dp", phase >= 4, 1);        // (the GLOBAL batch decides about BatchNorm; a rank may hold one row)
+    if (rc) return rc;
+    for (int e = 0; e < 4; ++e) CDC_CHECK_ARG(a->exchange[e] && (((uintptr_t)a->exchange[e]) & 7) == 0, CDC_E_BADARG, "tower_dp: exchange buffer %d", e);
+    if (phase >= 4) {
+        const bool bce = a->bce_y_i16 || a->bce_y_f32;
+        CDC_CHECK_ARG(bce || a->d_out, CDC_E_BADARG, "tower_dp: needs the output gradient or the fused loss");
+        CDC_CHECK_ARG(!bce || (a->sigmoid && a->bce_loss && a->bce_inv_count > 0.f), CDC_E_BADARG, "tower_dp: the fused BCE needs sigmoid outputs and a loss pointer");
+        for (int t = 0; t < a->n_tower; ++t)
+            CDC_CHECK_ARG(a->t[t].dy2 && a->t[t].dy1 && (((uintptr_t)a->t[t].dy2 | (uintptr_t)a->t[t].dy1) & 15) == 0 && a->t[t].lddy2 % 4 == 0 &&
+                              a->t[t].lddy1 % 4 == 0, CDC_E_BADARG, "tower_dp: tower %d gradient scratch", t);
+    }
+    const unsigned grid = (unsigned)(a->n_tower * cdc_ceil_div(a->M, TW_ROWS));
+    hipStream_t st = (hipStream_t)stream;
+#define TW_DP(P) case P: if (a->H0 == 64) tower_dp_launch<1, P>(a, grid, st); else tower_dp_launch<2, P>(a, grid, st); break;
+    switch (phase) { TW_DP(1) TW_DP(2) TW_DP(3) TW_DP(4) TW_DP(5) TW_DP(6) }
+#undef TW_DP
+    CDC_LAUNCH_CHECK("tower_dp");
     return 0;
 }

@@ -39,6 +39,7 @@ class DataParallel:
             else:
                 dist.init_process_group(backend, rank=self.rank, world_size=self.world_size)
         self.device = device
+        self._on_close = []               # callbacks run before the process group goes (graphs that captured collectives must go first)
 
     def _staged(self, t):
         """gloo moves host memory: device tensors are staged through the CPU (rehearsal / tests only; RCCL is direct)."""
@@ -117,6 +118,18 @@ class DataParallel:
         per = n // self.world_size
         return self.rank * per, (self.rank + 1) * per
 
+    @property
+    def capturable(self):
+        """collectives of this backend can be captured into a hipGraph together with the launches around them (RCCL: yes — round 4
+        measured capture and replay of all-reduce / all-to-all on this stack; the host-staged gloo rehearsal: no)"""
+        return self.active and self.backend == "nccl"
+
     def close(self):
         if self.active and dist.is_initialized():
+            # a live graph that captured a collective makes destroy_process_group() hang (PyTorch 2.10 / RCCL of ROCm 7: the
+            # "capture never returns" of rounds 2-3 was this): release them first
+            for fn in self._on_close:
+                fn()
+            self._on_close.clear()
+            torch.cuda.synchronize() if torch.cuda.is_available() else None
             dist.destroy_process_group()

@@ -1826,7 +1826,9 @@ class TowerChain:
         if not (isinstance(l1, GLinear) and isinstance(b1, BatchNorm) and isinstance(l2, GLinear) and isinstance(b2, BatchNorm) and
                 isinstance(head, TowerHead)):
             return False
-        if not (plan.use_g2 and plan.training and plan.dist is None and plan.B >= 2):
+        # data parallel with global-batch statistics (plan.dist): the split form, cdc_tower_dp — six phases with the BatchNorm sums
+        # all-reduced between them; a rank's share may be a single row there (the GLOBAL batch decides about BatchNorm)
+        if not (plan.use_g2 and plan.training and (plan.B >= 2 or plan.dist is not None)):
             return False
         n = len(head.towers)
         if not (0 < n <= L.TOWER_MAX and n * math.ceil(plan.B / L.TOWER_ROWS) <= 256):
@@ -1927,6 +1929,26 @@ class TowerChain:
             raise RuntimeError("cdc_tower_workspace_bytes refused the argument block")
         return n
 
+    def _dp_buffers(self, a, plan):
+        """the split form's exchange buffers ([2 n C column sums | n row counts] doubles per exchange) and gradient scratch"""
+        if getattr(self, "_ex", None) is None:
+            n = self.n
+            self._ex = [torch.zeros(2 * n * c + n, dtype=torch.float64, device=plan.device) for c in (self.H1, self.H2, self.H2, self.H1)]
+            self._dy2, self._dy1 = plan.new(n * self.H2), plan.new(n * self.H1)
+        for e in range(4):
+            a.exchange[e] = self._ex[e].data_ptr()
+        for i in range(self.n):
+            T = a.t[i]
+            y2, y1 = self._dy2.slice(i * self.H2, (i + 1) * self.H2), self._dy1.slice(i * self.H1, (i + 1) * self.H1)
+            T.dy2, T.lddy2, T.dy1, T.lddy1 = y2.ptr, y2.ld, y1.ptr, y1.ld
+
+    def _dp_steps(self, plan, a, phases, exchanges, steps, flops):
+        for k, ph in enumerate(phases):
+            steps.append(plan.call("cdc_tower_dp", C.byref(a), ph, what=f"cdc_tower_dp({ph})", flops=flops if k == 0 else 0.0))
+            if k < len(exchanges):
+                ex = self._ex[exchanges[k]]
+                steps.append(plan.comm(lambda ex=ex: plan.dist.all_reduce_sum(ex)))
+
     def build_fwd(self, plan):
         plan.ensure_shadows([g["x"] for g in self.l1.groups], plan.fwd_steps)
         a = L.TowerArgs()
@@ -1935,6 +1957,11 @@ class TowerChain:
             plan.mark_shadow(s["y"])
         self._keep.append(a)
         fl = sum(2.0 * plan.B * g["w"].shape[0] * g["w"].shape[1] for g in self.l1.groups + self.l2.groups)
+        if plan.dist is not None:
+            # global-batch BatchNorm statistics: phases 1 | all-reduce | 2 | all-reduce | 3 (csrc/tower.hip cdc_tower_dp)
+            self._dp_buffers(a, plan)
+            self._dp_steps(plan, a, (1, 2, 3), (0, 1), plan.fwd_steps, fl)
+            return
         step = plan.call("cdc_tower_fwd", C.byref(a), flops=fl)
         self._fwd_calls = [step]
         plan.fwd_steps.append(step)
@@ -1983,7 +2010,11 @@ class TowerChain:
         self._keep.append(a)
         self.bwd_args = [a]                      # (trainer: the fused BCE is switched on in this launch)
         fl = sum(2.0 * plan.B * g["w"].shape[0] * g["w"].shape[1] for g in self.l1.groups + self.l2.groups)
-        plan.bwd_steps.append(plan.call("cdc_tower_bwd", C.byref(a), flops=fl))
+        if plan.dist is not None:
+            self._dp_buffers(a, plan)
+            self._dp_steps(plan, a, (4, 5, 6), (2, 3), plan.bwd_steps, fl)
+        else:
+            plan.bwd_steps.append(plan.call("cdc_tower_bwd", C.byref(a), flops=fl))
         # the grad-weight contractions of both layers: batched launch at the end of backward (operands: the shadows written above)
         for lin in (self.l2, self.l1):
             lin.skip_bwd_x = True

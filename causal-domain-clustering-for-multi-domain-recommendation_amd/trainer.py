@@ -84,6 +84,8 @@ class TrainStep:
         self.use_graph = use_graph
         self.graph = None
         self._stage_graphs = {}
+        self._step_graphs = {}            # data parallel over RCCL: the whole step (launches + collectives) as one graph per sequence
+        self._one_graph_ok = None
         self._dp_seq = None
         self._warm = 0
         self._reg_checked = False
@@ -380,6 +382,14 @@ class TrainStep:
         two waves per SIMD, lowest priority, table update behind a single join: 0.515."""
         return self._overlap_ok
 
+    def _drop_graphs(self):
+        """releases every captured graph (before the process group is destroyed: DataParallel.close)"""
+        self._step_graphs.clear()
+        self._stage_graphs.clear()
+        self.graph = None
+        if hasattr(self, "_graphs"):
+            self._graphs.clear()
+
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -590,6 +600,36 @@ class TrainStep:
             if self._dp_seq is None:
                 self._dp_seq = self._dp_sequence_sharded() if self.table_dist == "sharded" else self._dp_sequence()
             seq = self._dp_seq
+        if self.use_graph and self._warm >= 2 and self._one_graph_ok is not False and getattr(self.dist, "capturable", False):
+            # ONE graph for the whole step, collectives included (round 4: RCCL collectives capture and replay on this stack; what hung
+            # in rounds 2-3 was destroy_process_group() with such a graph alive — DataParallel.close() releases them first).  The
+            # five-segment cut (launch segments replayed, collectives issued by the host in between) is the fallback
+            g = self._step_graphs.get(key)
+            if g is None:
+                g = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        for _, fns in seq:
+                            for fn in fns:
+                                fn()
+                        # an exchange started for the NEXT step (look-ahead ids) has to be joined inside the graph that started it
+                        self.dist.wait(self.__dict__.pop("_ids_pending", None))
+                except Exception as e:  # noqa: BLE001
+                    import warnings
+                    warnings.warn(f"hipGraph capture of the whole data-parallel step failed ({e}); falling back to launch segments")
+                    torch.cuda.synchronize()
+                    self._one_graph_ok = False
+                    self.__dict__.pop("_ids_pending", None)
+                    g = None
+                else:
+                    if self._one_graph_ok is None:
+                        self._one_graph_ok = True
+                        self.dist._on_close.append(self._drop_graphs)
+                    self._step_graphs[key] = g
+            if g is not None:
+                g.replay()
+                self._warm += 1
+                return
         for i, (is_comm, fns) in enumerate(seq):
             if is_comm or not (self.use_graph and self._warm >= 2):
                 for fn in fns:

@@ -797,6 +797,8 @@ typedef struct {
     float* a2; int64_t lda2;              /* [M, H2] fp32 second hidden activation (forward -> backward) */
     const float* wo; const float* bo;     /* output Linear(H2 -> 1): [H2], [1] or NULL */
     float* dwo; float* dbo;               /* backward: [H2], [1] (may be NULL) */
+    float* dy2; int64_t lddy2;            /* cdc_tower_dp only: [M, H2] / [M, H1] fp32 scratch — the masked gradient w.r.t. a BatchNorm's */
+    float* dy1; int64_t lddy1;            /* output, handed from one phase to the next */
 } cdc_tower_desc;
 typedef struct {
     int32_t n_tower, H0, H1, H2;
@@ -822,11 +824,21 @@ typedef struct {
     int32_t pad2_;
     void* workspace;                      /* >= cdc_tower_workspace_bytes(), zeroed once */
     int32_t* err;                         /* device word that receives CDC_TOWER_ERR_TIMEOUT (may be NULL) */
+    double* exchange[4];                  /* cdc_tower_dp only: per exchange [2 * n_tower * C column sums | n_tower row counts] doubles
+                                             (C = H1, H2, H2, H1): written by the phase in front of it, summed over the ranks by the caller */
     cdc_tower_desc t[CDC_TOWER_MAX];
 } cdc_tower_args;
 int64_t cdc_tower_workspace_bytes(const cdc_tower_args* a);
 int cdc_tower_fwd(const cdc_tower_args* a, void* stream);
 int cdc_tower_bwd(const cdc_tower_args* a, void* stream);
+/* The same towers under DATA PARALLELISM with global-batch BatchNorm statistics (the reference's single process sees the global
+ * batch): the two launches cut at their four exchange points into six phases — 1, 2, 3 forward; 4, 5, 6 backward.  Phases 1, 2, 4, 5
+ * end with the LOCAL column sums of the statistics the next phase needs in exchange[0..3] (the last workgroup of a tower to finish
+ * adds the tower's partials up, in cdc_bn_fwd's order; nobody waits inside a launch); the caller sums each exchange buffer over
+ * the ranks (all-reduce) before the next phase, which normalises with the GLOBAL sums and row count.  Parameter gradients stay
+ * local sums (the data-parallel all-reduce of the gradient arena adds the ranks).  Same arithmetic as cdc_tower_fwd / _bwd;
+ * a one-rank run gives their results.  M is this rank's row count (may differ between ranks). */
+int cdc_tower_dp(const cdc_tower_args* a, int32_t phase, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Loss (reference: run.py:484,723 — BCELoss(mean) on probabilities gathered by group column,

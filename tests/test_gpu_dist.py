@@ -55,6 +55,11 @@ def _build(kind, dev):
         cfg = types.SimpleNamespace(ple_n_expert_specific=2, ple_n_expert_shared=2, dataset_name="t", use_atten=False, use_dcn=False)
         cdc = CDC(FD, 32, 4, 30, "ple", ((32, 16), (8,)), (8, 4), 0, n_causal_mask=2, device=dev, dropout=0.0, config=cfg)
         return cdc.base_model_instance.to(dev).set_precision("f32"), "multi"
+    if kind == "ple64":
+        # PLE whose towers have the reference's widths (64 -> 64 -> 32 -> 1, config.py:39-42) in bf16: the towers run as the fused
+        # launches (csrc/tower.hip) — split into six phases around the BatchNorm all-reduces under data parallelism
+        from cdcmdr_amd.model.ple import PLE
+        return PLE(FD, D, 3, 1, 1, ((32,), (64,)), (64, 32), dropout=0.0).to(dev).set_precision("bf16"), "multi"
     if kind == "star":
         from cdcmdr_amd.model.star import STAR
         return STAR(FD, D, 3, (32, 16), domain_idx=4, dropout=0.0).to(dev).set_precision("f32"), "star"
@@ -100,6 +105,8 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_
     torch.manual_seed(5)
     model, mode = _build(kind, dev)
     opt = FusedAdam(model, table_mode=table_mode, flush_every=2)
+    if kind == "ple64":
+        from cdcmdr_amd import plan as P
     ts = TrainStep(model, opt, B_LOCAL, mode=mode, use_graph=use_graph, dist=dp, table_dist=table_dist, sync_bn=sync_bn,
                    sort_ahead="force" if os.environ.get("CDC_TEST_AHEAD_FORCE") == "1" else True)
     assert ts.table_dist == (table_dist or ("sharded" if table_mode == "lazy" else "replicated"))
@@ -123,6 +130,10 @@ def _worker(rank, world, port, out_dir, table_mode, use_graph, table_dist, sync_
         losses.append(float(bce.item()))
     if ahead and table_dist == "sharded" and table_mode == "lazy":
         assert ts._ahead_dp_ok and len(ts._dp_seqs) >= 3, "the look-ahead sequences were not used"
+    if kind == "ple64":
+        assert any(isinstance(op, P.TowerChain) for op in ts.plan.ops), "the fused tower launches were not chosen"
+    if backend == "nccl" and use_graph:
+        assert ts._one_graph_ok is True and ts._step_graphs, "the step was not captured as ONE graph with its collectives"
     if os.environ.get("CDC_TEST_RAGGED") == "1":
         # the epoch's ragged tail, split as data.DeviceLoader splits it: rank r gets base + (r < rem) rows
         Xr, yr, gr = _ragged_batch(world)
@@ -211,6 +222,34 @@ def test_ranks_train_the_ragged_last_batch_like_one_rank(cuda, tmp_path, monkeyp
             continue
         atol = 6e-4 if k.endswith("running_mean") else 2e-5
         assert_close(rs[0]["sd"][k], v, 5e-4, atol, f"{world}-rank vs 1-rank with a ragged last batch: {k}")
+
+
+@pytest.mark.parametrize("world,use_graph", [(2, False), (3, True)])
+def test_ranks_with_the_fused_towers_split_around_the_batchnorm_exchanges(cuda, tmp_path, world, use_graph):
+    """Global-batch BatchNorm statistics under data parallelism with the towers as fused launches (round 4): cdc_tower_dp runs the
+    two launches of csrc/tower.hip as six phases, the local column sums of every BatchNorm all-reduced between them.  Replicas
+    identical; and equal — up to the summation order of the statistics and what a bf16 rounding that falls the other way does over
+    four Adam steps — to ONE rank running the monolithic launches (in-launch exchange) on the concatenated batches."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "lazy", use_graph, "sharded", True, "ple64"), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    for r in rs[1:]:
+        assert r["losses"] == rs[0]["losses"] and all(np.isfinite(r["losses"]))
+        for k in rs[0]["sd"]:
+            assert torch.equal(rs[0]["sd"][k], r["sd"][k]), f"replicas diverged in {k}"
+    from helpers import assert_close, is_pre_bn_bias
+    ref_sd, ref_losses = _single_process_reference("lazy", kind="ple64", world=world)
+    print("losses", rs[0]["losses"], ref_losses)
+    for a, b in zip(rs[0]["losses"], ref_losses):
+        assert abs(a - b) < 1e-5, (rs[0]["losses"], ref_losses)       # (measured: identical with 2 ranks, 6e-8 with 3)
+    names = set(ref_sd)
+    worst = 0.0
+    for k, v in ref_sd.items():
+        if is_pre_bn_bias(k, names) or "num_batches" in k:
+            continue
+        d = float((rs[0]["sd"][k].double() - v.double()).abs().max())
+        worst = max(worst, d)
+        assert d < 2e-4, f"{world}-rank split towers vs 1-rank monolithic towers: {k}: {d:.3e}"     # (measured 1e-7 / 6e-6)
+    print(f"worst parameter difference after {STEPS} steps: {worst:.2e}")
 
 
 def test_two_ranks_cdc_ple_row_sharded_equals_one_rank(cuda, tmp_path, monkeypatch):
@@ -331,11 +370,28 @@ def test_one_rank_through_rccl_with_the_id_exchange_one_step_ahead(cuda, tmp_pat
     test_one_rank_through_rccl(cuda, tmp_path, "sharded", True)
 
 
+def test_one_rank_through_rccl_with_the_split_fused_towers(cuda, tmp_path):
+    """cdc_tower_dp's six phases and the four BatchNorm all-reduces between them, issued through RCCL (forced one-rank group) and
+    captured with every other launch and collective of the step in ONE graph: equal to the single-process step with the monolithic
+    tower launches."""
+    mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), "lazy", True, "sharded", True, "ple64", "nccl", True), nprocs=1, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    ref_sd, ref_losses = _single_process_reference("lazy", kind="ple64", world=1)
+    for a, b in zip(r0["losses"], ref_losses):
+        assert abs(a - b) < 1e-5, (r0["losses"], ref_losses)
+    from helpers import is_pre_bn_bias
+    for k, v in ref_sd.items():
+        if is_pre_bn_bias(k, set(ref_sd)) or "num_batches" in k:
+            continue
+        assert float((r0["sd"][k].double() - v.double()).abs().max()) < 2e-4, k
+
+
 @pytest.mark.parametrize("table_dist,use_graph", [("sharded", True), ("sharded", False), ("replicated", True)])
 def test_one_rank_through_rccl(cuda, tmp_path, table_dist, use_graph):
     """The collective call path itself over RCCL ("nccl" backend): a forced one-rank process group issues every all-to-all /
-    all-reduce / all-gather of the data-parallel step on the communicator's stream (async row-gradient exchange, launch
-    segments between the collectives replayed as graphs).  With one rank the step must equal the single-process step."""
+    all-reduce / all-gather of the data-parallel step on the communicator's stream (async row-gradient exchange); with use_graph the
+    whole step — launches AND collectives — is captured and replayed as ONE graph (round 4; the worker asserts it).  With one rank
+    the step must equal the single-process step."""
     mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), "lazy", use_graph, table_dist, True, "mmoe", "nccl", True), nprocs=1, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
     from helpers import assert_close, is_pre_bn_bias

@@ -35,7 +35,7 @@ names = {0: "tiles issued", 1: "tiles landed", 2: "L1 done, stats published, arr
 for rep in range(6):
     ts.step(X, y, g)
     torch.cuda.synchronize()
-    st = chain.ws[2048:2048 + 32 * 8].view(torch.int64).cpu().numpy()
+    st = chain.ws[4096:4096 + 32 * 8].view(torch.int64).cpu().numpy()
     if rep < 3:
         continue
     for lo, hi, what in ((0, 16, "forward"), (16, 32, "backward")):
