@@ -126,8 +126,11 @@ def cpu_baseline(args, model, field_dims, Xc, yc, gc):
 class Loopback:
     """--simulate-world: the DataParallel interface with every collective a local copy."""
 
+    capturable = True                 # local copies: the whole step is captured as ONE graph, as over RCCL
+
     def __init__(self, world):
         self.world_size, self.rank, self.backend = world, 0, "loopback"
+        self._on_close = []
 
     def all_reduce_sum(self, t):
         return t

@@ -458,6 +458,11 @@ class TrainStep:
         lib = self.lib
         bufs = (self.recv_ids, self.recv_ids_alt)
         recv_cur, recv_nxt = bufs[p], bufs[1 - p]
+        # round 4: with the whole step in ONE graph (or issued eagerly) a second chain can run beside the dense one, as on one GPU:
+        # the owner's replay slice (capped, lowest priority) from the catch-up to the row update, and the next batch's sort and
+        # bucketing beside the grad-weight launches.  Launch SEGMENTS cannot hold a fork in one and its join in another: there
+        # (gloo rehearsal with graphs, or after a refused capture) everything stays on the one chain
+        side_ok = self._overlap_ok and (not self.use_graph or (getattr(dp, "capturable", False) and self._one_graph_ok is not False))
 
         def st():
             return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -476,6 +481,11 @@ class TrainStep:
 
         def serve():
             opt.table_catchup_rows(recv_cur, Bv, F, D, "owner", runs=N, flush=False)   # each sender's list is sorted
+            if side_ok:                               # the slice of the owned rows in the background, until the row update
+                main, side = torch.cuda.current_stream(), self._side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    opt.flush_slice(background_waves=self._overlap_waves)
             L.launch("cdc_embed_gather_fwd(owner)", lib.cdc_embed_gather_fwd,
                      (recv_cur.data_ptr(), self.zero_offsets.data_ptr(), opt.table.data_ptr(), self.rows_send.data_ptr(),
                       None, None, Bv, F, D, opt.table.shape[0]), st())
@@ -513,10 +523,23 @@ class TrainStep:
             dp.wait(self.__dict__.pop("_ids_pending", None))
 
         def update():
+            if side_ok:
+                torch.cuda.current_stream().wait_stream(self._side_stream())      # the slice (and the look-ahead sort) are done
             opt.table_step(recv_cur, self.grads_recv, Bv, F, D, "owner", short_segments=True)
-            opt.flush_slice()                           # off the rows-exchange critical path: after the owner's update
+            if not side_ok:
+                opt.flush_slice()                       # off the rows-exchange critical path: after the owner's update
             opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
             self._reg()
+
+        def stage0_next_side():
+            # the next batch's sort + bucketing beside the grad-weight launches (its workspaces are free once `pack` has run)
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sort_bucket(self.ids_next, begin=False)
+
+        def join_side():
+            torch.cuda.current_stream().wait_stream(self._side_stream())
 
         def run_steps(steps):
             def fn():
@@ -537,9 +560,13 @@ class TrainStep:
         late = set(id(s_) for s_ in plan.deferred_dw_steps)
         for is_comm, steps in plan.segments([s_ for s_ in plan.bwd_steps if id(s_) not in late]):
             seq.append((is_comm, run_steps(steps)))
-        seq += [(False, pack), (True, exchange_rows_start), (False, run_steps(plan.deferred_dw_steps))]
-        if prefetch:
-            seq.append((False, stage0_next))
+        if prefetch and side_ok:
+            seq += [(False, pack), (False, stage0_next_side), (True, exchange_rows_start), (False, run_steps(plan.deferred_dw_steps)),
+                    (False, join_side)]
+        else:
+            seq += [(False, pack), (True, exchange_rows_start), (False, run_steps(plan.deferred_dw_steps))]
+            if prefetch:
+                seq.append((False, stage0_next))
         seq += [(True, exchange_finish), (False, update)]
         merged = []
         for is_comm, fn in seq:
@@ -588,18 +615,23 @@ class TrainStep:
             prefetch = nx is not None                                   #  buffer is simply overwritten by the next one)
             p = self._parity
             key = (have, prefetch, p)
-            seq = self._dp_seqs.get(key)
-            if seq is None:
-                seq = self._dp_seqs[key] = self._dp_sequence_sharded(ahead=True, have=have, prefetch=prefetch, p=p)
             if prefetch:
                 self._parity = 1 - p
                 self._sorted_for = (nx.data_ptr(), nx._version, nx)
             else:
                 self._sorted_for = None
-        else:
+
+        def sequence():
+            if key is not None:
+                seq = self._dp_seqs.get(key)
+                if seq is None:
+                    seq = self._dp_seqs[key] = self._dp_sequence_sharded(ahead=True, have=key[0], prefetch=key[1], p=key[2])
+                return seq
             if self._dp_seq is None:
                 self._dp_seq = self._dp_sequence_sharded() if self.table_dist == "sharded" else self._dp_sequence()
-            seq = self._dp_seq
+            return self._dp_seq
+
+        seq = sequence()
         if self.use_graph and self._warm >= 2 and self._one_graph_ok is not False and getattr(self.dist, "capturable", False):
             # ONE graph for the whole step, collectives included (round 4: RCCL collectives capture and replay on this stack; what hung
             # in rounds 2-3 was destroy_process_group() with such a graph alive — DataParallel.close() releases them first).  The
@@ -621,6 +653,11 @@ class TrainStep:
                     self._one_graph_ok = False
                     self.__dict__.pop("_ids_pending", None)
                     g = None
+                    # the sequences were built with a side chain, which launch segments cannot hold: build them again without
+                    self._dp_seq = None
+                    if hasattr(self, "_dp_seqs"):
+                        self._dp_seqs.clear()
+                    seq = sequence()
                 else:
                     if self._one_graph_ok is None:
                         self._one_graph_ok = True
