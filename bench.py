@@ -58,6 +58,8 @@ def parse():
                     help="1: the reference's default attention branch (config.py:24-28: 3 x MultiheadAttention(64, 2 heads) + residual) "
                          "on top of the BASELINE configuration, which is defined without it")
     ap.add_argument("--flush-every", type=int, default=64, help="lazy table: the whole table is replayed once per this many steps")
+    ap.add_argument("--rows-dense-one-launch", type=int, default=1, help="0: the step's row update and the dense Adam as two launches (A/B only)")
+    ap.add_argument("--tower-one-launch", type=int, default=1, help="0: the fused towers as two launches, forward and backward (A/B only)")
     ap.add_argument("--fuse-towers", type=int, default=1, help="0: the towers as the five launches per direction the fused launch replaces (A/B only)")
     ap.add_argument("--pool", type=int, default=0,
                     help="resident synthetic batches cycled through; 0 = warmup+steps (max 1024), so that no batch repeats and "
@@ -249,7 +251,7 @@ def main():
                     flush_every=args.flush_every)
     dist_obj = dp or sim
     ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dist_obj, sync_bn=bool(args.sync_bn),
-                   table_dist=args.table_dist)
+                   table_dist=args.table_dist, tower_one_launch=bool(args.tower_one_launch), rows_dense_one_launch=bool(args.rows_dense_one_launch))
     # N>1: the headline runs with global-batch BatchNorm statistics (the parity semantic); the per-rank-statistics step
     # (torch DDP without SyncBatchNorm) is timed beside it on the same model and optimiser state
     ts_local = None
@@ -338,6 +340,9 @@ def main():
                        "global_batch": B * world, "dropout": args.dropout, "table_mode": table_mode,
                        "hip_graph": use_graph, "row_sort_one_batch_ahead": bool(getattr(ts, "_ahead_ok", False)), "id_dist": args.id_dist, "parallelism": f"dp{world}", "attention_branch": bool(args.atten),
                        "table_dist": ts.table_dist if world > 1 else None,
+                       # N > 1: how the step's collectives are issued — "one_graph": captured with the launches in one hipGraph per
+                       # step (RCCL); "segments": launch segments replayed, collectives issued by the host in between (fallback)
+                       "exchange": None if not ts.dp_on else ("rccl, one_graph" if ts._one_graph_ok else "rccl, segments"),
                        "bn_stats": None if world == 1 else ("global batch (sync)" if args.sync_bn else "per rank"),
                        "steady_state": bool(steady), "preroll_steps": args.preroll,
                        "mean_replay_depth_of_next_slice_flush": depth, "flush_every": args.flush_every if table_mode == "lazy" else None,

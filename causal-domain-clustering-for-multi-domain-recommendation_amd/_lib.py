@@ -367,6 +367,7 @@ _SIGNATURES = {
     "cdc_head_workspace_floats": (c_i64, [C.POINTER(HeadArgs)]),
     "cdc_tower_fwd": (c_i32, [C.POINTER(TowerArgs), c_p]),
     "cdc_tower_bwd": (c_i32, [C.POINTER(TowerArgs), c_p]),
+    "cdc_tower_step": (c_i32, [C.POINTER(TowerArgs), c_p]),
     "cdc_tower_workspace_bytes": (c_i64, [C.POINTER(TowerArgs)]),
     "cdc_tower_dp": (c_i32, [C.POINTER(TowerArgs), c_i32, c_p]),
     "cdc_bce_fwd_bwd": (c_i32, [c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i32, c_f, c_p]),
@@ -397,6 +398,8 @@ _SIGNATURES = {
     "cdc_sum_slices": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_adam_multi": (c_i32, [C.POINTER(AdamArgs), c_p]),
     "cdc_adam_multi_table": (c_i32, [C.POINTER(AdamArgs), c_p, c_p, c_p, c_i32, c_p]),
+    "cdc_embed_segsum_lazy_update_dense": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32,
+                                                   C.POINTER(AdamArgs), c_p, c_p, c_p, c_i32, c_p]),
     "cdc_step_increment": (c_i32, [c_p, c_p]),
     "cdc_begin_step": (c_i32, [c_p, c_p, c_i32, c_p]),
     "cdc_fill_f32": (c_i32, [c_p, c_f, c_i64, c_p]),

@@ -6,6 +6,7 @@
 //   model/layer.py:31,96-112 + run.py:489,720-721       whole-table L2 + dense torch.optim.Adam
 // HBM-bound byte work: no MFMA here; coalesced 16-B lanes, LDS only for the per-field sort.
 #include "common.h"
+#include "adam_dense.h"
 
 // ------------------------------------------------------------------------------------------------
 // gather
@@ -738,6 +739,36 @@ __global__ void __launch_bounds__(256) k_segment_sum(const float* __restrict__ d
     else
         seg_direct_body<VEC>(blockIdx.x - n_long, gridDim.x - n_long, d_out, seg_start, perm, uniq_cnt, nullptr, sink, B, F, D, SEG_DIRECT);
 }
+// ... and the dense parameters' Adam step in the same launch (cdc_embed_segsum_lazy_update_dense): the two updates that end a training
+// step touch disjoint memory (the step's table rows with their gradient sums; the dense parameters with theirs) and each alone is a
+// launch of a few hundred to two thousand short-lived workgroups living on memory latency.  Workgroups [n_long, n_long + n_dense)
+// take one ADAM_CHUNK of one dense tensor each (csrc/adam_dense.h, in two passes so that the launch keeps four waves per SIMD for
+// the row gathers), the others are k_segment_sum's.
+template <int VEC>
+__global__ void __launch_bounds__(256, 4) k_segment_sum_dense(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
+                                                           const int32_t* __restrict__ perm, const int32_t* __restrict__ uniq_cnt,
+                                                           SegSink sink, cdc_adam_hp hp, const int32_t* __restrict__ step_dev, int32_t B,
+                                                           int32_t F, int32_t D, int32_t subs, const AdamHdr h,
+                                                           const cdc_adam_tensor* __restrict__ tab, const int32_t* __restrict__ wg_tensor,
+                                                           const int32_t* __restrict__ wg_chunk, int32_t n_dense) {
+    const int n_long = F * SEG_LONG_BLOCKS;
+    const int b = (int)blockIdx.x;
+    if (b >= n_long && b < n_long + n_dense) {
+        const int ti = __builtin_amdgcn_readfirstlane(wg_tensor[b - n_long]);
+        const int chunk = __builtin_amdgcn_readfirstlane(wg_chunk[b - n_long]);
+        const cdc_adam_tensor T = tab[ti];
+        adam_chunk<ADAM_CHUNK / 2>(h, T, chunk, b == n_long);
+        return;
+    }
+    sink.c = make_consts(hp);
+    sink.t = *step_dev;
+    step_scalars_at(hp.step_scalars, hp.n_scalars, sink.t, sink.step_size, sink.bc2s);
+    if (b < n_long)
+        seg_long_body<VEC>(b / SEG_LONG_BLOCKS, b % SEG_LONG_BLOCKS, d_out, seg_start, perm, uniq_cnt, sink, B, F, D, subs, SEG_DIRECT);
+    else
+        seg_direct_body<VEC>(b - n_long - n_dense, (int)gridDim.x - n_long - n_dense, d_out, seg_start, perm, uniq_cnt, nullptr, sink, B, F, D,
+                             SEG_DIRECT);
+}
 // short segments only (an owner's merged row lists), same sink
 template <int VEC>
 __global__ void __launch_bounds__(256) k_segment_sum_short_sink(const float* __restrict__ d_out, const int32_t* __restrict__ seg_start,
@@ -792,6 +823,35 @@ extern "C" int cdc_embed_segsum_lazy_update(const float* d_out, const int32_t* s
         else     hipLaunchKernelGGL(k_segment_sum<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D, subs);
     }
     CDC_LAUNCH_CHECK("embed_segsum_lazy_update");
+    return 0;
+}
+
+// cdc_embed_segsum_lazy_update (all segment lengths) and cdc_adam_multi_table in ONE launch: see k_segment_sum_dense
+extern "C" int cdc_embed_segsum_lazy_update_dense(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
+                                                  const int32_t* uniq_row, float* w, float* m, float* v, int32_t* last, cdc_adam_hp hp,
+                                                  const int32_t* step_dev, int64_t B, int32_t F, int32_t D, const cdc_adam_args* dense,
+                                                  const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev,
+                                                  const int32_t* wg_chunk_dev, int32_t n_dense_workgroups, void* stream) {
+    CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && uniq_row && w && m && v && last && step_dev && hp.step_scalars &&
+                      hp.n_scalars > 0, CDC_E_BADARG, "embed_segsum_lazy_update_dense: null pointer");
+    CDC_CHECK_ARG(B > 0 && F > 0 && D > 0 && B <= CDC_SORT_MAX_ROWS, CDC_E_BADARG, "embed_segsum_lazy_update_dense: bad sizes");
+    CDC_CHECK_ARG(dense && tensors_dev && wg_tensor_dev && wg_chunk_dev && n_dense_workgroups > 0 && n_dense_workgroups < (1 << 24) &&
+                      dense->step_dev && dense->step_scalars && dense->n_scalars > 0, CDC_E_BADARG,
+                  "embed_segsum_lazy_update_dense: the dense parameters' descriptor table (as for cdc_adam_multi_table) is missing");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (D % 4 == 0) && ((((uintptr_t)d_out | (uintptr_t)w | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    SegSink sink = {};
+    sink.w = w; sink.m = m; sink.v = v; sink.last = last; sink.uniq_row = uniq_row;
+    const int direct_blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
+    const int blocks = direct_blocks + F * SEG_LONG_BLOCKS + n_dense_workgroups;
+    const int subs = (D <= 64 && 64 % D == 0) ? 64 / D : 1;
+    const AdamHdr h = {dense->lerp_w, dense->beta2, dense->one_minus_beta2, dense->eps, dense->weight_decay, dense->grad_scale,
+                       dense->step_scalars, dense->n_scalars, dense->step_dev, dense->reg_sum, dense->reg_seed};
+    if (vec) hipLaunchKernelGGL(k_segment_sum_dense<4>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D, subs,
+                                h, tensors_dev, wg_tensor_dev, wg_chunk_dev, n_dense_workgroups);
+    else     hipLaunchKernelGGL(k_segment_sum_dense<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D, subs,
+                                h, tensors_dev, wg_tensor_dev, wg_chunk_dev, n_dense_workgroups);
+    CDC_LAUNCH_CHECK("embed_segsum_lazy_update_dense");
     return 0;
 }
 

@@ -109,7 +109,7 @@ struct TwLayout {
     int64_t b2, b1;          // backward: per row block column sums (dz, dz*xhat): [block][n_tower*H][2] doubles
     int64_t hd;              // backward: head weight-gradient partials [block][n_tower][H2 + 4] floats (slot H2 = bias)
     int64_t wd;              // backward: wide weight-gradient partials [n_tower*block][WD_LD] floats (slot wide_K = bias)
-    int64_t loss;            // backward: [block] doubles
+    int64_t loss;            // backward: [workgroup] doubles (a row's loss is added by the workgroup of its OWN tower)
     int64_t wide;            // forward: the wide term of every row [M] floats (each row formed by ONE workgroup, read by all towers)
     int64_t total;
     int wd_ld;
@@ -126,7 +126,7 @@ __host__ __device__ inline TwLayout tw_layout(int n_tower, int H1, int H2, int64
     L.wd_ld = (wide_K + 1 + 3) / 4 * 4;
     L.wd = o; o += (int64_t)n_tower * G * L.wd_ld * 4;
     o = (o + 15) / 16 * 16;
-    L.loss = o; o += G * 8;
+    L.loss = o; o += (int64_t)n_tower * G * 8;
     L.wide = o; o += (M + 3) / 4 * 16;
     L.total = (o + 127) / 128 * 128;
     return L;
@@ -327,14 +327,11 @@ struct TwFwdCfg {
     static constexpr int SMEM = PAR + TW_PAR_FLOATS * 4;
 };
 
+// `keep` (cdc_tower_step only, else null): LDS floats [mean1 64 | invstd1 64 | mean2 64 | invstd2 64] handed to the backward body
 template <int NK0, int H1, int H2>
-__global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a_by_value) {
-    CDC_PRIO_MAIN();
-    (void)a_by_value;
-    const TW_KARG cdc_tower_args& a = *(const TW_KARG cdc_tower_args*)__builtin_amdgcn_kernarg_segment_ptr();
+__device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, unsigned char* smem, float* keep) {
     typedef TwFwdCfg<NK0, H1, H2> Cfg;
     static_assert(H1 % 64 == 0 && H1 <= 64 && H2 % 16 == 0 && H2 <= 64 && H2 % 8 == 0, "instantiated shapes");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = (int)a.M, n_tower = a.n_tower;
@@ -471,6 +468,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
     tw_gather_sums<H1>(reinterpret_cast<const double*>(wsb + L.st1), (M + 63) / 64, n_tower * H1, t * H1, part, sums, tid);
     tw_finish_stats<H1>(sums, M, a.eps, a.momentum, writer, T.l1.save_mean, T.l1.save_invstd, T.l1.running_mean, T.l1.running_var,
                         T.l1.num_batches_tracked, col_mean, col_inv, tid);
+    if (keep && tid < H1) { keep[tid] = col_mean[tid]; keep[64 + tid] = col_inv[tid]; }
     TW_STAMP(5);
 
     // ---- A1 = dropout(relu(bn(Z1))): bf16 into the A operand image of layer 2 and into its global copy
@@ -535,6 +533,7 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a
     tw_gather_sums<H2>(reinterpret_cast<const double*>(wsb + L.st2), (M + 63) / 64, n_tower * H2, t * H2, part, sums, tid);
     tw_finish_stats<H2>(sums, M, a.eps, a.momentum, writer, T.l2.save_mean, T.l2.save_invstd, T.l2.running_mean, T.l2.running_var,
                         T.l2.num_batches_tracked, col_mean, col_inv, tid);
+    if (keep && tid < H2) { keep[128 + tid] = col_mean[tid]; keep[192 + tid] = col_inv[tid]; }
     TW_STAMP(8);
     // ---- A2 = dropout(relu(bn(Z2))) in fp32: kept in the tile for the head, written out for the backward
     {
@@ -681,14 +680,12 @@ __device__ __forceinline__ void tw_wide_apply(const TwWideRound& R, float* wide_
     }
 }
 
+// `keep`: see tw_fwd_body — the batch statistics every workgroup of the forward holds anyway (save_mean / save_invstd in global
+// memory are written by the tower's FIRST workgroup only, which the others must not wait for)
 template <int NK0, int H1, int H2>
-__global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a_by_value) {
-    CDC_PRIO_MAIN();
-    (void)a_by_value;
-    const TW_KARG cdc_tower_args& a = *(const TW_KARG cdc_tower_args*)__builtin_amdgcn_kernarg_segment_ptr();
+__device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, unsigned char* smem, const float* keep) {
     typedef TwBwdCfg<NK0, H1, H2> Cfg;
     constexpr int H0 = Cfg::H0;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = (int)a.M, n_tower = a.n_tower;
@@ -722,12 +719,12 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     {
         const int k = tid & 63, which = tid >> 6;
         if (which == 0 && k < H1) {
-            const float inv = T.l1.save_invstd[k];
-            par_s[TW_PAR_B1 + k] = T.l1.save_mean[k]; par_s[TW_PAR_G1 + k] = T.l1.gamma[k] * inv; par_s[TW_PAR_BE1 + k] = inv;
+            const float inv = keep ? keep[64 + k] : T.l1.save_invstd[k];
+            par_s[TW_PAR_B1 + k] = keep ? keep[k] : T.l1.save_mean[k]; par_s[TW_PAR_G1 + k] = T.l1.gamma[k] * inv; par_s[TW_PAR_BE1 + k] = inv;
         }
         if (which == 1 && k < H2) {
-            const float inv = T.l2.save_invstd[k];
-            par_s[TW_PAR_B2 + k] = T.l2.save_mean[k]; par_s[TW_PAR_G2 + k] = T.l2.gamma[k] * inv; par_s[TW_PAR_BE2 + k] = inv;
+            const float inv = keep ? keep[192 + k] : T.l2.save_invstd[k];
+            par_s[TW_PAR_B2 + k] = keep ? keep[128 + k] : T.l2.save_mean[k]; par_s[TW_PAR_G2 + k] = T.l2.gamma[k] * inv; par_s[TW_PAR_BE2 + k] = inv;
         }
         if (which == 2 && k < H2) par_s[TW_PAR_WO + k] = T.wo[k];
     }
@@ -773,24 +770,30 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
                 own = (int)c;
                 tgt = a.bce_y_i16 ? (float)a.bce_y_i16[r] : a.bce_y_f32[r];
             }
-            for (int tt = 0; tt < n_tower; ++tt) {
-                const float o = a.out[r * a.ld_out + tt];
-                float dout;
-                if (bce) {
-                    if (tt == own) {
-                        lp = (double)((tgt - 1.f) * fmaxf(log1pf(-o), -100.f) - tgt * fmaxf(logf(o), -100.f));
-                        dout = a.bce_inv_count * (o - tgt) / fmaxf((1.f - o) * o, 1e-12f);
-                    } else dout = 0.f;
-                } else dout = a.d_out[r * a.ld_dout + tt];
-                const float d = a.sigmoid ? dout * o * (1.f - o) : dout;
-                dsum += d;                                               // ascending tower order
-                if (tt == t) d_t = d;
+            if (bce) {
+                // only the row's OWN tower has a gradient, and only that tower's workgroup looks at the row: it reads nothing but
+                // what the forward of the SAME workgroup wrote (which is what lets cdc_tower_step run both in one launch)
+                if (own == t) {
+                    const float o = a.out[r * a.ld_out + t];
+                    lp = (double)((tgt - 1.f) * fmaxf(log1pf(-o), -100.f) - tgt * fmaxf(logf(o), -100.f));
+                    const float dout = a.bce_inv_count * (o - tgt) / fmaxf((1.f - o) * o, 1e-12f);
+                    d_t = a.sigmoid ? dout * o * (1.f - o) : dout;
+                    dsum = d_t;
+                }
+            } else {
+                for (int tt = 0; tt < n_tower; ++tt) {
+                    const float o = a.out[r * a.ld_out + tt];
+                    const float dout = a.d_out[r * a.ld_dout + tt];
+                    const float d = a.sigmoid ? dout * o * (1.f - o) : dout;
+                    dsum += d;                                           // ascending tower order
+                    if (tt == t) d_t = d;
+                }
             }
             const int owner = bce ? own : (int)(r % n_tower);            // which tower's workgroup forms the row's wide gradient
             mine = owner == t;
         }
         d_s[tid] = d_t; dsum_s[tid] = dsum;
-        loss_s[tid] = (t == 0) ? lp : 0.0;
+        loss_s[tid] = lp;
         mine_s[tid] = mine;
     }
     __syncthreads();
@@ -862,10 +865,10 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
             for (int q = 0; q < NPT; ++q) b += part[(1 * NPT + q) * H2 + 0];
             tw_st(hd + H2, (float)b);
         }
-        if (t == 0 && wave == 1) {                                       // the block's loss partial
+        if (bce && wave == 1) {                                          // the loss of the block's rows of this tower
             double s_ = (lane < rows ? loss_s[lane] : 0.0) + (lane + 64 < rows ? loss_s[lane + 64] : 0.0);
             s_ = wave_sum_d(s_);
-            if (lane == 0) tw_st(reinterpret_cast<double*>(wsb + L.loss) + jb, s_);
+            if (lane == 0) tw_st(reinterpret_cast<double*>(wsb + L.loss) + blockIdx.x, s_);
         }
     }
     tw_drain();
@@ -1101,12 +1104,50 @@ __global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a
     if (bce && blockIdx.x == 0 && wave == 1 && a.bce_loss) {
         const double* lp = reinterpret_cast<const double*>(wsb + L.loss);
         double s = 0.0;
-        for (int b = lane; b < G; b += 64) s += tw_ld(lp + b);
+        for (int b = lane; b < n_wg; b += 64) s += tw_ld(lp + b);
         s = wave_sum_d(s);
         if (lane == 0) *a.bce_loss = (float)(s * (double)a.bce_inv_count);
     }
     TW_STAMP(28);
     if (tid == 0) tw_finish(hdr, TW_BDONE, n_wg, TW_B3(0), TW_BDONE);
+}
+
+template <int NK0, int H1, int H2>
+__global__ void __launch_bounds__(TW_THREADS) k_tower_fwd(const cdc_tower_args a_by_value) {
+    CDC_PRIO_MAIN();
+    (void)a_by_value;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tw_fwd_body<NK0, H1, H2>(*(const TW_KARG cdc_tower_args*)__builtin_amdgcn_kernarg_segment_ptr(), smem, nullptr);
+}
+template <int NK0, int H1, int H2>
+__global__ void __launch_bounds__(TW_THREADS) k_tower_bwd(const cdc_tower_args a_by_value) {
+    CDC_PRIO_MAIN();
+    (void)a_by_value;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tw_bwd_body<NK0, H1, H2>(*(const TW_KARG cdc_tower_args*)__builtin_amdgcn_kernarg_segment_ptr(), smem, nullptr);
+}
+template <int NK0, int H1, int H2>
+struct TwStepCfg {
+    static constexpr int F = TwFwdCfg<NK0, H1, H2>::SMEM, B = TwBwdCfg<NK0, H1, H2>::SMEM;
+    static constexpr int KEEP = ((F > B ? F : B) + 15) / 16 * 16;    // the bodies' regions overlay each other; the statistics sit behind both
+    static constexpr int SMEM = KEEP + 256 * 4;
+    static_assert(SMEM <= 150 * 1024, "one workgroup per CU");
+};
+// Forward and backward of a TRAINING step in one launch (cdc_tower_step): with the fused loss a workgroup's backward needs nothing
+// but what the same workgroup's forward produced (a row's logit gradient comes from its OWN tower's output, formed by the tower's
+// workgroup of that block), so the second body simply follows the first — one launch and one ramp less, and the backward reads
+// z1 / a1 / z2 / a2 / out where its own forward has just written them.
+template <int NK0, int H1, int H2>
+__global__ void __launch_bounds__(TW_THREADS) k_tower_step(const cdc_tower_args a_by_value) {
+    CDC_PRIO_MAIN();
+    (void)a_by_value;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const TW_KARG cdc_tower_args& a = *(const TW_KARG cdc_tower_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    float* keep = reinterpret_cast<float*>(smem + TwStepCfg<NK0, H1, H2>::KEEP);
+    tw_fwd_body<NK0, H1, H2>(a, smem, keep);
+    tw_drain();                                                          // this workgroup's stores of the forward have left
+    __syncthreads();
+    tw_bwd_body<NK0, H1, H2>(a, smem, keep);
 }
 
 // =================================================================================================
@@ -1809,6 +1850,30 @@ extern "C" int cdc_tower_bwd(const cdc_tower_args* a, void* stream) {
     if (a->H0 == 64) hipLaunchKernelGGL((k_tower_bwd<1, 64, 32>), dim3(grid), dim3(TW_THREADS), lds1, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL((k_tower_bwd<2, 64, 32>), dim3(grid), dim3(TW_THREADS), lds2, (hipStream_t)stream, *a);
     CDC_LAUNCH_CHECK("tower_bwd");
+    return 0;
+}
+
+// Both directions of a training step in one launch: the fused-loss form of cdc_tower_bwd's arguments (which include everything
+// cdc_tower_fwd reads).  Same results as cdc_tower_fwd followed by cdc_tower_bwd, bit for bit.
+extern "C" int cdc_tower_step(const cdc_tower_args* a, void* stream) {
+    int rc = tower_check(a, "tower_step", false);
+    if (rc) return rc;
+    rc = tower_check(a, "tower_step", true);
+    if (rc) return rc;
+    const bool bce = a->bce_y_i16 || a->bce_y_f32;
+    CDC_CHECK_ARG(bce && a->sigmoid && a->bce_loss && a->bce_inv_count > 0.f, CDC_E_BADARG,
+                  "tower_step: needs the fused BCE (labels, sigmoid outputs, a loss pointer): with an output gradient from outside the two directions are two launches");
+    const unsigned grid = (unsigned)(a->n_tower * cdc_ceil_div(a->M, TW_ROWS));
+    static bool attr_done = false;
+    if (!attr_done) {
+        tower_attr(k_tower_step<1, 64, 32>, TwStepCfg<1, 64, 32>::SMEM);
+        tower_attr(k_tower_step<2, 64, 32>, TwStepCfg<2, 64, 32>::SMEM);
+        attr_done = true;
+    }
+    constexpr int lds1 = TwStepCfg<1, 64, 32>::SMEM, lds2 = TwStepCfg<2, 64, 32>::SMEM;
+    if (a->H0 == 64) hipLaunchKernelGGL((k_tower_step<1, 64, 32>), dim3(grid), dim3(TW_THREADS), lds1, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((k_tower_step<2, 64, 32>), dim3(grid), dim3(TW_THREADS), lds2, (hipStream_t)stream, *a);
+    CDC_LAUNCH_CHECK("tower_step");
     return 0;
 }
 

@@ -159,6 +159,11 @@ def train_epoch(step, loader, log_interval=None, log=None):
     The ragged last batch of an epoch is trained on like any other (a sibling step of that size on the same model and
     optimiser state); under data parallelism every rank gets its share of it (DeviceLoader) and the sibling step is told the
     batch's global size: loss mean, BatchNorm statistics and row-list capacities are those of the whole ragged batch.
+    LOADER CONTRACT: the loop looks one batch ahead (the next batch's row sort runs beside this batch's step), so a yielded batch
+    must stay valid and unchanged while the NEXT one is produced and until its own step has been issued — DeviceLoader yields
+    fresh tensors or views of the resident data; a loader that refills ONE staging buffer per batch must double-buffer.  The
+    look-ahead recognises "the batch I was told about" by (address, tensor version): contents changed behind torch's back
+    (`.data.copy_`, a custom kernel, DLPack) are not seen.
     Out-of-range ids and row-list overflows are surfaced at the logging synchronisations and at the end of the epoch
     (`step.check_ids()`: IndexError like nn.Embedding's).  Returns (batches run, batches skipped)."""
     if log_interval is None:

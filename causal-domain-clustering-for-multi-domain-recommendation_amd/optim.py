@@ -295,8 +295,34 @@ class FusedAdam:
         """Adam step t on every dense parameter that has a gradient in the plan (params without one are skipped,
         as torch.optim.Adam skips `grad is None`).  slabs (plan.grad_slabs): gradients whose split-K slabs the grad-weight launches
         left unreduced — the launch adds them while it reads (address of the gradient tensor -> (first slab, stride, count))."""
+        self._dense_prepare(param_grads, param_refs, slabs, False)
+        s = self._stream()
+        if getattr(self, "_dense_table", None) is not None:
+            hdr, tab, wg_t, wg_c, n_wg = self._dense_table
+            L.launch("cdc_adam_multi", self.lib.cdc_adam_multi_table, (C.byref(hdr), tab.data_ptr(), wg_t.data_ptr(), wg_c.data_ptr(), n_wg), s)
+        for a in self._dense_args:
+            L.launch("cdc_adam_multi", self.lib.cdc_adam_multi, (C.byref(a),), s)
+
+    def rows_and_dense_step(self, idx, d_out, B, F, D, param_grads, param_refs, slabs=None, tag=""):
+        """table_step (lazy table: per-row gradient sums + the rows' Adam step) and dense_step in ONE launch
+        (cdc_embed_segsum_lazy_update_dense): what ends a single-GPU training step."""
+        if self.table_mode != "lazy":
+            raise RuntimeError("rows_and_dense_step: lazy table only")
+        self._dense_prepare(param_grads, param_refs, slabs, True)
+        if self._dense_table is None:            # (no dense parameter has a gradient)
+            return self.table_step(idx, d_out, B, F, D, tag=tag)
+        hdr, tab, wg_t, wg_c, n_wg = self._dense_table
+        ws = self._workspace(B, F, D, tag)       # rows were sorted by the catch-up of this step
+        L.launch("cdc_embed_segsum_lazy_update_dense", self.lib.cdc_embed_segsum_lazy_update_dense,
+                 (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["uniq"].data_ptr(),
+                  self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(),
+                  self.step_dev.data_ptr(), B, F, D, C.byref(hdr), tab.data_ptr(), wg_t.data_ptr(), wg_c.data_ptr(), n_wg), self._stream())
+
+    def _dense_prepare(self, param_grads, param_refs, slabs, table_form):
+        """argument blocks of the dense Adam launch(es) for this gradient layout -> self._dense_args / self._dense_table.
+        table_form: descriptors and workgroup map as device arrays whatever the tensor count."""
         slabs = slabs or {}
-        sig = tuple((k, g.data_ptr(), slabs.get(g.data_ptr())) for k, g in param_grads.items())
+        sig = (tuple((k, g.data_ptr(), slabs.get(g.data_ptr())) for k, g in param_grads.items()), bool(table_form))
         # one argument set per gradient layout (= per plan stepping this optimiser: a training step and its sibling for the ragged
         # batch alternate), ALL kept alive: a captured graph holds the address of the device-resident descriptor table it was
         # captured with (round 3 kept only the last one: a sibling's step freed the table the main step's graphs point to)
@@ -317,7 +343,7 @@ class FusedAdam:
                     self.state[k] = st
                 items.append((p, g, st))
             self._dense_table = None
-            if len(items) > L.MAX_TENSORS:
+            if len(items) > L.MAX_TENSORS or (table_form and items):
                 # more tensors than one kernel-argument block holds: ONE launch whose descriptors and workgroup map are device arrays
                 tab = (L.AdamTensor * len(items))()
                 wg_t, wg_c = [], []
@@ -366,12 +392,6 @@ class FusedAdam:
                 args.append(a)
             self._dense_args, self._dense_sig = args, sig
             cache[sig] = (args, self._dense_table)
-        s = self._stream()
-        if getattr(self, "_dense_table", None) is not None:
-            hdr, tab, wg_t, wg_c, n_wg = self._dense_table
-            L.launch("cdc_adam_multi", self.lib.cdc_adam_multi_table, (C.byref(hdr), tab.data_ptr(), wg_t.data_ptr(), wg_c.data_ptr(), n_wg), s)
-        for a in self._dense_args:
-            L.launch("cdc_adam_multi", self.lib.cdc_adam_multi, (C.byref(a),), s)
 
     def reg_loss(self):
         """device double: the step's regularisation term sum(l2*w^2) (dense params + table).  Lazy mode: the table's part is the

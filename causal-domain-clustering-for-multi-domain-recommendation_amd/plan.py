@@ -1820,6 +1820,10 @@ class TowerChain:
 
     SHAPES = ((64, 64, 32), (128, 64, 32))      # (H0, H1, H2) csrc/tower.hip is instantiated for (config.py:39-42: tower_dims (64, 32))
     enabled = True                              # tests set this to False to build the five launches at a matching shape
+    # set by the trainer around a step whose loss is formed inside the backward launch (fused BCE, one GPU): the forward step then
+    # launches nothing and the backward step launches cdc_tower_step — forward and backward of the towers in ONE launch.  The
+    # tower forward is the last launch of the plan's forward and the tower backward the first of its backward, so nothing moves.
+    one_launch = False
 
     @classmethod
     def match(cls, plan, l1, b1, l2, b2, head):
@@ -1962,7 +1966,11 @@ class TowerChain:
             self._dp_buffers(a, plan)
             self._dp_steps(plan, a, (1, 2, 3), (0, 1), plan.fwd_steps, fl)
             return
-        step = plan.call("cdc_tower_fwd", C.byref(a), flops=fl)
+        fwd = plan.call("cdc_tower_fwd", C.byref(a), flops=fl)
+
+        def step(stream):
+            if not self.one_launch:               # (one_launch: both directions go out where the backward stands, cdc_tower_step)
+                fwd(stream)
         self._fwd_calls = [step]
         plan.fwd_steps.append(step)
 
@@ -2014,7 +2022,12 @@ class TowerChain:
             self._dp_buffers(a, plan)
             self._dp_steps(plan, a, (4, 5, 6), (2, 3), plan.bwd_steps, fl)
         else:
-            plan.bwd_steps.append(plan.call("cdc_tower_bwd", C.byref(a), flops=fl))
+            bwd = plan.call("cdc_tower_bwd", C.byref(a), flops=fl)
+            both = plan.call("cdc_tower_step", C.byref(a), flops=2.0 * fl)
+
+            def step(stream):
+                (both if self.one_launch else bwd)(stream)
+            plan.bwd_steps.append(step)
         # the grad-weight contractions of both layers: batched launch at the end of backward (operands: the shadows written above)
         for lin in (self.l2, self.l1):
             lin.skip_bwd_x = True

@@ -31,7 +31,7 @@ class TrainStep:
 
     def __init__(self, model, optimizer: FusedAdam, batch_size, mode="multi", use_graph=False, dist=None, sync_bn=True,
                  table_dist=None, shard_slack=1.5, train_mode=True, overlap=True, overlap_waves=2, sort_ahead=True, fuse_gather=False,
-                 defer_dw_reduce=None, global_rows=None, cap_rows=None):
+                 defer_dw_reduce=None, global_rows=None, cap_rows=None, tower_one_launch=True, rows_dense_one_launch=True):
         """sync_bn (data parallel only): BatchNorm statistics over the GLOBAL batch, as the reference's single process
         computes them — two small all-reduces per BatchNorm launch; False = per-rank statistics.
         table_dist (data parallel only): "sharded" (row r owned by rank r % world; default with the lazy table optimiser)
@@ -57,6 +57,9 @@ class TrainStep:
         self.train_mode = bool(train_mode)
         self._overlap_ok, self._overlap_waves = bool(overlap), int(overlap_waves)
         self._sort_ahead_wanted, self._fuse_gather_wanted = sort_ahead, bool(fuse_gather)
+        # the two updates that end a single-GPU step with the lazy table (the step's rows; the dense parameters) as one launch
+        self._rows_dense_one = bool(rows_dense_one_launch) and not self.dp_on
+        self.tower_one_launch = bool(tower_one_launch)        # the fused towers' forward and backward as one launch (cdc_tower_step)
         # split-K slabs of the batched grad-weight launches summed by the dense Adam launch (single GPU; under data parallelism the
         # reduced gradient is what is all-reduced)
         self._defer_dw = (not self.dp_on) if defer_dw_reduce is None else (bool(defer_dw_reduce) and not self.dp_on)
@@ -165,7 +168,10 @@ class TrainStep:
         for op in self.plan.ops:
             if isinstance(op, (P.TowerHead, P.TowerChain)) and op.sigmoid and op.out.root is out.root and op.out.col0 == out.col0 and op.out.cols == out.cols:
                 args = getattr(op, "bwd_args", [])
-                return args[0] if len(args) == 1 and op.M == self.B else None
+                if len(args) == 1 and op.M == self.B:
+                    self._head_op = op
+                    return args[0]
+                return None
         for op in self.plan.ops:
             if not isinstance(op, P.RowDot) or not op.sigmoid or op.row_offsets is not None or len(op.groups) != out.cols:
                 continue
@@ -174,15 +180,29 @@ class TrainStep:
                 return args[0] if len(args) == 1 and op.M == self.B else None
         return None
 
-    def _bce(self):
-        og = self.out.grad
+    def _head_lookup(self):
         head = self.__dict__.get("_head", False)
         if head is False:
-            import os
+            self._head_op = None
             head = self._head = self._find_head()
             self._fuse_bce = head is not None and self.mode in ("multi", "single", "single_group")
             if self._fuse_bce:
                 self._bce_partial = torch.zeros(L.MAX_GROUPS * L.ROWDOT_PARTS, dtype=torch.float64, device=self.device)
+            from . import plan as P
+            # the towers' two launches as one (csrc/tower.hip cdc_tower_step): the fused loss, one GPU
+            self._tower_both = (self._head_op if self._fuse_bce and self.tower_one_launch and not self.dp_on and
+                                isinstance(self._head_op, P.TowerChain) and self.plan.dist is None else None)
+        return head
+
+    def _towers_one_launch(self, on):
+        """around the launches of a step (the plan, and with it the op, may be shared with a trainer that wants the other form)"""
+        self._head_lookup()
+        if self._tower_both is not None:
+            self._tower_both.one_launch = bool(on)
+
+    def _bce(self):
+        og = self.out.grad
+        head = self._head_lookup()
         if head is not None:
             # the argument block belongs to the (cached, possibly shared) plan: set for this trainer before every backward
             if self._fuse_bce:
@@ -243,6 +263,13 @@ class TrainStep:
         return self.opt.refresh_table_reg(self.dist if sharded else None)
 
     def _launch_all(self):
+        self._towers_one_launch(True)
+        try:
+            self._launch_all_seq()
+        finally:
+            self._towers_one_launch(False)
+
+    def _launch_all_seq(self):
         """single GPU: the whole step is one launch sequence (one hipGraph when use_graph)."""
         opt, plan, emb = self.opt, self.plan, self.emb
         B, F, D = self.B, emb.F, emb.D
@@ -276,6 +303,12 @@ class TrainStep:
                 plan.forward()
             self._bce()
             plan.backward()
+            if self._rows_dense_one:
+                if bg:
+                    main.wait_stream(side)
+                opt.rows_and_dense_step(emb.idx, emb.out.grad.root, B, F, D, plan.param_grads, plan._param_refs, plan.grad_slabs)
+                self._reg()
+                return
             opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
             if bg:
                 main.wait_stream(side)
@@ -303,6 +336,13 @@ class TrainStep:
         return self._ahead_ok
 
     def _launch_ahead(self, have, prefetch, p):
+        self._towers_one_launch(True)
+        try:
+            self._launch_ahead_seq(have, prefetch, p)
+        finally:
+            self._towers_one_launch(False)
+
+    def _launch_ahead_seq(self, have, prefetch, p):
         """_launch_all's lazy branch with the row sort out of the chain and the catch-up on the SIDE chain: have = this batch's
         sorted rows are in workspace a<p> (sorted by the previous step), prefetch = sort the batch in ids_next into workspace
         a<1-p>.  begin_step's work was done by the staging launch (cdc_stage_batch_next).
@@ -346,7 +386,16 @@ class TrainStep:
                 fn(st)
         for fn in plan.deferred_dw_steps:
             fn(st)
+        if self._rows_dense_one:
+            # the step's rows and the dense parameters in one launch behind the join (optim.rows_and_dense_step)
+            main.wait_stream(side)
+            opt.rows_and_dense_step(emb.idx, emb.out.grad.root, B, F, D, plan.param_grads, plan._param_refs, plan.grad_slabs, tag=cur)
+            self._reg()
+            return
         opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
+        # (the row update on the side chain beside these two, or on this chain in front of them as soon as the slice has ended, was
+        # measured again in round 4: 0.345 and 0.350 ms against 0.338 — every additional cross-queue edge of the replayed graph moves
+        # nodes to another hardware queue and costs ~10 us where it lands, profiles/round4/README.md section 6)
         main.wait_stream(side)
         opt.table_step(emb.idx, emb.out.grad.root, B, F, D, tag=cur)
         self._reg()
@@ -705,10 +754,11 @@ class TrainStep:
         fast = (X.is_cuda and X.dtype == torch.int32 and X.is_contiguous() and tuple(X.shape) == (self.B, self.emb.F) and
                 yf.is_cuda and yf.dtype == torch.int16 and yf.is_contiguous() and yf.numel() == self.B and
                 (gdst is None or (gf is not None and gf.is_cuda and gf.dtype == torch.int64 and gf.is_contiguous() and gf.numel() == self.B)))
-        if not self._reg_checked:
-            # the first reported loss of a lazy run carries the table's L2 term like every later one (a freshly built or loaded
-            # optimiser has not evaluated it yet).  Before the staging launch: with the look-ahead sort that launch advances the step
-            # counter, and the refresh brings the table to the counter's step
+        if not self._reg_checked or (self.opt.table_mode == "lazy" and not self.opt.table_reg_ready):
+            # the first reported loss of a lazy run carries the table's L2 term like every later one (a freshly built or LOADED
+            # optimiser has not evaluated it yet: load_state_dict clears table_reg_ready, also for a TrainStep that already ran).
+            # Before the staging launch: with the look-ahead sort that launch advances the step counter, and the refresh brings
+            # the table to the counter's step
             self._reg_checked = True
             if self.opt.table_mode == "lazy" and not self.opt.table_reg_ready:
                 self.refresh_table_reg()

@@ -831,6 +831,10 @@ typedef struct {
 int64_t cdc_tower_workspace_bytes(const cdc_tower_args* a);
 int cdc_tower_fwd(const cdc_tower_args* a, void* stream);
 int cdc_tower_bwd(const cdc_tower_args* a, void* stream);
+/* Both directions of a TRAINING step in one launch, for the fused-loss form only (bce_y_* set: the output gradient does not come
+ * from outside, so a workgroup's backward needs nothing but what its own forward produced).  `a` holds what cdc_tower_bwd takes —
+ * a superset of cdc_tower_fwd's.  Results bit-identical to cdc_tower_fwd followed by cdc_tower_bwd. */
+int cdc_tower_step(const cdc_tower_args* a, void* stream);
 /* The same towers under DATA PARALLELISM with global-batch BatchNorm statistics (the reference's single process sees the global
  * batch): the two launches cut at their four exchange points into six phases — 1, 2, 3 forward; 4, 5, 6 backward.  Phases 1, 2, 4, 5
  * end with the LOCAL column sums of the statistics the next phase needs in exchange[0..3] (the last workgroup of a tower to finish
@@ -945,6 +949,16 @@ int cdc_adam_multi(const cdc_adam_args* a, void* stream);
 #define CDC_ADAM_CHUNK 4096
 int cdc_adam_multi_table(const cdc_adam_args* a, const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev,
                          const int32_t* wg_chunk_dev, int32_t n_workgroups, void* stream);
+/* The two updates that end a training step with the lazy table in ONE launch: cdc_embed_segsum_lazy_update(short_only = 0) on the
+ * step's rows and cdc_adam_multi_table on the dense parameters (they touch disjoint memory; each alone is a short launch living on
+ * memory latency, one behind the other 20 us + 23 us of the C2 step).  Arguments: those of the two calls.  Same arithmetic and
+ * summation orders as the two launches: identical weights and moments; the regularisation sum is added up in another order
+ * (double atomics in both forms). */
+int cdc_embed_segsum_lazy_update_dense(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
+                                       const int32_t* uniq_row, float* w, float* m, float* v, int32_t* last, cdc_adam_hp hp,
+                                       const int32_t* step_dev, int64_t B, int32_t F, int32_t D, const cdc_adam_args* dense,
+                                       const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev, const int32_t* wg_chunk_dev,
+                                       int32_t n_dense_workgroups, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * STAR parameter fusion (reference: model/star.py:90-93,100-102,169-176): for every domain g

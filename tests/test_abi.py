@@ -201,6 +201,9 @@ def test_entry_points_reject_bad_arguments_without_touching_the_device():
     hp.step_scalars, hp.n_scalars = 16, 4
     rc = lib.cdc_embed_lazy_flush(one, one, one, one, 1 << 40, 4, hp, one, 0, 2, 0, 0, None)
     assert rc == -2 and b"exceeds the 2^31 work items" in lib.cdc_last_error()
+    # the rows + dense-parameter update in one launch needs the dense descriptor table
+    rc = lib.cdc_embed_segsum_lazy_update_dense(one, one, one, one, one, one, one, one, one, hp, one, 8, 2, 4, None, None, None, None, 0, None)
+    assert rc == -1 and b"descriptor table" in lib.cdc_last_error()
     # the fused PLE level boundary's LDS budget, as plan.CGCMid.match asks it: 3 domains fit, 6 and 7 domains (2 + 2 experts) do not
     assert lib.cdc_cgc_mid_fits(8, 4, 8, 3) == 1 and lib.cdc_cgc_mid_fits(12, 6, 12, 5) == 1
     assert lib.cdc_cgc_mid_fits(14, 7, 14, 6) == 0 and lib.cdc_cgc_mid_fits(16, 8, 16, 7) == 0
@@ -223,3 +226,6 @@ def test_fused_tower_launch_refuses_bad_arguments_without_a_launch():
     assert lib.cdc_tower_bwd(C.byref(a), None) == -1 and b"two rows" in lib.cdc_last_error()
     a.M = 128 * 100
     assert lib.cdc_tower_fwd(C.byref(a), None) == -2 and b"resident" in lib.cdc_last_error()
+    assert lib.cdc_tower_step(C.byref(a), None) == -2 and b"tower_step" in lib.cdc_last_error()
+    a.M = 1
+    assert lib.cdc_tower_step(C.byref(a), None) == -1 and b"two rows" in lib.cdc_last_error()

@@ -195,7 +195,48 @@ def test_training_steps_with_the_fused_towers_follow_the_unfused_trajectory(cuda
             assert float(d.mean()) < 2e-4, f"{k}: mean |d| {float(d.mean()):.3e}"
 
 
-def test_a_wait_that_cannot_complete_gives_up_and_says_so(cuda):
+@pytest.mark.parametrize("B,n_tower,table_mode,use_graph", [(1024, 3, "lazy", True), (130, 3, "dense", False), (2, 3, "dense", False),
+                                                          (300, 4, "dense", False)])
+def test_both_directions_in_one_launch_equal_the_two_launches(cuda, B, n_tower, table_mode, use_graph):
+    """cdc_tower_step (TrainStep's default with the fused loss on one GPU) against cdc_tower_fwd + cdc_tower_bwd: the same arithmetic
+    in the same order (the backward body reads what the forward body of the same workgroup wrote; the batch statistics travel in
+    LDS instead of through save_mean / save_invstd) — losses and every parameter after four steps held to BIT equality."""
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    from cdcmdr_amd import plan as P
+    steps = 4
+    rng = np.random.default_rng(11)
+    X = [torch.from_numpy(make_ids(rng, B, FD)).to(cuda) for _ in range(steps)]
+    for x in X:
+        x[:, 10] = x[:, 10] % n_tower
+    y = [torch.from_numpy(rng.integers(0, 2, B).astype(np.int16)).to(cuda) for _ in range(steps)]
+    res = {}
+    for both in (False, True):
+        m = _model(cuda, n_tower, 0.2, True)
+        m.train()
+        opt = FusedAdam(m, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode)
+        ts = TrainStep(m, opt, B, mode="multi", use_graph=use_graph, tower_one_launch=both)
+        chain = [op for op in ts.plan.ops if isinstance(op, P.TowerChain)][0]
+        losses = []
+        for s in range(steps):
+            ts.step(X[s], y[s], X[s][:, 10].long())
+            losses.append(float(ts.loss.item()))
+            assert chain.one_launch is False                       # (only set around the launches of a step)
+        ts.check_ids()
+        assert (ts._tower_both is chain) == both
+        if table_mode == "lazy":
+            opt.flush_table()
+        z1, a1, z2, a2 = _tower_bufs(m.plan_holder(B), chain)
+        res[both] = (losses, sd_cpu(m), [t.detach().clone() for t in (z1, a1, z2, a2)])
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    for u, v in zip(res[False][2], res[True][2]):
+        assert torch.equal(u, v)
+    for k, v in res[False][1].items():
+        assert torch.equal(v, res[True][1][k]), k
+
+
+@pytest.mark.parametrize("both", [True, False])
+def test_a_wait_that_cannot_complete_gives_up_and_says_so(cuda, both):
     """The in-launch exchange is a bounded spin: with an arrival counter that can never reach its target the launch still ends (~0.3 s),
     the error word carries CDC_TOWER_ERR_TIMEOUT, TrainStep.check_ids() raises, and the following step runs normally (the last workgroup
     of a launch puts the counters back)."""
@@ -211,7 +252,7 @@ def test_a_wait_that_cannot_complete_gives_up_and_says_so(cuda):
     m = _model(cuda, n_tower, 0.0, True)
     m.train()
     opt = FusedAdam(m, table_mode="dense")
-    ts = TrainStep(m, opt, B, mode="multi", use_graph=False)
+    ts = TrainStep(m, opt, B, mode="multi", use_graph=False, tower_one_launch=both)
     chain = [op for op in ts.plan.ops if isinstance(op, P.TowerChain)][0]
     ts.step(x, y, x[:, 10].long())
     ts.check_ids()

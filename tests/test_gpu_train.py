@@ -249,6 +249,45 @@ def test_row_sort_one_batch_ahead_trains_bit_identically(cuda, monkeypatch, use_
         assert torch.equal(res["0"][2][k][0], res["1"][2][k][0]) and torch.equal(res["0"][2][k][1], res["1"][2][k][1]), k
 
 
+@pytest.mark.parametrize("use_graph,sort_ahead,precision", [(False, True, "f32"), (True, True, "bf16"), (False, False, "bf16")])
+def test_rows_and_dense_parameters_updated_by_one_launch_train_bit_identically(cuda, use_graph, sort_ahead, precision):
+    """cdc_embed_segsum_lazy_update_dense (the step's table rows and the dense parameters' Adam in ONE launch, TrainStep's default on
+    one GPU with the lazy table) against cdc_adam_multi followed by cdc_embed_segsum_lazy_update: per element the same arithmetic,
+    the split-K slabs added in the same order — weights, moments and the BCE losses held to BIT equality, the regularisation figure
+    (double atomics in both forms) to 1e-6 relative.  A field with few distinct ids gives segments of every length class."""
+    from cdcmdr_amd.optim import FusedAdam
+    from cdcmdr_amd.trainer import TrainStep
+    from cdcmdr_amd.model.ple import PLE
+    fd = [50, 3, 500, 7, 90, 4, 3000, 30]
+    B, n = 1024, 6
+    r = np.random.default_rng(18)
+    Xs = [torch.from_numpy(make_ids(r, B, fd)).to(cuda) for _ in range(n + 1)]
+    ys = [torch.from_numpy(r.integers(0, 2, size=B).astype(np.int16)).to(cuda) for _ in range(n)]
+    gs = [torch.from_numpy(r.integers(0, 3, size=B).astype(np.int64)).to(cuda) for _ in range(n)]
+    res = {}
+    for one in (False, True):
+        torch.manual_seed(4)
+        model = PLE(fd, 16, 3, 2, 2, ((64, 32), (16,)), (8, 4), dropout=0.2).to(cuda).set_precision(precision)
+        model.seed = 5
+        opt = FusedAdam(model, table_mode="lazy", flush_every=4)
+        ts = TrainStep(model, opt, B, use_graph=use_graph, sort_ahead=sort_ahead, rows_dense_one_launch=one)
+        losses, regs = [], []
+        for i in range(n):
+            bce, reg = ts.step(Xs[i], ys[i], gs[i], next_X=Xs[i + 1])
+            losses.append(float(bce.item()))
+            regs.append(float(reg.item()))
+        ts.check_ids()
+        opt.flush_table()
+        res[one] = (losses, regs, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                    {k: (v["exp_avg"].cpu(), v["exp_avg_sq"].cpu()) for k, v in opt.state_dict()["state"].items()})
+    assert res[False][0] == res[True][0]
+    assert np.allclose(res[False][1], res[True][1], rtol=1e-6, atol=0.0), (res[False][1], res[True][1])
+    for k in res[False][2]:
+        assert torch.equal(res[False][2][k], res[True][2][k]), k
+    for k in res[False][3]:
+        assert torch.equal(res[False][3][k][0], res[True][3][k][0]) and torch.equal(res[False][3][k][1], res[True][3][k][1]), k
+
+
 def test_table_adam_kernels_bits_equal_the_c_restatement(cuda):
     """The dense streaming pass (untouched rows: L2-only gradient) and the touched-row kernel against
     oracle/adam_elem_ref.c, which tests/test_host_logic.py pins bit-for-bit to torch's CPU Adam."""
