@@ -297,9 +297,12 @@ def main():
         return el
 
     run(ts, args.preroll)                        # untimed, independent of --warmup: reach the steady state
-    depth = replay_depth(opt)                    # (host-synchronising: before the warm-up, so the timed region starts on a busy GPU)
     run(ts, max(args.warmup, 1))
     elapsed = timed(ts, args.steps)
+    # (host-synchronising and the first use of a few torch kernels: behind the timed region — in front of the warm-up it left the
+    # first ~100 steps 3 % slower, which is what a --steps 20 --warmup 5 run then measured; the replay depth is a periodic function
+    # of the step count in steady state)
+    depth = replay_depth(opt)
     if os.environ.get("CDC_BENCH_REPEAT"):                     # development: the same bracket again (is the first one special?)
         print("brackets ms/step:", [round(elapsed / args.steps * 1e3, 4)] + [round(timed(ts, args.steps) / args.steps * 1e3, 4) for _ in range(4)], file=sys.stderr)
     loss_val = float(ts.loss.item())

@@ -687,6 +687,15 @@ class TrainStep:
             # five-segment cut (launch segments replayed, collectives issued by the host in between) is the fallback
             g = self._step_graphs.get(key)
             if g is None:
+                # capture from a quiescent state: an exchange the previous (eager) step left in flight is awaited OUTSIDE the capture
+                # (inside, ids_await then finds nothing: a replayed predecessor has joined its own exchange at its end), the device is
+                # drained, and the RCCL watchdog thread gets time to retire the eager collectives it is still polling — it must not
+                # query events while this thread captures (seen once in a full-suite run: the capture ended "unjoined" and the
+                # watchdog then died on an event "last recorded in a capturing stream")
+                import time
+                self.dist.wait(self.__dict__.pop("_ids_pending", None))
+                torch.cuda.synchronize()
+                time.sleep(0.25)
                 g = torch.cuda.CUDAGraph()
                 try:
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
