@@ -1,16 +1,20 @@
-"""AUC parity at the scale SURVEY.md 8d prescribes (fast variant): PLE-3 with the reference's dims, 26 fields x vocab 10k,
-emb_dim 16, 488 training steps of 4096 rows, 0.5 M evaluation rows, dropout 0, same synthetic data and initial tensors on
+"""AUC parity at the scale SURVEY.md 8d prescribes: PLE-3 with the reference's dims, 26 fields x vocab 1 M (the headline
+configuration) and x vocab 10k (the fast variant, three sets), emb_dim 16, 488 training steps of 4096 rows, 0.5 M evaluation rows, dropout 0, same synthetic data and initial tensors on
 both sides.
 
 The CPU sides were run in the build container by tools/auc_parity.py and are committed as fixtures
 (tests/golden/auc_parity_*.json): the REFERENCE itself (/root/reference/model/ple.py driven like run.py:481-493), the
 reference with the rows of every batch reversed and in five seeded random orders (same mathematics, other summation
-order: SEVEN runs of the reference against itself), and the CPU restatement (oracle).  Three data sets:
+order: SEVEN runs of the reference against itself), and the CPU restatement (oracle).  Four data sets:
 
     v10k          uniform ids, teacher std 0.3   reference AUC 0.521  (near chance: says little about the model, a lot about
                                                                        how far two correct runs drift apart)
     v10k_zipf     Zipf ids,    teacher std 0.3   reference AUC 0.672
     v10k_zipf_t05 Zipf ids,    teacher std 0.5   reference AUC 0.733
+    v1m_zipf      Zipf ids,    teacher std 0.3   reference AUC 0.680  the HEADLINE vocabulary: 26 fields x 1 M ids (a 26 M-row table,
+                                                                       the configuration BASELINE.json's metric is quoted on); seven runs of
+                                                                       the reference (as is, reversed, five seeded row orders; 27-33 min each
+                                                                       on 5 threads): sigma(AUC) 1.5e-4, largest deviation from their mean 2.8e-4
 
 This test trains the HIP path (exact-fp32 and bf16 contractions) on the same data from the same initial state, several times
 (the batches as they are and in seeded row orders: one run is ONE sample of the trajectory distribution), and holds both
@@ -46,8 +50,8 @@ from helpers import O
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIXTURES = ["auc_parity_v10k_zipf", "auc_parity_v10k_zipf_t05", "auc_parity_v10k"]
-LEARNABLE = {"auc_parity_v10k_zipf": 0.65, "auc_parity_v10k_zipf_t05": 0.70}       # the teacher must be learnable on these sets
+FIXTURES = ["auc_parity_v1m_zipf", "auc_parity_v10k_zipf", "auc_parity_v10k_zipf_t05", "auc_parity_v10k"]
+LEARNABLE = {"auc_parity_v1m_zipf": 0.65, "auc_parity_v10k_zipf": 0.65, "auc_parity_v10k_zipf_t05": 0.70}  # the teacher must be learnable on these sets
 
 
 @pytest.mark.parametrize("name", FIXTURES)
@@ -86,8 +90,8 @@ def test_auc_parity_at_the_protocol_scale(cuda, name):
     figures = {"auc": (lambda v: v["auc"], 1e-4), "logloss": (lambda v: v["logloss"], 1e-4)}
     for d in range(3):
         figures[f"domain {d} auc"] = ((lambda v, d=d: v["domain_auc"][d]), 1e-4)
-    # the Zipf set carries the bias check with five row orders per precision; the other two with three
-    orders = [None, 1, 2, 3, 4] if name == "auc_parity_v10k_zipf" else [None, 1, 2]
+    # five row orders per precision on every set (round 4: the two sets that had three were raised to five)
+    orders = [None, 1, 2, 3, 4]
     runs = {}
     for precision in ("f32", "bf16"):
         runs[precision] = []
