@@ -58,6 +58,7 @@ def parse():
                     help="1: the reference's default attention branch (config.py:24-28: 3 x MultiheadAttention(64, 2 heads) + residual) "
                          "on top of the BASELINE configuration, which is defined without it")
     ap.add_argument("--flush-every", type=int, default=64, help="lazy table: the whole table is replayed once per this many steps")
+    ap.add_argument("--overlap-waves", type=int, default=2, help="waves per SIMD of the background replay slice's capped grid (A/B only)")
     ap.add_argument("--rows-dense-one-launch", type=int, default=1, help="0: the step's row update and the dense Adam as two launches (A/B only)")
     ap.add_argument("--tower-one-launch", type=int, default=1, help="0: the fused towers as two launches, forward and backward (A/B only)")
     ap.add_argument("--fuse-towers", type=int, default=1, help="0: the towers as the five launches per direction the fused launch replaces (A/B only)")
@@ -251,7 +252,7 @@ def main():
                     flush_every=args.flush_every)
     dist_obj = dp or sim
     ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dist_obj, sync_bn=bool(args.sync_bn),
-                   table_dist=args.table_dist, tower_one_launch=bool(args.tower_one_launch), rows_dense_one_launch=bool(args.rows_dense_one_launch))
+                   table_dist=args.table_dist, tower_one_launch=bool(args.tower_one_launch), rows_dense_one_launch=bool(args.rows_dense_one_launch), overlap_waves=args.overlap_waves)
     # N>1: the headline runs with global-batch BatchNorm statistics (the parity semantic); the per-rank-statistics step
     # (torch DDP without SyncBatchNorm) is timed beside it on the same model and optimiser state
     ts_local = None

@@ -12,15 +12,18 @@
 // between any two layers.  Here a workgroup owns CDC_TOWER_ROWS rows of one tower and keeps them in LDS from the first
 // contraction to the sigmoid (forward) and from the loss gradient to the input gradient (backward); the column sums are
 // exchanged among the workgroups of a tower INSIDE the launch:
-//     publish partial sums (write-through stores) -> every storing wave drains (s_waitcnt vmcnt(0)) -> workgroup barrier ->
-//     ONE lane adds to the tower's arrival counter (agent scope) ... ONE lane polls the counter (write-through loads, bounded
-//     spin) -> workgroup barrier -> every workgroup adds ALL partials up in the same fixed order (write-through loads).
-// That is the hand-off of MI355X_MICROARCH.md (inter-workgroup visibility: "ONE lane of each storing workgroup ... agent-scope
-// atomic add" / "sc1 load poll of that counter" / "stores, all sc1; loads, all sc1"): no fence, no reliance on placement.  Every
-// word another workgroup reads is stored and loaded through tw_st/tw_ld below (relaxed agent-scope atomics = global_store/load
-// ... sc1), nothing else.  Work that needs no exchange runs under the waits: the wide term's dot products (forward), the wide
-// term's gradients (backward).  A spin that runs out sets CDC_TOWER_ERR_TIMEOUT in *err and a poison word that ends the other
-// waits of the launch at once, so the grid always drains.  Residency: at most 256 workgroups of 256 threads, one per CU, <= 128
+//     publish partial sums (write-through stores; a published value is never all-zero bits) ... every workgroup loads ALL
+//     partials of its tower (write-through loads, a batch in flight together), loads again while any of them is still an empty
+//     slot (bounded), and adds them up in the same fixed order.
+// Every 4- or 8-byte value is its own flag (aligned accesses of that size are single-copy atomic): no arrival counter, no wait for
+// the stores' acknowledgement in front of one, no ordering between different words to rely on, no fence, no reliance on placement
+// (the first version of this round used MI355X_MICROARCH.md's counter hand-off — publish, drain, "ONE lane ... agent-scope atomic
+// add", "sc1 load poll of that counter", gather: 5.5-6.5 us per exchange against 3-4 now).  Record arrays exist twice, chosen by a
+// launch count: a workgroup clears its own slots of the other copy at entry (tw_nz / tw_empty / tw_poll / tw_finish below).  Every
+// word another workgroup reads is stored and loaded through tw_st/tw_ld (relaxed agent-scope atomics = global_store/load ... sc1),
+// nothing else.  Work that needs no exchange runs while the others' sums arrive: the wide term's dot products (forward), the wide
+// term's gradients (backward).  A poll that runs out sets CDC_TOWER_ERR_TIMEOUT in *err and a give-up word that ends the other
+// polls of the launch at once, so the grid always drains.  Residency: at most 256 workgroups of 256 threads, one per CU, <= 128
 // VGPRs — they fit beside the background replay slice (2 x 64 VGPRs per SIMD, no LDS); kernels of the other queue that hold a
 // CU finish without depending on this launch.
 //
@@ -44,11 +47,10 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define TW_HDR_BYTES 8192
 #define TW_LINE 32                           /* ints per 128-byte line: every counter on a line of its own */
 // header lines
-#define TW_F1(t) (t)
-#define TW_F2(t) (4 + (t))
+#define TW_FEPOCH 0                          /* launches of the forward body so far: its parity chooses the record copy */
+#define TW_MUTE 1                            /* tests only: workgroup (value - 1) of the next forward publishes nothing (the others give up) */
 #define TW_FDONE 8
-#define TW_B3(t) (9 + (t))
-#define TW_B4 13
+#define TW_BEPOCH 9                          /* the same for the backward body */
 #define TW_BDONE 14
 #define TW_POISON 15
 // the split form (data parallel, cdc_tower_dp): one arrival counter per tower and exchange — the LAST workgroup to arrive adds the
@@ -76,30 +78,52 @@ __device__ __forceinline__ int tw_add(int* p, int v) {
 }
 __device__ __forceinline__ void tw_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// every storing wave has drained and passed the workgroup barrier before this: ONE lane signals for the workgroup
-__device__ __forceinline__ void tw_arrive(int* hdr, int line) { tw_add(hdr + line * TW_LINE, 1); }
-// ONE lane: bounded poll of an arrival counter.  false = gave up (the launch's results are void; *err says so)
-__device__ __forceinline__ bool tw_wait(int* hdr, int line, int target, int32_t* err) {
-    int* cnt = hdr + line * TW_LINE;
+// ---- the in-launch exchange of the monolithic kernels (cdc_tower_fwd / _bwd / _step): SELF-VALIDATING records.
+// A published value is never all-zero bits (tw_nz: +0 goes out as -0, which adds like +0), an unpublished slot is all-zero bits.
+// A reader loads the records it needs (a batch in flight together) and loads again while any of them is still empty: every 4- or
+// 8-byte value is its own flag (naturally aligned accesses of that size are single-copy atomic), so there is no arrival counter, no
+// wait for the write-through stores to be acknowledged before one, and no ordering between different values to rely on.
+// Two copies of every record array, chosen by the parity of a launch count in the header (TW_FEPOCH / TW_BEPOCH, advanced by the
+// last workgroup through the body): a workgroup publishes into copy e & 1 and, at entry, clears ITS OWN slots of copy (e + 1) & 1 —
+// whose readers ran in the previous launch and whose next readers run in the next one.  A zeroed workspace is a valid start, and a
+// launch that gave up (bounded polls, below) leaves nothing behind that the launches after it could trip over.
+__device__ __forceinline__ double tw_nz(double v) { return v == 0.0 ? -0.0 : v; }
+__device__ __forceinline__ float tw_nz(float v) { return v == 0.f ? -0.f : v; }
+__device__ __forceinline__ bool tw_empty(double v) { return __double_as_longlong(v) == 0ll; }
+__device__ __forceinline__ bool tw_empty(float v) { return __float_as_uint(v) == 0u; }
+// one more round of a poll loop: false = give up (~0.2-0.3 s of polls, or another workgroup has given up: the launch's results are
+// void and *err says so)
+__device__ __forceinline__ bool tw_spin(unsigned& spins, int* hdr, int32_t* err) {
     int* poison = hdr + TW_POISON * TW_LINE;
-    for (unsigned spins = 0;; ++spins) {
-        if (tw_ld(cnt) >= target) return true;
-        __builtin_amdgcn_s_sleep(8);
-        if ((spins & 63u) == 63u && tw_ld(poison) != 0) return false;
-        if (spins >= TW_SPIN_LIMIT) {
-            tw_st(poison, 1);
-            if (err) __hip_atomic_fetch_or((TW_GLOBAL int32_t*)err, (int32_t)CDC_TOWER_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
+    __builtin_amdgcn_s_sleep(2);
+    ++spins;
+    if ((spins & 63u) == 0u && tw_ld(poison) != 0) return false;
+    if (spins >= TW_SPIN_LIMIT) {
+        tw_st(poison, 1);
+        if (err) __hip_atomic_fetch_or((TW_GLOBAL int32_t*)err, (int32_t)CDC_TOWER_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
     }
+    return true;
 }
-// the last workgroup through `done_line` puts every word of its direction back to zero for the next launch (all others are
-// past their last poll: a workgroup adds here after it)
-__device__ __forceinline__ void tw_finish(int* hdr, int done_line, int n_wg, int first_line, int last_line) {
+// one value per lane (inactive lanes pass p = nullptr): loaded again while any lane of the wave still sees an empty slot
+template <typename T>
+__device__ __forceinline__ T tw_poll(const T* p, int* hdr, int32_t* err) {
+    T v = p ? tw_ld(p) : (T)1;
+    unsigned spins = 0;
+    while (__any(tw_empty(v))) {
+        if (!tw_spin(spins, hdr, err)) break;
+        if (p) v = tw_ld(p);
+    }
+    return v;
+}
+// the last workgroup through `done_line` advances the direction's launch count (the next launch publishes into the other copy) and
+// puts the give-up word back (all others are past their last poll: a workgroup adds here after it)
+__device__ __forceinline__ void tw_finish(int* hdr, int done_line, int epoch_line, int n_wg, int epoch) {
     const int old = tw_add(hdr + done_line * TW_LINE, 1);
     if (old == n_wg - 1) {
-        for (int l = first_line; l <= last_line; ++l) tw_st(hdr + l * TW_LINE, 0);
+        tw_st(hdr + done_line * TW_LINE, 0);
         tw_st(hdr + TW_POISON * TW_LINE, 0);
+        tw_st(hdr + epoch_line * TW_LINE, epoch + 1);
     }
 }
 
@@ -111,6 +135,7 @@ struct TwLayout {
     int64_t wd;              // backward: wide weight-gradient partials [n_tower*block][WD_LD] floats (slot wide_K = bias)
     int64_t loss;            // backward: [workgroup] doubles (a row's loss is added by the workgroup of its OWN tower)
     int64_t wide;            // forward: the wide term of every row [M] floats (each row formed by ONE workgroup, read by all towers)
+    int64_t copy;            // the record arrays above exist twice: copy 1 sits `copy` bytes behind copy 0 (the split form uses copy 0)
     int64_t total;
     int wd_ld;
 };
@@ -128,7 +153,9 @@ __host__ __device__ inline TwLayout tw_layout(int n_tower, int H1, int H2, int64
     o = (o + 15) / 16 * 16;
     L.loss = o; o += (int64_t)n_tower * G * 8;
     L.wide = o; o += (M + 3) / 4 * 16;
-    L.total = (o + 127) / 128 * 128;
+    o = (o + 127) / 128 * 128;
+    L.copy = o - TW_HDR_BYTES;
+    L.total = TW_HDR_BYTES + 2 * L.copy;
     return L;
 }
 
@@ -196,9 +223,9 @@ __device__ __forceinline__ void tw_acc_to_tile(const f32x4_t (&acc)[2][NT], floa
 // ---- forward statistics of one layer: this workgroup's (at most two) 64-row chunks -> workspace, in the order of
 // cdc_gemm_bf16_nt's statistics epilogue (csrc/gemm2.hip): wave q adds rows 16q..16q+15 of the chunk, quarters in order.
 // All threads call (barriers inside).  Waves 0 and 1 store; both have drained when the call returns.
-template <int C>
+template <int C, bool DRAIN = true>
 __device__ __forceinline__ void tw_fwd_chunk_sums(const float* ct, int cs, int row0, int M, double* quarter /*[2][4][64][2]*/, double* ws,
-                                                  int total_c, int col0, int wave, int lane) {
+                                                  int total_c, int col0, int wave, int lane, bool publish = true) {
     static_assert(TW_ROWS == 128, "two 64-row chunks per block");
     const int rows0 = min(64, M - row0), rows1 = min(64, M - row0 - 64);          // rows of the two chunks (rows1 may be <= 0)
     double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
@@ -212,30 +239,41 @@ __device__ __forceinline__ void tw_fwd_chunk_sums(const float* ct, int cs, int r
 #pragma unroll
     for (int h = 0; h < 2; ++h) { quarter[((h * 4 + wave) * 64 + lane) * 2] = s1[h]; quarter[((h * 4 + wave) * 64 + lane) * 2 + 1] = s2[h]; }
     __syncthreads();
-    if (wave < 2 && lane < C && (wave == 0 || rows1 > 0)) {                         // wave h publishes chunk h
+    if (publish && wave < 2 && lane < C && (wave == 0 || rows1 > 0)) {              // wave h publishes chunk h
         const int h = wave;
         double* p = ws + ((int64_t)(row0 / 64 + h) * total_c + col0 + lane) * 2;
         const double* q = quarter + (h * 4 * 64 + lane) * 2;
-        tw_st(p, ((q[0] + q[64 * 2]) + q[2 * 64 * 2]) + q[3 * 64 * 2]);
-        tw_st(p + 1, ((q[1] + q[64 * 2 + 1]) + q[2 * 64 * 2 + 1]) + q[3 * 64 * 2 + 1]);
+        tw_st(p, tw_nz(((q[0] + q[64 * 2]) + q[2 * 64 * 2]) + q[3 * 64 * 2]));
+        tw_st(p + 1, tw_nz(((q[1] + q[64 * 2 + 1]) + q[2 * 64 * 2 + 1]) + q[3 * 64 * 2 + 1]));
     }
-    tw_drain();                                                                    // every wave: also what it stored before this call
-    __syncthreads();                                                               // (the storing waves have drained; `quarter` is free again)
+    if (DRAIN) tw_drain();                                                         // (split form: every wave, also what it stored before this call)
+    __syncthreads();                                                               // (`quarter` is free again)
 }
 // Sum over `n_parts` published partial records of the tower's C columns, as cdc_bn_fwd's bn_sum_partials_v does: NP = 256 / C
 // threads per column take records pt, pt + NP, ... and the NP sums are added in order.  out[2][C] doubles in LDS.  All threads call.
+// POLL (hdr != nullptr): the monolithic kernels' exchange — a batch is loaded again while any of its records is still unpublished.
 template <int C>
-__device__ __forceinline__ void tw_gather_sums(const double* ws, int n_parts, int total_c, int col0, double* part /*[2][NP][C]*/, double* out, int tid) {
+__device__ __forceinline__ void tw_gather_sums(const double* ws, int n_parts, int total_c, int col0, double* part /*[2][NP][C]*/, double* out, int tid,
+                                               int* hdr = nullptr, int32_t* err = nullptr) {
     constexpr int NP = TW_THREADS / C, BATCH = 16;
     const int j = tid % C, pt = tid / C;
     double a1 = 0.0, a2 = 0.0;
+    unsigned spins = 0;
     for (int k0 = pt; k0 < n_parts; k0 += NP * BATCH) {                  // a batch's 32 loads are in flight together (one round trip
         double v1[BATCH], v2[BATCH];                                     // to L2 per batch, not per record); the adds keep the order
+        for (;;) {
+            bool bad = false;
 #pragma unroll
-        for (int b = 0; b < BATCH; ++b) {
-            const int k = k0 + b * NP;
-            const double* p = ws + ((int64_t)(k < n_parts ? k : pt) * total_c + col0 + j) * 2;
-            v1[b] = tw_ld(p); v2[b] = tw_ld(p + 1);
+            for (int b = 0; b < BATCH; ++b) {
+                const int k = k0 + b * NP;
+                const double* p = ws + ((int64_t)(k < n_parts ? k : pt) * total_c + col0 + j) * 2;
+                v1[b] = tw_ld(p); v2[b] = tw_ld(p + 1);
+            }
+            if (!hdr) break;
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) bad = bad || tw_empty(v1[b]) || tw_empty(v2[b]);
+            if (!__any(bad)) break;
+            if (!tw_spin(spins, hdr, err)) break;
         }
 #pragma unroll
         for (int b = 0; b < BATCH; ++b)
@@ -344,6 +382,24 @@ __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, uns
     unsigned char* wsb = reinterpret_cast<unsigned char*>(a.workspace);
     int32_t* err = a.err;
     const bool writer = jb == 0;
+    // the record copy of this launch; this workgroup's slots of the OTHER copy are cleared for the next launch
+    const int epoch = __builtin_amdgcn_readfirstlane(tw_ld(hdr + TW_FEPOCH * TW_LINE));
+    const bool mute = __builtin_amdgcn_readfirstlane(tw_ld(hdr + TW_MUTE * TW_LINE)) == (int)blockIdx.x + 1;
+    unsigned char* const rec = wsb + (epoch & 1) * L.copy;
+    {
+        unsigned char* const nxt = wsb + ((epoch + 1) & 1) * L.copy;
+        const int c0 = row0 / 64;                                        // this block's two 64-row chunks
+        for (int i = tid; i < 2 * 2 * H1; i += TW_THREADS) {
+            const int h = i / (2 * H1), k = i - h * 2 * H1;
+            if ((c0 + h) * 64 < M) tw_st(reinterpret_cast<double*>(nxt + L.st1) + ((int64_t)(c0 + h) * n_tower * H1 + t * H1) * 2 + k, 0.0);
+        }
+        for (int i = tid; i < 2 * 2 * H2; i += TW_THREADS) {
+            const int h = i / (2 * H2), k = i - h * 2 * H2;
+            if ((c0 + h) * 64 < M) tw_st(reinterpret_cast<double*>(nxt + L.st2) + ((int64_t)(c0 + h) * n_tower * H2 + t * H2) * 2 + k, 0.0);
+        }
+        if (a.wide_x)
+            for (int i = t + n_tower * tid; i < rows; i += n_tower * TW_THREADS) tw_st(reinterpret_cast<float*>(nxt + L.wide) + row0 + i, 0.f);
+    }
 
     unsigned char* XS = smem + Cfg::XS;
     unsigned char* W1S = smem + Cfg::W1S;
@@ -415,16 +471,15 @@ __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, uns
         }
     }
     __syncthreads();
-    tw_fwd_chunk_sums<H1>(ct, Cfg::CS1, row0, M, part, reinterpret_cast<double*>(wsb + L.st1), n_tower * H1, t * H1, wave, lane);
-    if (tid == 0) tw_arrive(hdr, TW_F1(t));
+    tw_fwd_chunk_sums<H1, false>(ct, Cfg::CS1, row0, M, part, reinterpret_cast<double*>(rec + L.st1), n_tower * H1, t * H1, wave, lane, !mute);
     TW_STAMP(2);
 
-    // ---- under the wait: the wide term (model/layer.py:122-126) of this block's rows l = t, t + n_tower, ... (the other towers'
-    // workgroups of the block form the rest; everyone reads all of them behind the second exchange, which is why that one is an
-    // exchange of ALL workgroups): a wave per row, 16-byte lanes, the loads of twelve rows in flight together
+    // ---- while the other workgroups' sums arrive: the wide term (model/layer.py:122-126) of this block's rows l = t, t + n_tower, ...
+    // (the other towers' workgroups of the block form the rest; everyone reads all of them in front of the head): a wave per row,
+    // 16-byte lanes, the loads of twelve rows in flight together
     if (a.wide_x) {
         const float* wx = a.wide_x; const int64_t ldw = a.ld_wide; const int K4 = a.wide_K >> 2;
-        float* pub = reinterpret_cast<float*>(wsb + L.wide);
+        float* pub = reinterpret_cast<float*>(rec + L.wide);
         f32x4_t wv[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) wv[q] = (lane + 64 * q) < K4 ? *reinterpret_cast<const f32x4_t*>(a.wide_w + 4 * (lane + 64 * q)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -455,17 +510,13 @@ __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, uns
 #pragma unroll
             for (int b = 0; b < 12; ++b) {
                 const int i = i0 + 4 * b;
-                if (lane == 0 && i < n_mine) tw_st(pub + row0 + t + n_tower * i, sv[b] + wb);
+                if (lane == 0 && i < n_mine) tw_st(pub + row0 + t + n_tower * i, tw_nz(sv[b] + wb));
             }
         }
-        // (no drain here: these write-through stores have until the second exchange's arrival; every wave drains in front of the
-        // barrier that precedes it, tw_fwd_chunk_sums)
     }
     TW_STAMP(3);
-    if (tid == 0) (void)tw_wait(hdr, TW_F1(t), G, err);
-    __syncthreads();
     TW_STAMP(4);
-    tw_gather_sums<H1>(reinterpret_cast<const double*>(wsb + L.st1), (M + 63) / 64, n_tower * H1, t * H1, part, sums, tid);
+    tw_gather_sums<H1>(reinterpret_cast<const double*>(rec + L.st1), (M + 63) / 64, n_tower * H1, t * H1, part, sums, tid, hdr, err);
     tw_finish_stats<H1>(sums, M, a.eps, a.momentum, writer, T.l1.save_mean, T.l1.save_invstd, T.l1.running_mean, T.l1.running_var,
                         T.l1.num_batches_tracked, col_mean, col_inv, tid);
     if (keep && tid < H1) { keep[tid] = col_mean[tid]; keep[64 + tid] = col_inv[tid]; }
@@ -521,16 +572,14 @@ __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, uns
         }
     }
     __syncthreads();
-    tw_fwd_chunk_sums<H2>(ct, Cfg::CS2, row0, M, part, reinterpret_cast<double*>(wsb + L.st2), n_tower * H2, t * H2, wave, lane);
+    tw_fwd_chunk_sums<H2, false>(ct, Cfg::CS2, row0, M, part, reinterpret_cast<double*>(rec + L.st2), n_tower * H2, t * H2, wave, lane);
     TW_STAMP(6);
-    if (tid == 0) {
-        tw_arrive(hdr, TW_F2(0));                                        // ALL workgroups (the wide term's rows come from every tower's)
-        (void)tw_wait(hdr, TW_F2(0), n_tower * G, err);
-    }
-    __syncthreads();
     TW_STAMP(7);
-    if (a.wide_x && tid < rows) wide_s[tid] = tw_ld(reinterpret_cast<const float*>(wsb + L.wide) + row0 + tid);
-    tw_gather_sums<H2>(reinterpret_cast<const double*>(wsb + L.st2), (M + 63) / 64, n_tower * H2, t * H2, part, sums, tid);
+    tw_gather_sums<H2>(reinterpret_cast<const double*>(rec + L.st2), (M + 63) / 64, n_tower * H2, t * H2, part, sums, tid, hdr, err);
+    if (a.wide_x && wave < (rows + 63) / 64) {                           // (behind the sums: the block's other workgroups published these long ago)
+        const float v = tw_poll<float>(tid < rows ? reinterpret_cast<const float*>(rec + L.wide) + row0 + tid : nullptr, hdr, err);
+        if (tid < rows) wide_s[tid] = v;
+    }
     tw_finish_stats<H2>(sums, M, a.eps, a.momentum, writer, T.l2.save_mean, T.l2.save_invstd, T.l2.running_mean, T.l2.running_var,
                         T.l2.num_batches_tracked, col_mean, col_inv, tid);
     if (keep && tid < H2) { keep[128 + tid] = col_mean[tid]; keep[192 + tid] = col_inv[tid]; }
@@ -577,7 +626,7 @@ __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, uns
         }
     }
     TW_STAMP(9);
-    if (tid == 0) tw_finish(hdr, TW_FDONE, n_tower * G, TW_F1(0), TW_FDONE);
+    if (tid == 0) tw_finish(hdr, TW_FDONE, TW_FEPOCH, n_tower * G, epoch);
 }
 
 // =================================================================================================
@@ -729,6 +778,19 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
         if (which == 2 && k < H2) par_s[TW_PAR_WO + k] = T.wo[k];
     }
 
+    // the record copy of this launch; this workgroup's slots of the OTHER copy are cleared for the next launch
+    const int epoch = __builtin_amdgcn_readfirstlane(tw_ld(hdr + TW_BEPOCH * TW_LINE));
+    unsigned char* const rec = wsb + (epoch & 1) * L.copy;
+    {
+        unsigned char* const nxt = wsb + ((epoch + 1) & 1) * L.copy;
+        for (int i = tid; i < 2 * H2; i += TW_THREADS) tw_st(reinterpret_cast<double*>(nxt + L.b2) + ((int64_t)jb * n_tower * H2 + t * H2) * 2 + i, 0.0);
+        for (int i = tid; i < 2 * H1; i += TW_THREADS) tw_st(reinterpret_cast<double*>(nxt + L.b1) + ((int64_t)jb * n_tower * H1 + t * H1) * 2 + i, 0.0);
+        if (tid <= H2) tw_st(reinterpret_cast<float*>(nxt + L.hd) + ((int64_t)jb * n_tower + t) * (H2 + 4) + tid, 0.f);
+        if (has_wide)
+            for (int i = tid; i < L.wd_ld; i += TW_THREADS) tw_st(reinterpret_cast<float*>(nxt + L.wd) + ((int64_t)t * G + jb) * L.wd_ld + i, 0.f);
+        if (tid == 0) tw_st(reinterpret_cast<double*>(nxt + L.loss) + blockIdx.x, 0.0);
+    }
+
     // ---- grad-input operands: W2^T and W1^T -> LDS (needed after the first exchange: they land under everything before it)
     tw_load_tile(reinterpret_cast<const __bf16*>(T.l2.wt), T.l2.ldwt, 0, H1, H1, WT2S, wave, lane);
     tw_load_tile(reinterpret_cast<const __bf16*>(T.l1.wt), T.l1.ldwt, 0, H0, H0, WT1S, wave, lane);
@@ -842,8 +904,8 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
     __syncthreads();
     tw_block_sums<H2>(DZ2, XH2, Cfg::CS2, rows, part, sums, tid);
     {
-        double* b2 = reinterpret_cast<double*>(wsb + L.b2) + ((int64_t)jb * n_tower * H2 + t * H2) * 2;
-        if (tid < H2) { tw_st(b2 + 2 * tid, sums[tid]); tw_st(b2 + 2 * tid + 1, sums[H2 + tid]); }
+        double* b2 = reinterpret_cast<double*>(rec + L.b2) + ((int64_t)jb * n_tower * H2 + t * H2) * 2;
+        if (tid < H2) { tw_st(b2 + 2 * tid, tw_nz(sums[tid])); tw_st(b2 + 2 * tid + 1, tw_nz(sums[H2 + tid])); }
     }
     // head weight gradient of this block: dwo[c] = sum_r d[r] a2[r, c], dbo = sum_r d[r]  (fp64 sums, stored as fp32 partials)
     {
@@ -853,30 +915,28 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
         for (int r = pt * RPP; r < min((pt + 1) * RPP, rows); ++r) { s += (double)(d_s[r] * A2T[r * Cfg::CS2 + j]); sb += (double)d_s[r]; }
         part[(0 * NPT + pt) * H2 + j] = s; part[(1 * NPT + pt) * H2 + j] = sb;
         __syncthreads();
-        float* hd = reinterpret_cast<float*>(wsb + L.hd) + ((int64_t)jb * n_tower + t) * (H2 + 4);
+        float* hd = reinterpret_cast<float*>(rec + L.hd) + ((int64_t)jb * n_tower + t) * (H2 + 4);
         if (tid < H2) {
             double b = 0.0;
 #pragma unroll
             for (int q = 0; q < NPT; ++q) b += part[(0 * NPT + q) * H2 + tid];
-            tw_st(hd + tid, (float)b);
+            tw_st(hd + tid, tw_nz((float)b));
         } else if (tid == H2) {
             double b = 0.0;
 #pragma unroll
             for (int q = 0; q < NPT; ++q) b += part[(1 * NPT + q) * H2 + 0];
-            tw_st(hd + H2, (float)b);
+            tw_st(hd + H2, tw_nz((float)b));
         }
         if (bce && wave == 1) {                                          // the loss of the block's rows of this tower
             double s_ = (lane < rows ? loss_s[lane] : 0.0) + (lane + 64 < rows ? loss_s[lane + 64] : 0.0);
             s_ = wave_sum_d(s_);
-            if (lane == 0) tw_st(reinterpret_cast<double*>(wsb + L.loss) + blockIdx.x, s_);
+            if (lane == 0) tw_st(reinterpret_cast<double*>(rec + L.loss) + blockIdx.x, tw_nz(s_));
         }
     }
-    tw_drain();
     __syncthreads();
-    if (tid == 0) tw_arrive(hdr, TW_B3(t));
     TW_STAMP(18);
 
-    // ---- under the wait: the wide term's gradients for the rows this workgroup owns (k_head_bwd (3)): a wave per row
+    // ---- while the other workgroups' sums arrive: the wide term's gradients for the rows this workgroup owns (k_head_bwd (3)): a wave per row
     if (has_wide) {
         const int K4 = wide_K >> 2;
         const int n_own = own_s[TW_ROWS];
@@ -901,11 +961,11 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
             if ((lane + 64 * q) < K4) *reinterpret_cast<f32x4_t*>(mine + 4 * (lane + 64 * q)) = dwv[q];
         if (lane == 0) mine[wide_K] = dbv;
         __syncthreads();
-        float* wd = reinterpret_cast<float*>(wsb + L.wd) + ((int64_t)t * G + jb) * L.wd_ld;
+        float* wd = reinterpret_cast<float*>(rec + L.wd) + ((int64_t)t * G + jb) * L.wd_ld;
         for (int k = 2 * tid; k <= wide_K; k += 2 * TW_THREADS) {            // 8-byte write-through stores (a 4-byte one costs as much)
             union { float f[2]; unsigned long long u; } pk;
-            pk.f[0] = ((wdw_s[k] + wdw_s[520 + k]) + wdw_s[2 * 520 + k]) + wdw_s[3 * 520 + k];
-            pk.f[1] = k + 1 <= wide_K ? ((wdw_s[k + 1] + wdw_s[520 + k + 1]) + wdw_s[2 * 520 + k + 1]) + wdw_s[3 * 520 + k + 1] : 0.f;
+            pk.f[0] = tw_nz(((wdw_s[k] + wdw_s[520 + k]) + wdw_s[2 * 520 + k]) + wdw_s[3 * 520 + k]);
+            pk.f[1] = k + 1 <= wide_K ? tw_nz(((wdw_s[k + 1] + wdw_s[520 + k + 1]) + wdw_s[2 * 520 + k + 1]) + wdw_s[3 * 520 + k + 1]) : 0.f;
             tw_st(reinterpret_cast<unsigned long long*>(wd + k), pk.u);
         }
     }
@@ -927,10 +987,8 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
         }
     }
     TW_STAMP(19);
-    if (tid == 0) (void)tw_wait(hdr, TW_B3(t), G, err);
-    __syncthreads();
     TW_STAMP(20);
-    tw_gather_sums<H2>(reinterpret_cast<const double*>(wsb + L.b2), G, n_tower * H2, t * H2, part, sums, tid);
+    tw_gather_sums<H2>(reinterpret_cast<const double*>(rec + L.b2), G, n_tower * H2, t * H2, part, sums, tid, hdr, err);
     if (writer) {
         if (tid < H2) {
             if (T.l2.dbeta) T.l2.dbeta[tid] = (float)sums[tid];
@@ -942,12 +1000,20 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
         // adds the eight
         for (int k = tid >> 3; k <= H2; k += TW_THREADS / 8) {
             const int p8 = tid & 7;
-            const float* hd = reinterpret_cast<const float*>(wsb + L.hd) + (int64_t)t * (H2 + 4) + k;
+            const float* hd = reinterpret_cast<const float*>(rec + L.hd) + (int64_t)t * (H2 + 4) + k;
             float s = 0.f;
+            unsigned spins = 0;
             for (int b0 = p8; b0 < G; b0 += 64) {
                 float v[8];
+                for (;;) {                                               // (published in front of the sums gathered above: rarely a second pass)
+                    bool bad = false;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = (b0 + 8 * q) < G ? tw_ld(hd + (int64_t)(b0 + 8 * q) * n_tower * (H2 + 4)) : 0.f;
+                    for (int q = 0; q < 8; ++q) {
+                        v[q] = (b0 + 8 * q) < G ? tw_ld(hd + (int64_t)(b0 + 8 * q) * n_tower * (H2 + 4)) : 0.f;
+                        bad = bad || ((b0 + 8 * q) < G && tw_empty(v[q]));
+                    }
+                    if (!bad || !tw_spin(spins, hdr, err)) break;
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) s += v[q];
             }
@@ -1018,19 +1084,12 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
     __syncthreads();
     tw_block_sums<H1>(DZ1, XH1, Cfg::CS1, rows, part, sums, tid);
     {
-        double* b1 = reinterpret_cast<double*>(wsb + L.b1) + ((int64_t)jb * n_tower * H1 + t * H1) * 2;
-        if (tid < H1) { tw_st(b1 + 2 * tid, sums[tid]); tw_st(b1 + 2 * tid + 1, sums[H1 + tid]); }
+        double* b1 = reinterpret_cast<double*>(rec + L.b1) + ((int64_t)jb * n_tower * H1 + t * H1) * 2;
+        if (tid < H1) { tw_st(b1 + 2 * tid, tw_nz(sums[tid])); tw_st(b1 + 2 * tid + 1, tw_nz(sums[H1 + tid])); }
     }
-    tw_drain();
-    __syncthreads();
     TW_STAMP(23);
-    if (tid == 0) {
-        tw_arrive(hdr, TW_B4);                                           // ALL towers: the wide gradient's partials come from all of them
-        (void)tw_wait(hdr, TW_B4, n_wg, err);
-    }
-    __syncthreads();
     TW_STAMP(24);
-    tw_gather_sums<H1>(reinterpret_cast<const double*>(wsb + L.b1), G, n_tower * H1, t * H1, part, sums, tid);
+    tw_gather_sums<H1>(reinterpret_cast<const double*>(rec + L.b1), G, n_tower * H1, t * H1, part, sums, tid, hdr, err);
     TW_STAMP(25);
     if (writer && tid < H1) {
         if (T.l1.dbeta) T.l1.dbeta[tid] = (float)sums[tid];
@@ -1090,10 +1149,21 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
     // ---- (7) sums over ALL workgroups (published before the last exchange): the wide term's weight gradient (a wave per
     // column: lanes take partials l, l + 64, ... in order, then a butterfly) and the loss
     if (has_wide) {
-        const float* wd = reinterpret_cast<const float*>(wsb + L.wd);
+        const float* wd = reinterpret_cast<const float*>(rec + L.wd);
         for (int k = (int)blockIdx.x * 4 + wave; k <= wide_K; k += n_wg * 4) {
-            float s = 0.f;
-            for (int p = lane; p < n_wg; p += 64) s += tw_ld(wd + (int64_t)p * L.wd_ld + k);
+            float v[4];                                                  // n_wg <= 256: at most four partials per lane, in flight together
+            unsigned spins = 0;
+            for (;;) {
+                bool bad = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = lane + 64 * q;
+                    v[q] = p < n_wg ? tw_ld(wd + (int64_t)p * L.wd_ld + k) : 0.f;
+                    bad = bad || (p < n_wg && tw_empty(v[q]));
+                }
+                if (!__any(bad) || !tw_spin(spins, hdr, err)) break;
+            }
+            float s = ((v[0] + v[1]) + v[2]) + v[3];
             s = wave_sum(s);
             if (lane == 0) {
                 if (k < wide_K) { if (a.wide_dw) a.wide_dw[k] = s; }
@@ -1102,14 +1172,25 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
         }
     }
     if (bce && blockIdx.x == 0 && wave == 1 && a.bce_loss) {
-        const double* lp = reinterpret_cast<const double*>(wsb + L.loss);
-        double s = 0.0;
-        for (int b = lane; b < n_wg; b += 64) s += tw_ld(lp + b);
+        const double* lp = reinterpret_cast<const double*>(rec + L.loss);
+        double v[4];
+        unsigned spins = 0;
+        for (;;) {
+            bool bad = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = lane + 64 * q;
+                v[q] = p < n_wg ? tw_ld(lp + p) : 0.0;
+                bad = bad || (p < n_wg && tw_empty(v[q]));
+            }
+            if (!__any(bad) || !tw_spin(spins, hdr, err)) break;
+        }
+        double s = ((v[0] + v[1]) + v[2]) + v[3];
         s = wave_sum_d(s);
         if (lane == 0) *a.bce_loss = (float)(s * (double)a.bce_inv_count);
     }
     TW_STAMP(28);
-    if (tid == 0) tw_finish(hdr, TW_BDONE, n_wg, TW_B3(0), TW_BDONE);
+    if (tid == 0) tw_finish(hdr, TW_BDONE, TW_BEPOCH, n_wg, epoch);
 }
 
 template <int NK0, int H1, int H2>

@@ -767,9 +767,9 @@ int64_t cdc_head_workspace_floats(const cdc_head_args* a);
  * Geometry: a workgroup owns CDC_TOWER_ROWS rows of one tower; grid = n_tower * ceil(M / CDC_TOWER_ROWS) workgroups, which
  * must all be resident (checked against 256 CUs: M <= 256 / n_tower * CDC_TOWER_ROWS, else CDC_E_TOOBIG).  The column sums a
  * BatchNorm needs over all rows are exchanged INSIDE the launch: every workgroup publishes its partial sums with write-through
- * stores and adds to an arrival counter, waits (bounded) until the counter holds every workgroup of its tower, and adds the
- * partials up in a fixed order (deterministic; identical in every workgroup).  A wait that runs out sets bit CDC_TOWER_ERR_TIMEOUT
- * in *err (results of that step are then undefined) and poisons the remaining waits of the launch so that it still ends.
+ * stores (a published value is never all-zero bits), loads the partials of every workgroup of its tower — again while any slot is
+ * still empty (bounded) — and adds them up in a fixed order (deterministic; identical in every workgroup).  A poll that runs out
+ * sets bit CDC_TOWER_ERR_TIMEOUT in *err (results of that step are then undefined) and ends the remaining polls of the launch.
  * `workspace`: cdc_tower_workspace_bytes() bytes, zeroed once by the caller, private to one (fwd, bwd) pair at a time.
  * Instantiated for H0 in {64, 128}, H1 = 64, H2 = 32 (config.py:39-42: tower_dims (64, 32)); anything else: CDC_E_BADARG.
  * ---------------------------------------------------------------------------------------- */

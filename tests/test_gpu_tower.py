@@ -237,7 +237,7 @@ def test_both_directions_in_one_launch_equal_the_two_launches(cuda, B, n_tower, 
 
 @pytest.mark.parametrize("both", [True, False])
 def test_a_wait_that_cannot_complete_gives_up_and_says_so(cuda, both):
-    """The in-launch exchange is a bounded spin: with an arrival counter that can never reach its target the launch still ends (~0.3 s),
+    """The in-launch exchange is a bounded poll: with a record that is never published the launch still ends (~0.3 s),
     the error word carries CDC_TOWER_ERR_TIMEOUT, TrainStep.check_ids() raises, and the following step runs normally (the last workgroup
     of a launch puts the counters back)."""
     from cdcmdr_amd import _lib as L
@@ -257,9 +257,10 @@ def test_a_wait_that_cannot_complete_gives_up_and_says_so(cuda, both):
     ts.step(x, y, x[:, 10].long())
     ts.check_ids()
     good = float(ts.loss.item())
-    # counter of tower 1's first forward exchange: 128-byte lines of int32 at the head of the workspace
+    # the test hook in the header of the workspace (128-byte lines of int32; csrc/tower.hip TW_MUTE): workgroup 1 of the next forward
+    # publishes no layer-1 sums, so its tower's other workgroups never find them
     hdr = chain.ws.view(torch.int32)
-    hdr[1 * 32] = -100000
+    hdr[1 * 32] = 2
     ts.step(x, y, x[:, 10].long())
     torch.cuda.synchronize()
     assert int(chain.tmo_word.item()) & L.TOWER_ERR_TIMEOUT
