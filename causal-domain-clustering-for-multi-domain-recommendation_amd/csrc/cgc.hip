@@ -23,7 +23,6 @@
 //     the compiler keep a private copy of all 2.5 KB of it in scratch), and descriptor fields are copied to locals before the
 //     loops that use them: reads through that pointer are not treated as invariant across stores.
 #include "common.h"
-#include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -39,7 +38,17 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define MID_KARG __attribute__((address_space(4)))   /* the kernarg segment: constant address space */
 #define MID_JPW 3                       /* forward: MFMA tiles per wave whose B fragments are fetched at kernel entry */
 #define MID_JPW2 2                      /* backward: the same for the grad-input tiles */
-#define MID_XCH 8                       /* backward: experts whose rows a lane holds in registers at once */
+#define MID_XW 2                        /* backward: experts whose row pieces a lane holds in registers at once (a wave takes every fourth expert) */
+#ifndef MID_TRACE
+#define MID_TRACE 0                     /* probe builds only (tools/mid_trace.py): thread 0 of workgroup 0 stamps the 100 MHz wall clock at phase boundaries */
+#endif
+#if MID_TRACE
+__device__ unsigned long long g_mid_stamps[32];
+#define MID_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mid_stamps[(i)] = wall_clock64(); } while (0)
+extern "C" int cdc_debug_mid_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mid_stamps), sizeof(unsigned long long) * 32); }
+#else
+#define MID_STAMP(i) do { } while (0)
+#endif
 #define MID_MAXSTEP 6                   /* K steps of 32 per grad-input tile: 2 per expert reading the source + 1 per gate */
 
 template <int H1, int H2>
@@ -74,23 +83,53 @@ __device__ __forceinline__ float mid_wave_sum(float v) {
     return v;
 }
 
-// sel lists and position tables in LDS: sel[g][j] (bytes) and pos[g][e] = index of expert e in gate g's ascending sel list or -1
+// sum over the 16 lanes of a DPP row, result in every lane of the row: four cross-lane adds in the VALU (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror) — the pool backwards give a batch row to 16 lanes
+__device__ __forceinline__ float mid_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// sel lists and position tables in LDS: sel[g][j] (bytes) and pos[g][e] = index of expert e in gate g's ascending sel list or -1.
+// Thread (g, j) fetches ONE entry of gate g's list from the argument block (one round trip for the whole table: a loop over the list
+// in every thread was a dependent chain of them, several microseconds at the head of both kernels); the 16 threads of a gate sit in
+// one wave, whose LDS instructions execute in order, so thread (g, e) finds the complete list in LDS for its look-up.
+struct MidTabReg { int ns, sv; };
 template <typename GatePtr>
-__device__ __forceinline__ void mid_fill_tables(signed char (*pos)[MID_E], unsigned char (*sel)[CDC_MAX_SEL], GatePtr gates, int n_gate, int tid) {
+__device__ __forceinline__ MidTabReg mid_tables_fetch(GatePtr gates, int n_gate, int tid) {            // the round trip (issue early)
+    MidTabReg t = {0, 0};
     if (tid < MID_G * MID_E) {
-        const int g = tid / MID_E, e = tid % MID_E;                  // (MID_E == CDC_MAX_SEL: the same thread fills sel[g][e])
-        int p = -1, sv = 0;
+        const int g = tid / MID_E, e = tid % MID_E;
         if (g < n_gate) {
-            const int ns = gates[g].n_sel;
-            for (int j = 0; j < ns; ++j)
-                if (gates[g].sel[j] == e) p = j;
-            if (e < ns) sv = gates[g].sel[e];
+            t.ns = gates[g].n_sel;
+            t.sv = gates[g].sel[e];                                    // (slots >= n_sel of the argument block are readable; masked below)
         }
+    }
+    return t;
+}
+__device__ __forceinline__ void mid_tables_store(signed char (*pos)[MID_E], unsigned char (*sel)[CDC_MAX_SEL], const MidTabReg& t, int tid) {
+    if (tid < MID_G * MID_E) {
+        const int g = tid / MID_E, e = tid % MID_E;
+        sel[g][e] = (unsigned char)(e < t.ns ? t.sv : 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int p = -1;
+#pragma unroll
+        for (int q = 0; q < MID_E; ++q)
+            if (q < t.ns && sel[g][q] == e) p = q;
         pos[g][e] = (signed char)p;
-        sel[g][e] = (unsigned char)sv;
     }
 }
+template <typename GatePtr>
+__device__ __forceinline__ void mid_fill_tables(signed char (*pos)[MID_E], unsigned char (*sel)[CDC_MAX_SEL], GatePtr gates, int n_gate, int tid) {
+    mid_tables_store(pos, sel, mid_tables_fetch(gates, n_gate, tid), tid);
+}
 static_assert(MID_E == CDC_MAX_SEL, "mid_fill_tables fills both tables with one index");
+static_assert(2 * MID_E + MID_G <= 64, "k_cgc_mid_bwd: one lane of a wave per grad-input K-step candidate");
 
 // softmax over n_sel <= 16 values exactly as cdc_gate_pool_fwd computes it (max-subtract, expf, sum in index order, one divide)
 __device__ __forceinline__ void mid_softmax(float (&p)[CDC_MAX_SEL], int n_sel) {
@@ -143,6 +182,47 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     const bool live = row < B;
     const int64_t last_row = B - 1;
 
+    MID_STAMP(0);
+    const int32_t sp_val = (a.drop_p > 0.f && a.seed_offset_dev) ? *a.seed_offset_dev : 0;     // (consumed behind the entry's other loads)
+    // ---- (0) the level-k gate logits of this wave's row, lane g = gate g: they head the longest dependent chain of the entry
+    //      (descriptor -> logits -> softmax -> pooling), so they are issued first; the descriptors come by scalar loads (a lane-indexed
+    //      read of the argument block is a vector-memory round trip of its own)
+    // EVERY read of the argument block the entry needs goes out before the first of them is used (the block lives where the launch put
+    // it — host-visible memory for a plain launch: a read is a microsecond or two, and reads issued one behind the other's result were
+    // most of the entry's 9 us): the gates' descriptors — all MID_G slots, unconditionally: the slots exist whatever n_gate1 is —, the
+    // descriptors of this wave's first tiles, the table entries (a lane-indexed read)
+    float p_a1[CDC_MAX_SEL];
+    int ns_a1 = 0;
+    float* pr_a1 = nullptr;
+    const float* lg_a1 = nullptr;
+#pragma unroll
+    for (int g = 0; g < MID_G; ++g) {
+        const int ns = a.g1[g].n_sel;
+        const float* lgp = a.g1[g].logits + row * a.g1[g].ld_logits;
+        float* prp = a.g1[g].probs + row * ns;
+        if (lane == g) { ns_a1 = ns; lg_a1 = lgp; pr_a1 = prp; }
+    }
+    if (lane >= ng1) ns_a1 = 0;
+    struct JobDesc { const __bf16* W; int64_t ldw; const float* bp; int n_rows, nt; bool on; };
+    auto job_desc = [&](int i) __attribute__((always_inline)) {
+        const int job = wave + MID_WAVES * i;
+        const bool on = job < n_jobs, is_gate = job >= n_tile_jobs;
+        const int e = (on && !is_gate) ? job / Cfg::NT2 : 0, nt = (on && !is_gate) ? job % Cfg::NT2 : 0;
+        const int t = (on && is_gate) ? job - n_tile_jobs : 0;
+        JobDesc d;
+        d.W = reinterpret_cast<const __bf16*>(is_gate ? a.g2[t].w : a.e2[e].w);
+        d.ldw = is_gate ? a.g2[t].ldw : a.e2[e].ldw;
+        d.bp = is_gate ? a.g2[t].bias : a.e2[e].bias;
+        d.n_rows = is_gate ? a.g2[t].n_sel : H2;                       // weight rows (= output columns) that exist
+        d.nt = nt; d.on = on;
+        return d;
+    };
+    JobDesc jd[MID_JPW];
+#pragma unroll
+    for (int i = 0; i < MID_JPW; ++i) jd[i] = job_desc(i);
+    const MidTabReg tab1 = mid_tables_fetch(a.g1, ng1, tid), tab2 = mid_tables_fetch(a.g2, ng2, tid);
+#pragma unroll
+    for (int j = 0; j < CDC_MAX_SEL; ++j) p_a1[j] = (live && j < ns_a1) ? lg_a1[j] : 0.f;
     // ---- entry: every load that depends on nothing.  (1) the level-k expert rows of the block -> LDS, 1 KiB (two rows of one
     //      expert) per wave instruction; rows past the batch re-read the last row (their results are never stored)
     {
@@ -156,54 +236,44 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
             mid_glds16(ex1 + grow * ld_ex1 + (int64_t)e * H1 + (lane % (H1 / 4)) * 4, reinterpret_cast<unsigned char*>(xs) + (size_t)k * 1024);
         }
     }
-    // (2) the B fragments (and the bias of the lane's output column) of this wave's tiles: job = wave + 16 * i -> expert tile (e, nt) or gate t
-    auto load_w = [&](bf16x8_t (&w)[KS], float& bias, int i) __attribute__((always_inline)) {
-        const int job = wave + MID_WAVES * i;
-        const bool on = job < n_jobs, is_gate = job >= n_tile_jobs;
-        const int e = (on && !is_gate) ? job / Cfg::NT2 : 0, nt = (on && !is_gate) ? job % Cfg::NT2 : 0;
-        const int t = (on && is_gate) ? job - n_tile_jobs : 0;
-        const __bf16* W = reinterpret_cast<const __bf16*>(is_gate ? a.g2[t].w : a.e2[e].w);
-        const int64_t ldw = is_gate ? a.g2[t].ldw : a.e2[e].ldw;
-        const float* bp = is_gate ? a.g2[t].bias : a.e2[e].bias;
-        const int n_rows = is_gate ? a.g2[t].n_sel : H2;               // weight rows (= output columns) that exist
-        const int wrow = nt * 16 + frow;
+    // (2) the B fragments (and the bias of the lane's output column) of this wave's tiles: job = wave + 16 * i -> expert tile (e, nt) or
+    //     gate t.  The descriptors of a job are scalar loads; those of the first MID_JPW jobs are gathered before any of the fragment
+    //     loads is issued, so that they travel together (job by job they were a chain of round trips: 2.4 us of the entry)
+    auto load_wd = [&](bf16x8_t (&w)[KS], float& bias, const JobDesc& d) __attribute__((always_inline)) {
+        const int wrow = d.nt * 16 + frow;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            w[ks] = (on && wrow < n_rows) ? *reinterpret_cast<const bf16x8_t*>(W + (int64_t)wrow * ldw + ks * 32 + fk) : (bf16x8_t)(__bf16)0.f;
-        bias = (on && bp && wrow < n_rows) ? bp[wrow] : 0.f;
+            w[ks] = (d.on && wrow < d.n_rows) ? *reinterpret_cast<const bf16x8_t*>(d.W + (int64_t)wrow * d.ldw + ks * 32 + fk) : (bf16x8_t)(__bf16)0.f;
+        bias = (d.on && d.bp && wrow < d.n_rows) ? d.bp[wrow] : 0.f;
     };
+    auto load_w = [&](bf16x8_t (&w)[KS], float& bias, int i) __attribute__((always_inline)) { load_wd(w, bias, job_desc(i)); };
     bf16x8_t wq[MID_JPW][KS];
     float bq[MID_JPW];
 #pragma unroll
-    for (int i = 0; i < MID_JPW; ++i) load_w(wq[i], bq[i], i);
+    for (int i = 0; i < MID_JPW; ++i) load_wd(wq[i], bq[i], jd[i]);
     uint32_t seed_base = 0u;                                           // g2_seed32 without its per-call read of the step counter
     const float drop_p = a.drop_p;
     const int relu = a.relu;
     if (drop_p > 0.f) {
         const uint64_t seed = a.seed;
-        const int32_t* sp = a.seed_offset_dev;
         seed_base = (uint32_t)seed ^ (uint32_t)(seed >> 32) * 0x9E3779B1U;
-        if (sp) seed_base ^= (uint32_t)(*sp) * 0x85EBCA77U;
+        if (a.seed_offset_dev) seed_base ^= (uint32_t)sp_val * 0x85EBCA77U;
     }
-    mid_fill_tables(pos1, sel1, a.g1, ng1, tid);
-    mid_fill_tables(pos2, sel2, a.g2, ng2, tid);
+    mid_tables_store(pos1, sel1, tab1, tid);
+    mid_tables_store(pos2, sel2, tab2, tid);
     // ---- A1: level-k gate probabilities: lane g of wave r takes (row r, gate g)
     if (lane < ng1) {
         const int g = lane;
-        const int ns = a.g1[g].n_sel;
-        const float* lg = a.g1[g].logits + row * a.g1[g].ld_logits;
-        float* pr = a.g1[g].probs + row * ns;
-        float p[CDC_MAX_SEL];
-#pragma unroll
-        for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] = (live && j < ns) ? lg[j] : 0.f;
-        mid_softmax(p, ns);
+        mid_softmax(p_a1, ns_a1);
 #pragma unroll
         for (int j = 0; j < CDC_MAX_SEL; ++j) {
-            p1[(r * ng1 + g) * 16 + j] = p[j];
-            if (j < ns && live) pr[j] = p[j];
+            p1[(r * ng1 + g) * 16 + j] = p_a1[j];
+            if (j < ns_a1 && live) pr_a1[j] = p_a1[j];
         }
     }
+    MID_STAMP(1);
     __syncthreads();                                                   // (waits for the direct-to-LDS loads as well)
+    MID_STAMP(2);
     // ---- A2: pooled level-k vectors; sel ascending = the summation order of the reference
     {
         const int c = lane * 2;
@@ -222,6 +292,7 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();                                                   // pooled vectors complete; xs is dead from here (x2 takes its place)
+    MID_STAMP(3);
     // ---- B: level-k+1 experts (16 x 16 tiles, K = H1) and gate logits
     {
         const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -270,6 +341,7 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
+    MID_STAMP(4);
     // ---- D1: level-k+1 gate probabilities, in place: lane t of wave r takes (row r, gate t)
     if (lane < ng2) {
         const int t = lane;
@@ -286,6 +358,7 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
+    MID_STAMP(5);
     // ---- D2: second pooling out of LDS (lane = column); the expert tiles go to memory for the backward
     {
         const int c2 = lane;
@@ -306,6 +379,7 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
             }
         }
     }
+    MID_STAMP(6);
 }
 
 template <int H1, int H2>
@@ -404,6 +478,8 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     const bool live = row < B;
     const int64_t last_row = B - 1;
 
+    MID_STAMP(16);
+    const MidTabReg tab1 = mid_tables_fetch(a.g1, ng1, tid), tab2 = mid_tables_fetch(a.g2, ng2, tid);    // (stored into LDS behind the entry's loads)
     // ---- entry: direct-to-LDS loads of the gradients of the level-k+1 pooled outputs (1 KiB = four rows per wave instruction)
     //      and of both levels' probabilities (256 B = four rows of one gate per wave instruction; slots j >= n_sel hold a
     //      duplicate and are never read); rows past the batch re-read the last row (nothing of theirs is stored)
@@ -426,43 +502,70 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
             mid_glds4(pr + grow * ns + j, reinterpret_cast<unsigned char*>(lvl2 ? p2 : p1) + ((size_t)g * MID_BM + (k % 4) * 4) * 64);
         }
     }
-    // the expert rows of both pool backwards: one column of level k+1 and two of level k per lane, MID_XCH experts at a time in
-    // registers (all of them when a level has at most MID_XCH experts — then no load of theirs is issued after this point)
-    float x2r[MID_XCH];
-    f32x2_t x1r[MID_XCH];
-    const float* ex2p = a.ex2 + row * a.ld_ex2 + lane;
-    const float* ex1p = a.ex1 + row * a.ld_ex1 + lane * 2;
-    auto load_x2 = [&](int e0) __attribute__((always_inline)) {
+    // the pool backwards (phases 1 and 3): a batch row belongs to the 16 lanes of a DPP row — wave w takes rows 4 (w & 3) .. + 3 and
+    // the experts e = (w >> 2), (w >> 2) + 4, ...; a lane holds four columns of level k+1 (two times four of level k) of its row, so
+    // that a gate-gradient dot product is four (eight) multiply-adds and four in-row DPP adds for FOUR rows at once.  (Round 3 gave
+    // a row to a whole wave, a column to a lane: a 64-lane tree with two LDS-crossbar steps per (expert, gate) pair and row — with 16
+    // waves on the CU the two phases were bound by instruction ISSUE, 7.4 us each; profiles/round4/README.md section 11.)
+    // MID_XW experts per wave in registers at once (all of them when a level has at most 4 MID_XW experts: then no load of theirs is
+    // issued after this point)
+    const int rq = 4 * (wave & 3) + (lane >> 4), l16 = lane & 15, eg = wave >> 2;
+    const int64_t rowq = row0 + rq;
+    const bool liveq = rowq < B;
+    f32x4_t x2q[MID_XW], x1q[MID_XW][2];
+    const float* ex2p = a.ex2 + rowq * a.ld_ex2 + 4 * l16;
+    const float* ex1p = a.ex1 + rowq * a.ld_ex1 + 4 * l16;
+    auto load_x2 = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int el = 0; el < MID_XCH; ++el) x2r[el] = (live && e0 + el < ne2) ? ex2p[(int64_t)(e0 + el) * H2] : 0.f;
+        for (int u = 0; u < MID_XW; ++u) {
+            const int e = eg + 4 * (MID_XW * c + u);
+            x2q[u] = (liveq && e < ne2) ? *reinterpret_cast<const f32x4_t*>(ex2p + (int64_t)e * H2) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
     };
-    auto load_x1 = [&](int e0) __attribute__((always_inline)) {
+    auto load_x1 = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int el = 0; el < MID_XCH; ++el)
-            x1r[el] = (live && e0 + el < ne1) ? *reinterpret_cast<const f32x2_t*>(ex1p + (int64_t)(e0 + el) * H1) : f32x2_t{0.f, 0.f};
+        for (int u = 0; u < MID_XW; ++u) {
+            const int e = eg + 4 * (MID_XW * c + u);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                x1q[u][h] = (liveq && e < ne1) ? *reinterpret_cast<const f32x4_t*>(ex1p + (int64_t)e * H1 + 64 * h) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
     };
     load_x2(0);
     load_x1(0);
     // the K steps of every source's grad-input tiles: experts reading it (ascending), then gates — the segment order of the
     // unfused grad-input launch
-    if (tid < ng1) {
-        const int s = tid;
-        int n = 0;
-        for (int e = 0; e < ne2; ++e)
-            if (a.e2[e].src == s)
-                for (int ks = 0; ks < H2 / 32; ++ks)
-                    if (n < MID_MAXSTEP) steps[s][n++] = MidStep{reinterpret_cast<const __bf16*>(a.e2[e].wt) + ks * 32, (int32_t)a.e2[e].ldwt,
-                                                                 e * MID_BM * Cfg::DZ_LD + ks * 32, Cfg::DZ_LD, 0};
-        for (int t = 0; t < ng2; ++t)
-            if (a.g2[t].src == s && n < MID_MAXSTEP)
-                steps[s][n++] = MidStep{reinterpret_cast<const __bf16*>(a.g2[t].wt), (int32_t)a.g2[t].ldwt, dl2_off + t * MID_BM * Cfg::DL_LD, Cfg::DL_LD, 0};
-        n_steps[s] = n;
+    if (wave == 0) {
+        // lane i is candidate i of every source's list — i < 2 MID_E: K step i & 1 of expert i >> 1, then the gates — and fetches its
+        // own descriptor once (one round trip for the whole table; a loop over the experts in one thread per source was a chain of
+        // dependent scalar loads at the head of the kernel); its place in source s's list is the number of matching candidates below it
+        const bool is_e = lane < 2 * MID_E, is_g = !is_e && lane < 2 * MID_E + MID_G;
+        const int ce = lane >> 1, ct = lane - 2 * MID_E;
+        int c_src = -1, c_ld = 0, c_off = 0, c_ald = 0;
+        const __bf16* c_wt = nullptr;
+        if (is_e && ce < ne2) {
+            c_src = a.e2[ce].src; c_ld = (int32_t)a.e2[ce].ldwt;
+            c_wt = reinterpret_cast<const __bf16*>(a.e2[ce].wt) + (lane & 1) * 32;
+            c_off = ce * MID_BM * Cfg::DZ_LD + (lane & 1) * 32; c_ald = Cfg::DZ_LD;
+        } else if (is_g && ct < ng2) {
+            c_src = a.g2[ct].src; c_ld = (int32_t)a.g2[ct].ldwt;
+            c_wt = reinterpret_cast<const __bf16*>(a.g2[ct].wt);
+            c_off = dl2_off + ct * MID_BM * Cfg::DL_LD; c_ald = Cfg::DL_LD;
+        }
+        for (int sidx = 0; sidx < ng1; ++sidx) {
+            const unsigned long long m = __ballot(c_src == sidx);
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (c_src == sidx && rank < MID_MAXSTEP) steps[sidx][rank] = MidStep{c_wt, c_ld, c_off, c_ald, 0};
+            if (lane == 0) n_steps[sidx] = min((int)__popcll(m), MID_MAXSTEP);
+        }
     }
-    mid_fill_tables(pos1, sel1, a.g1, ng1, tid);
-    mid_fill_tables(pos2, sel2, a.g2, ng2, tid);
+    mid_tables_store(pos1, sel1, tab1, tid);
+    mid_tables_store(pos2, sel2, tab2, tid);
     const int mask1 = a.mask1, mask2 = a.mask2;
     const float scale1 = a.scale1, scale2 = a.scale2;
+    MID_STAMP(17);
     __syncthreads();                                                   // tables, dO2 and the probabilities are in LDS
+    MID_STAMP(18);
     // B fragments of this wave's first grad-input tiles: job = wave + 16 * i -> (source s, column tile nt)
     const int n_jobs = ng1 * Cfg::NT1;
     auto load_w = [&](bf16x8_t (&w)[MID_MAXSTEP], int i) __attribute__((always_inline)) {
@@ -475,39 +578,44 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
         for (int st = 0; st < MID_MAXSTEP; ++st)
             w[st] = st < ns ? *reinterpret_cast<const bf16x8_t*>(steps[s][st].wt + (int64_t)wrow * steps[s][st].ldwt + fk) : (bf16x8_t)(__bf16)0.f;
     };
+    // ---- 1: pool backward of level k+1.  dp_tj = <dOut_t, expert_sel(t,j)> over the row; dExpert_e = sum over the gates t that
+    //         select e, in gate order, of p_tj * dOut_t, then the activation mask
+    {
+        __bf16* dzg = reinterpret_cast<__bf16*>(a.dz2_h) + rowq * a.ld_dz2_h + 4 * l16;
+        for (int c = 0; eg + 4 * MID_XW * c < ne2; ++c) {
+            if (c > 0) load_x2(c);
+#pragma unroll
+            for (int u = 0; u < MID_XW; ++u) {
+                const int e = eg + 4 * (MID_XW * c + u);
+                if (e >= ne2) continue;                                         // uniform
+                const f32x4_t x = x2q[u];
+                f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < ng2; ++t) {
+                    const int j = __builtin_amdgcn_readfirstlane((int)pos2[t][e]);
+                    if (j < 0) continue;                                        // uniform
+                    const f32x4_t dO = *reinterpret_cast<const f32x4_t*>(dO2 + ((size_t)t * MID_BM + rq) * H2 + 4 * l16);
+                    const float part = mid_row16_sum((dO[0] * x[0] + dO[1] * x[1]) + (dO[2] * x[2] + dO[3] * x[3]));
+                    if (l16 == 0) dp2[(t * MID_BM + rq) * 16 + j] = part;
+                    d += p2[(t * MID_BM + rq) * 16 + j] * dO;
+                }
+                if (mask2) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = x[k] > 0.f ? d[k] * scale2 : 0.f;
+                }
+                const bf16x4_t h = {(__bf16)d[0], (__bf16)d[1], (__bf16)d[2], (__bf16)d[3]};
+                *reinterpret_cast<bf16x4_t*>(dz2 + ((size_t)e * MID_BM + rq) * Cfg::DZ_LD + 4 * l16) = h;
+                if (liveq) *reinterpret_cast<bf16x4_t*>(dzg + (int64_t)e * H2) = h;
+            }
+        }
+    }
+    // the B fragments of this wave's first grad-input tiles: fetched here, behind the first pool backward (whose side-by-side wave
+    // sums need the registers), in flight under the gate-logit phase
     bf16x8_t wq[MID_JPW2][MID_MAXSTEP];
 #pragma unroll
     for (int i = 0; i < MID_JPW2; ++i) load_w(wq[i], i);
-    // ---- 1: pool backward of level k+1 (lane = column).  dp_tj = <dOut_t, expert_sel(t,j)> over the row (wave reduction);
-    //         dExpert_e = sum over the gates t that select e, in gate order, of p_tj * dOut_t, then the activation mask
-    {
-        __bf16* dzg = reinterpret_cast<__bf16*>(a.dz2_h) + row * a.ld_dz2_h + lane;
-        for (int e0 = 0; e0 < ne2; e0 += MID_XCH) {
-        if (e0 > 0) load_x2(e0);
-#pragma unroll
-        for (int el = 0; el < MID_XCH; ++el) {
-            const int e = e0 + el;
-            if (e < ne2) {                                                      // uniform
-                const float x = x2r[el];
-                float d = 0.f;
-                for (int t = 0; t < ng2; ++t) {
-                    const int j = pos2[t][e];
-                    if (j >= 0) {                                               // uniform
-                        const float dO = dO2[((size_t)t * MID_BM + r) * H2 + lane];
-                        const float part = mid_wave_sum(dO * x);
-                        if (lane == 0) dp2[(t * MID_BM + r) * 16 + j] = part;
-                        d += p2[(t * MID_BM + r) * 16 + j] * dO;
-                    }
-                }
-                if (mask2) d = x > 0.f ? d * scale2 : 0.f;
-                const __bf16 h = (__bf16)d;
-                dz2[((size_t)e * MID_BM + r) * Cfg::DZ_LD + lane] = h;
-                if (live) dzg[(int64_t)e * H2] = h;
-            }
-        }
-        }
-    }
+    MID_STAMP(19);
     __syncthreads();
+    MID_STAMP(20);
     // ---- 1b: d_logit_tj = p_tj * (dp_tj - sum_k p_tk dp_tk): lane t of wave r takes (row r, gate t)
     if (lane < ng2) {
         const int t = lane;
@@ -532,6 +640,7 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();                                                   // dz2, dl2 complete; dO2 is dead (dP1 takes its place)
+    MID_STAMP(21);
     // ---- 2: d(pooled level-k output s) [16, H1] = sum over the experts e reading s of dZ_e . W_e  +  the gates reading s
     {
         auto tile = [&](const bf16x8_t (&w)[MID_MAXSTEP], int i) __attribute__((always_inline)) {
@@ -560,37 +669,45 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
         }
     }
     __syncthreads();
-    // ---- 3: pool backward of level k (lane = two columns)
+    MID_STAMP(22);
+    // ---- 3: pool backward of level k (a lane: columns 4 l .. 4 l + 3 and 64 + 4 l .. of its row)
     {
-        const int c1 = lane * 2;
-        __bf16* dzg = reinterpret_cast<__bf16*>(a.dz1_h) + row * a.ld_dz1_h + c1;
-        for (int e0 = 0; e0 < ne1; e0 += MID_XCH) {
-        if (e0 > 0) load_x1(e0);
+        __bf16* dzg = reinterpret_cast<__bf16*>(a.dz1_h) + rowq * a.ld_dz1_h + 4 * l16;
+        for (int c = 0; eg + 4 * MID_XW * c < ne1; ++c) {
+            if (c > 0) load_x1(c);
 #pragma unroll
-        for (int el = 0; el < MID_XCH; ++el) {
-            const int e = e0 + el;
-            if (e < ne1) {
-                const f32x2_t x = x1r[el];
-                f32x2_t d = {0.f, 0.f};
+            for (int u = 0; u < MID_XW; ++u) {
+                const int e = eg + 4 * (MID_XW * c + u);
+                if (e >= ne1) continue;                                         // uniform
+                f32x4_t d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 for (int g = 0; g < ng1; ++g) {
-                    const int j = pos1[g][e];
-                    if (j >= 0) {
-                        const f32x2_t dO = *reinterpret_cast<const f32x2_t*>(dP1 + ((size_t)g * MID_BM + r) * Cfg::DP_LD + c1);
-                        const float part = mid_wave_sum(dO[0] * x[0] + dO[1] * x[1]);
-                        if (lane == 0) dp1[(g * MID_BM + r) * 16 + j] = part;
-                        d += p1[(g * MID_BM + r) * 16 + j] * dO;
+                    const int j = __builtin_amdgcn_readfirstlane((int)pos1[g][e]);
+                    if (j < 0) continue;                                        // uniform
+                    const float* src = dP1 + ((size_t)g * MID_BM + rq) * Cfg::DP_LD + 4 * l16;
+                    const f32x4_t dA = *reinterpret_cast<const f32x4_t*>(src), dB = *reinterpret_cast<const f32x4_t*>(src + 64);
+                    const f32x4_t xa = x1q[u][0], xb = x1q[u][1];
+                    const float part = mid_row16_sum(((dA[0] * xa[0] + dA[1] * xa[1]) + (dA[2] * xa[2] + dA[3] * xa[3])) +
+                                                     ((dB[0] * xb[0] + dB[1] * xb[1]) + (dB[2] * xb[2] + dB[3] * xb[3])));
+                    if (l16 == 0) dp1[(g * MID_BM + rq) * 16 + j] = part;
+                    const float pw = p1[(g * MID_BM + rq) * 16 + j];
+                    d[0] += pw * dA;
+                    d[1] += pw * dB;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4_t dv = d[h];
+                    if (mask1) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dv[k] = x1q[u][h][k] > 0.f ? dv[k] * scale1 : 0.f;
                     }
+                    if (liveq) *reinterpret_cast<bf16x4_t*>(dzg + (int64_t)e * H1 + 64 * h) = bf16x4_t{(__bf16)dv[0], (__bf16)dv[1], (__bf16)dv[2], (__bf16)dv[3]};
                 }
-                if (mask1) {
-                    d[0] = x[0] > 0.f ? d[0] * scale1 : 0.f;
-                    d[1] = x[1] > 0.f ? d[1] * scale1 : 0.f;
-                }
-                if (live) *reinterpret_cast<bf16x2_t*>(dzg + (int64_t)e * H1) = bf16x2_t{(__bf16)d[0], (__bf16)d[1]};
             }
         }
-        }
     }
+    MID_STAMP(23);
     __syncthreads();
+    MID_STAMP(24);
     if (lane < ng1 && live) {
         const int g = lane;
         const int ns = a.g1[g].n_sel;
@@ -606,6 +723,7 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
             if (dlh) dlh[j] = (__bf16)dl;
         }
     }
+    MID_STAMP(25);
 }
 
 template <int H1, int H2>
