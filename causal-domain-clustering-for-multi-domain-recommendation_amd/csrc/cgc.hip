@@ -150,6 +150,37 @@ __device__ __forceinline__ void mid_softmax(float (&p)[CDC_MAX_SEL], int n_sel) 
     for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] *= inv;
 }
 
+// the same softmax with ONE gate's logits spread over the 16 lanes of a DPP row (lane j holds logit j): the maximum is order-free,
+// every lane takes one expf instead of one lane sixteen, and the sum is formed in index order out of the LDS slot the probabilities
+// go to anyway (by every lane of the row: no broadcast) — the bits of mid_softmax.  active: the row's gate exists (its slot may be
+// written); valid: j < n_sel.  Returns the lane's probability.
+__device__ __forceinline__ float mid_softmax_row16(float l, bool active, bool valid, float* slot, int j) {
+    const float v = valid ? l : -INFINITY;
+    float mx = v;
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x141, 0xF, 0xF, true)));
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x140, 0xF, 0xF, true)));
+    float p = valid ? expf(v - mx) : 0.f;
+    if (active) slot[j] = p;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float sum = 0.f;
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < CDC_MAX_SEL; q += 4) {
+            const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(slot + q);
+            sum += t4[0]; sum += t4[1]; sum += t4[2]; sum += t4[3];
+        }
+    }
+    const float inv = 1.f / sum;
+    p *= inv;
+    __builtin_amdgcn_wave_barrier();                                   // (every lane has read the slot before it is overwritten)
+    if (active) slot[j] = p;
+    return p;
+}
+
 // =====================================================================================================================
 // forward
 // =====================================================================================================================
@@ -157,17 +188,29 @@ template <int H1, int H2>
 __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_eu(5, 5))) k_cgc_mid_fwd(const cdc_cgc_mid_fwd_args a_by_value) {
     CDC_PRIO_MAIN();
     (void)a_by_value;
-    const MID_KARG cdc_cgc_mid_fwd_args& a = *(const MID_KARG cdc_cgc_mid_fwd_args*)__builtin_amdgcn_kernarg_segment_ptr();
+    MID_STAMP(0);
+    // the argument block -> LDS, all of it at once (every thread one 8-byte piece): what the entry reads of it — counts, then the
+    // descriptors they index, then what those point to — was a chain of dependent reads of memory that is cold at every launch (1-2 us
+    // each); now ONE such read, and the chain runs out of LDS
+    __shared__ __attribute__((aligned(16))) cdc_cgc_mid_fwd_args a_s;
+    {
+        static_assert(sizeof(cdc_cgc_mid_fwd_args) % 8 == 0, "copied in 8-byte pieces");
+        const MID_KARG unsigned long long* src = (const MID_KARG unsigned long long*)__builtin_amdgcn_kernarg_segment_ptr();
+        for (int i = threadIdx.x; i < (int)(sizeof(cdc_cgc_mid_fwd_args) / 8); i += MID_THREADS) reinterpret_cast<unsigned long long*>(&a_s)[i] = src[i];
+        __syncthreads();
+    }
+    const cdc_cgc_mid_fwd_args& a = a_s;
     typedef MidCfg<H1, H2> Cfg;
     constexpr int KS = H1 / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ signed char pos1[MID_G][MID_E], pos2[MID_G][MID_E];
-    __shared__ unsigned char sel1[MID_G][CDC_MAX_SEL], sel2[MID_G][CDC_MAX_SEL];
+    __shared__ __attribute__((aligned(16))) unsigned char sel1[MID_G][CDC_MAX_SEL], sel2[MID_G][CDC_MAX_SEL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // uniform: descriptor reads indexed by it are scalar loads
     const int64_t row0 = (int64_t)blockIdx.x * MID_BM;
-    const int64_t B = a.B;
-    const int ng1 = a.n_gate1, ng2 = a.n_gate2, ne1 = a.n_exp1, ne2 = a.n_exp2;
+    const int64_t B = ((int64_t)__builtin_amdgcn_readfirstlane((int)(a.B >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)a.B);
+    const int ng1 = __builtin_amdgcn_readfirstlane(a.n_gate1), ng2 = __builtin_amdgcn_readfirstlane(a.n_gate2),
+              ne1 = __builtin_amdgcn_readfirstlane(a.n_exp1), ne2 = __builtin_amdgcn_readfirstlane(a.n_exp2);
     // LDS: p1 [16][ng1][16] f32 | p2 [16][ng2][16] f32 | pooled [ng1][16][PH_LD] bf16 | U = { xs [ne1][16][H1] f32 (phase A) ,
     //      x2 [ne2][16][E2_LD] f32 (phases B..D) }
     float* p1 = reinterpret_cast<float*>(smem);
@@ -182,7 +225,6 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     const bool live = row < B;
     const int64_t last_row = B - 1;
 
-    MID_STAMP(0);
     const int32_t sp_val = (a.drop_p > 0.f && a.seed_offset_dev) ? *a.seed_offset_dev : 0;     // (consumed behind the entry's other loads)
     // ---- (0) the level-k gate logits of this wave's row, lane g = gate g: they head the longest dependent chain of the entry
     //      (descriptor -> logits -> softmax -> pooling), so they are issued first; the descriptors come by scalar loads (a lane-indexed
@@ -191,18 +233,20 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     // it — host-visible memory for a plain launch: a read is a microsecond or two, and reads issued one behind the other's result were
     // most of the entry's 9 us): the gates' descriptors — all MID_G slots, unconditionally: the slots exist whatever n_gate1 is —, the
     // descriptors of this wave's first tiles, the table entries (a lane-indexed read)
-    float p_a1[CDC_MAX_SEL];
-    int ns_a1 = 0;
-    float* pr_a1 = nullptr;
-    const float* lg_a1 = nullptr;
+    // gate probabilities: lane (q, j) = (lane >> 4, lane & 15) takes logit j of gate q (pass 0) and of gate q + 4 (pass 1)
+    const int gq = lane >> 4, gj = lane & 15;
+    int ns_g1[2] = {0, 0}, ns_g2[2] = {0, 0};
+    float* pr_g1[2] = {nullptr, nullptr};
+    float* pr_g2[2] = {nullptr, nullptr};
+    const float* lg_g1[2] = {nullptr, nullptr};
 #pragma unroll
     for (int g = 0; g < MID_G; ++g) {
-        const int ns = a.g1[g].n_sel;
+        const int ns = a.g1[g].n_sel, ns2 = a.g2[g].n_sel;
         const float* lgp = a.g1[g].logits + row * a.g1[g].ld_logits;
         float* prp = a.g1[g].probs + row * ns;
-        if (lane == g) { ns_a1 = ns; lg_a1 = lgp; pr_a1 = prp; }
+        float* prp2 = a.g2[g].probs + row * ns2;
+        if (gq == (g & 3)) { ns_g1[g >> 2] = ns; lg_g1[g >> 2] = lgp; pr_g1[g >> 2] = prp; ns_g2[g >> 2] = ns2; pr_g2[g >> 2] = prp2; }
     }
-    if (lane >= ng1) ns_a1 = 0;
     struct JobDesc { const __bf16* W; int64_t ldw; const float* bp; int n_rows, nt; bool on; };
     auto job_desc = [&](int i) __attribute__((always_inline)) {
         const int job = wave + MID_WAVES * i;
@@ -221,8 +265,9 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
 #pragma unroll
     for (int i = 0; i < MID_JPW; ++i) jd[i] = job_desc(i);
     const MidTabReg tab1 = mid_tables_fetch(a.g1, ng1, tid), tab2 = mid_tables_fetch(a.g2, ng2, tid);
+    float lgt[2];
 #pragma unroll
-    for (int j = 0; j < CDC_MAX_SEL; ++j) p_a1[j] = (live && j < ns_a1) ? lg_a1[j] : 0.f;
+    for (int ps = 0; ps < 2; ++ps) lgt[ps] = (live && gq + 4 * ps < ng1 && gj < ns_g1[ps]) ? lg_g1[ps][gj] : 0.f;
     // ---- entry: every load that depends on nothing.  (1) the level-k expert rows of the block -> LDS, 1 KiB (two rows of one
     //      expert) per wave instruction; rows past the batch re-read the last row (their results are never stored)
     {
@@ -261,30 +306,44 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     }
     mid_tables_store(pos1, sel1, tab1, tid);
     mid_tables_store(pos2, sel2, tab2, tid);
-    // ---- A1: level-k gate probabilities: lane g of wave r takes (row r, gate g)
-    if (lane < ng1) {
-        const int g = lane;
-        mid_softmax(p_a1, ns_a1);
+    // ---- A1: level-k gate probabilities of row r: the 16 lanes of a DPP row per gate
 #pragma unroll
-        for (int j = 0; j < CDC_MAX_SEL; ++j) {
-            p1[(r * ng1 + g) * 16 + j] = p_a1[j];
-            if (j < ns_a1 && live) pr_a1[j] = p_a1[j];
-        }
+    for (int ps = 0; ps < 2; ++ps) {
+        if (4 * ps >= ng1) continue;                                   // uniform
+        const int g = gq + 4 * ps;
+        const bool active = g < ng1, valid = active && gj < ns_g1[ps];
+        const float pv = mid_softmax_row16(lgt[ps], active, valid, p1 + (r * ng1 + (active ? g : 0)) * 16, gj);
+        if (valid && live) pr_g1[ps][gj] = pv;
     }
     MID_STAMP(1);
     __syncthreads();                                                   // (waits for the direct-to-LDS loads as well)
     MID_STAMP(2);
-    // ---- A2: pooled level-k vectors; sel ascending = the summation order of the reference
+    // ---- A2: pooled level-k vectors; sel ascending = the summation order of the reference.  A gate's list comes out of LDS in one
+    //      16-byte read and its terms in groups of four whose reads are in flight together (one at a time, index and operand were a chain
+    //      of two LDS round trips per term)
     {
         const int c = lane * 2;
         for (int g = 0; g < ng1; ++g) {
             const int ns = a.g1[g].n_sel;
             __bf16* gp = reinterpret_cast<__bf16*>(a.g1[g].pooled_h);
             const int64_t ldp = a.g1[g].ld_pooled_h;
+            const uint4 sv4 = *reinterpret_cast<const uint4*>(&sel1[g][0]);
+            const uint32_t sw[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)sv4.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)sv4.y),
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)sv4.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)sv4.w)};
             f32x2_t acc = {0.f, 0.f};
-            for (int j = 0; j < ns; ++j) {
-                const int e = sel1[g][j];
-                acc += p1[(r * ng1 + g) * 16 + j] * *reinterpret_cast<const f32x2_t*>(xs + ((size_t)e * MID_BM + r) * H1 + c);
+#pragma unroll
+            for (int j0 = 0; j0 < CDC_MAX_SEL; j0 += 4) {
+                if (j0 >= ns) break;                                   // uniform
+                const f32x4_t pw = *reinterpret_cast<const f32x4_t*>(p1 + (r * ng1 + g) * 16 + j0);     // (slots >= n_sel hold 0: their terms add +0)
+                f32x2_t xv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = (int)((sw[j0 >> 2] >> (8 * q)) & 0xffu);                               // (0 beyond n_sel: a readable row)
+                    xv[q] = *reinterpret_cast<const f32x2_t*>(xs + ((size_t)e * MID_BM + r) * H1 + c);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (j0 + q < ns) acc += pw[q] * xv[q];             // uniform
             }
             const bf16x2_t h = {(__bf16)acc[0], (__bf16)acc[1]};
             *reinterpret_cast<bf16x2_t*>(ph + ((size_t)g * MID_BM + r) * Cfg::PH_LD + c) = h;
@@ -342,20 +401,15 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     }
     __syncthreads();
     MID_STAMP(4);
-    // ---- D1: level-k+1 gate probabilities, in place: lane t of wave r takes (row r, gate t)
-    if (lane < ng2) {
-        const int t = lane;
-        const int ns = a.g2[t].n_sel;
-        float* pr = a.g2[t].probs + row * ns;
-        float p[CDC_MAX_SEL];
+    // ---- D1: level-k+1 gate probabilities of row r, in place: the 16 lanes of a DPP row per gate
 #pragma unroll
-        for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] = j < ns ? p2[(r * ng2 + t) * 16 + j] : 0.f;
-        mid_softmax(p, ns);
-#pragma unroll
-        for (int j = 0; j < CDC_MAX_SEL; ++j) {
-            p2[(r * ng2 + t) * 16 + j] = p[j];
-            if (j < ns && live) pr[j] = p[j];
-        }
+    for (int ps = 0; ps < 2; ++ps) {
+        if (4 * ps >= ng2) continue;                                   // uniform
+        const int t = gq + 4 * ps;
+        const bool active = t < ng2, valid = active && gj < ns_g2[ps];
+        float* slot = p2 + (r * ng2 + (active ? t : 0)) * 16;
+        const float pv = mid_softmax_row16(valid ? slot[gj] : 0.f, active, valid, slot, gj);
+        if (valid && live) pr_g2[ps][gj] = pv;
     }
     __syncthreads();
     MID_STAMP(5);
@@ -371,8 +425,21 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
             float* out = a.g2[g].out;
             __bf16* outh = reinterpret_cast<__bf16*>(a.g2[g].out_h);
             const int64_t ldo = a.g2[g].ld_out, ldoh = a.g2[g].ld_out_h;
+            const uint4 sv4 = *reinterpret_cast<const uint4*>(&sel2[g][0]);
+            const uint32_t sw[4] = {(uint32_t)__builtin_amdgcn_readfirstlane((int)sv4.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)sv4.y),
+                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)sv4.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)sv4.w)};
             float acc = 0.f;
-            for (int j = 0; j < ns; ++j) acc += p2[(r * ng2 + g) * 16 + j] * x2[((size_t)sel2[g][j] * MID_BM + r) * Cfg::E2_LD + c2];
+#pragma unroll
+            for (int j0 = 0; j0 < CDC_MAX_SEL; j0 += 4) {
+                if (j0 >= ns) break;                                   // uniform
+                const f32x4_t pw = *reinterpret_cast<const f32x4_t*>(p2 + (r * ng2 + g) * 16 + j0);
+                float xv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[q] = x2[((size_t)((sw[j0 >> 2] >> (8 * q)) & 0xffu) * MID_BM + r) * Cfg::E2_LD + c2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (j0 + q < ns) acc += pw[q] * xv[q];             // uniform
+            }
             if (live) {
                 if (out) out[row * ldo + c2] = acc;
                 if (outh) outh[row * ldoh + c2] = (__bf16)acc;
@@ -437,6 +504,21 @@ extern "C" int cdc_cgc_mid_fwd(const cdc_cgc_mid_fwd_args* a, void* stream) {
     hipLaunchKernelGGL((k_cgc_mid_fwd<128, 64>), dim3((unsigned)cdc_ceil_div(a->B, MID_BM)), dim3(MID_THREADS), lds, (hipStream_t)stream, *a);
     CDC_LAUNCH_CHECK("cgc_mid_fwd");
     return 0;
+}
+
+// softmax backward of ONE gate over the 16 lanes of a DPP row (lane j takes term j): dot = sum_k p_k dp_k in index order (formed by
+// every lane of the row out of the two LDS slots), d_logit_j = p_j (dp_j - dot).  Slots >= n_sel of dp are never written: masked.
+__device__ __forceinline__ float mid_dlogit_row16(const float* pp, const float* dd, int ns, int j) {
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < CDC_MAX_SEL; q += 4) {
+        if (q >= ns) break;                                            // (uniform per row; lanes of inactive rows pass ns = 0)
+        const f32x4_t p4 = *reinterpret_cast<const f32x4_t*>(pp + q), d4 = *reinterpret_cast<const f32x4_t*>(dd + q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (q + k < ns) dot += p4[k] * d4[k];
+    }
+    return j < ns ? pp[j] * (dd[j] - dot) : 0.f;
 }
 
 // =====================================================================================================================
@@ -561,7 +643,7 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     }
     mid_tables_store(pos1, sel1, tab1, tid);
     mid_tables_store(pos2, sel2, tab2, tid);
-    const int mask1 = a.mask1, mask2 = a.mask2;
+    const int mask1 = __builtin_amdgcn_readfirstlane(a.mask1), mask2 = __builtin_amdgcn_readfirstlane(a.mask2);
     const float scale1 = a.scale1, scale2 = a.scale2;
     MID_STAMP(17);
     __syncthreads();                                                   // tables, dO2 and the probabilities are in LDS
@@ -616,27 +698,26 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     MID_STAMP(19);
     __syncthreads();
     MID_STAMP(20);
-    // ---- 1b: d_logit_tj = p_tj * (dp_tj - sum_k p_tk dp_tk): lane t of wave r takes (row r, gate t)
-    if (lane < ng2) {
-        const int t = lane;
-        const int ns = a.g2[t].n_sel;
-        float* dlg = a.g2[t].d_logits + row * a.g2[t].ld_dlogits;
-        __bf16* dlh = a.g2[t].d_logits_h ? reinterpret_cast<__bf16*>(a.g2[t].d_logits_h) + row * a.g2[t].ld_dlogits_h : nullptr;
-        const float* pp = p2 + (t * MID_BM + r) * 16;
-        const float* dd = dp2 + (t * MID_BM + r) * 16;
-        float dot = 0.f;
-        for (int j = 0; j < ns; ++j) dot += pp[j] * dd[j];
-        __bf16* lrow = dl2 + ((size_t)t * MID_BM + r) * Cfg::DL_LD;
-        for (int j = 0; j < 32; ++j) {
-            float dl = 0.f;
-            if (j < ns) {
-                dl = pp[j] * (dd[j] - dot);
-                if (live) {
-                    dlg[j] = dl;
-                    if (dlh) dlh[j] = (__bf16)dl;
+    // ---- 1b: d_logit_tj = p_tj * (dp_tj - sum_k p_tk dp_tk) of row r: the 16 lanes of a DPP row per gate (lane = term)
+    {
+        const int gq = lane >> 4, gj = lane & 15;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            if (4 * ps >= ng2) continue;                               // uniform
+            const int t = gq + 4 * ps;
+            const bool active = t < ng2;
+            const int tc = active ? t : 0;
+            const int ns = active ? a.g2[tc].n_sel : 0;
+            const float dl = mid_dlogit_row16(p2 + (tc * MID_BM + r) * 16, dp2 + (tc * MID_BM + r) * 16, ns, gj);
+            if (active) {
+                __bf16* lrow = dl2 + ((size_t)t * MID_BM + r) * Cfg::DL_LD;
+                lrow[gj] = (__bf16)dl;                                 // (0 beyond n_sel)
+                lrow[16 + gj] = (__bf16)0.f;
+                if (live && gj < ns) {
+                    a.g2[tc].d_logits[row * a.g2[tc].ld_dlogits + gj] = dl;
+                    if (a.g2[tc].d_logits_h) reinterpret_cast<__bf16*>(a.g2[tc].d_logits_h)[row * a.g2[tc].ld_dlogits_h + gj] = (__bf16)dl;
                 }
             }
-            lrow[j] = (__bf16)dl;
         }
     }
     __syncthreads();                                                   // dz2, dl2 complete; dO2 is dead (dP1 takes its place)
@@ -708,19 +789,20 @@ __global__ void __launch_bounds__(MID_THREADS) __attribute__((amdgpu_waves_per_e
     MID_STAMP(23);
     __syncthreads();
     MID_STAMP(24);
-    if (lane < ng1 && live) {
-        const int g = lane;
-        const int ns = a.g1[g].n_sel;
-        float* dlg = a.g1[g].d_logits + row * a.g1[g].ld_dlogits;
-        __bf16* dlh = a.g1[g].d_logits_h ? reinterpret_cast<__bf16*>(a.g1[g].d_logits_h) + row * a.g1[g].ld_dlogits_h : nullptr;
-        const float* pp = p1 + (g * MID_BM + r) * 16;
-        const float* dd = dp1 + (g * MID_BM + r) * 16;
-        float dot = 0.f;
-        for (int j = 0; j < ns; ++j) dot += pp[j] * dd[j];
-        for (int j = 0; j < ns; ++j) {
-            const float dl = pp[j] * (dd[j] - dot);
-            dlg[j] = dl;
-            if (dlh) dlh[j] = (__bf16)dl;
+    {
+        const int gq = lane >> 4, gj = lane & 15;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            if (4 * ps >= ng1) continue;                               // uniform
+            const int g = gq + 4 * ps;
+            const bool active = g < ng1;
+            const int gc = active ? g : 0;
+            const int ns = active ? a.g1[gc].n_sel : 0;
+            const float dl = mid_dlogit_row16(p1 + (gc * MID_BM + r) * 16, dp1 + (gc * MID_BM + r) * 16, ns, gj);
+            if (active && live && gj < ns) {
+                a.g1[gc].d_logits[row * a.g1[gc].ld_dlogits + gj] = dl;
+                if (a.g1[gc].d_logits_h) reinterpret_cast<__bf16*>(a.g1[gc].d_logits_h)[row * a.g1[gc].ld_dlogits_h + gj] = (__bf16)dl;
+            }
         }
     }
     MID_STAMP(25);
