@@ -370,6 +370,9 @@ template <int NK0, int H1, int H2>
 __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, unsigned char* smem, float* keep) {
     typedef TwFwdCfg<NK0, H1, H2> Cfg;
     static_assert(H1 % 64 == 0 && H1 <= 64 && H2 % 16 == 0 && H2 <= 64 && H2 % 8 == 0, "instantiated shapes");
+#if TW_TRACE
+    const unsigned long long t_top = wall_clock64();                   // (before the first read of the argument block)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = (int)a.M, n_tower = a.n_tower;
@@ -441,6 +444,9 @@ __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, uns
     const bool relu = a.relu != 0;
     const float drop_p = a.drop_p;
     TW_STAMP(0);
+#if TW_TRACE
+    if (blockIdx.x == TW_TRACE - 1 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.workspace) + 4096)[15] = t_top;
+#endif
     tw_drain();
     __syncthreads();
     TW_STAMP(1);
@@ -735,6 +741,9 @@ template <int NK0, int H1, int H2>
 __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, unsigned char* smem, const float* keep) {
     typedef TwBwdCfg<NK0, H1, H2> Cfg;
     constexpr int H0 = Cfg::H0;
+#if TW_TRACE
+    const unsigned long long t_top = wall_clock64();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = (int)a.M, n_tower = a.n_tower;
@@ -816,6 +825,9 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
         }
     }
     TW_STAMP(16);
+#if TW_TRACE
+    if (blockIdx.x == TW_TRACE - 1 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.workspace) + 4096)[31] = t_top;
+#endif
 
     // ---- (1) logit gradients of the block's rows (k_head_bwd's arithmetic: BCELoss(mean) on the row's own tower, or d_out)
     if (tid < TW_ROWS) {

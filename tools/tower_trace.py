@@ -39,10 +39,10 @@ for rep in range(6):
     if rep < 3:
         continue
     for lo, hi, what in ((0, 16, "forward"), (16, 32, "backward")):
-        t0 = st[lo]
+        t0 = st[hi - 1] if st[hi - 1] else st[lo]          # slot 15 / 31: the wall clock at the body's first instruction
         print(f"-- {what}")
         prev = t0
-        for i in range(lo, hi):
+        for i in range(lo, hi - 1):
             if st[i]:
                 print(f"  {names.get(i, i):48s} {(st[i] - t0) / 100.0:7.2f} us   (+{(st[i] - prev) / 100.0:5.2f})")
                 prev = st[i]
