@@ -58,6 +58,7 @@ def parse():
                     help="1: the reference's default attention branch (config.py:24-28: 3 x MultiheadAttention(64, 2 heads) + residual) "
                          "on top of the BASELINE configuration, which is defined without it")
     ap.add_argument("--flush-every", type=int, default=64, help="lazy table: the whole table is replayed once per this many steps")
+    ap.add_argument("--fast-replay", type=int, default=-1, help="lazy table: 1 scaled-state replay of untouched rows (hardware rcp / sqrt), 0 the exact recurrence; -1 = FusedAdam's default")
     ap.add_argument("--overlap-waves", type=int, default=2, help="waves per SIMD of the background replay slice's capped grid (A/B only)")
     ap.add_argument("--rows-dense-one-launch", type=int, default=1, help="0: the step's row update and the dense Adam as two launches (A/B only)")
     ap.add_argument("--tower-one-launch", type=int, default=1, help="0: the fused towers as two launches, forward and backward (A/B only)")
@@ -248,8 +249,9 @@ def main():
     model, field_dims = build_model(args, device)
     table_mode = args.table_mode
     use_graph = bool(args.graph)        # under DP the launch stages between the collectives are graphs
+    opt_kw = {} if args.fast_replay < 0 else {"fast_replay": bool(args.fast_replay)}
     opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode,
-                    flush_every=args.flush_every)
+                    flush_every=args.flush_every, **opt_kw)
     dist_obj = dp or sim
     ts = TrainStep(model, opt, args.batch, mode="multi", use_graph=use_graph, dist=dist_obj, sync_bn=bool(args.sync_bn),
                    table_dist=args.table_dist, tower_one_launch=bool(args.tower_one_launch), rows_dense_one_launch=bool(args.rows_dense_one_launch), overlap_waves=args.overlap_waves)

@@ -31,7 +31,7 @@ c_p = C.c_void_p
 class AdamHP(C.Structure):
     _fields_ = [("lerp_w", c_f), ("beta2", c_f), ("one_minus_beta2", c_f), ("eps", c_f),
                 ("weight_decay", c_f), ("l2_twice", c_f), ("step_scalars", c_p), ("n_scalars", c_i32), ("fast_replay", c_i32),
-                ("inv_bc2", c_p), ("replay_tab", c_p), ("k1", c_f), ("k2", c_f)]
+                ("inv_bc2", c_p), ("replay_tab", c_p), ("k1", c_f), ("k2", c_f), ("ik1", c_f), ("ik2", c_f), ("k1_lo", c_f), ("k2_lo", c_f)]
 
 
 class LinGroup(C.Structure):

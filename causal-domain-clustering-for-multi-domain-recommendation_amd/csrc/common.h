@@ -215,7 +215,7 @@ __device__ __forceinline__ void adam_replay_wave_scaled(float (&w)[N], float (&m
     }
     fmin = __builtin_amdgcn_readfirstlane(fmin);
     if (fmin >= to) return;                                           // wave-uniform: nothing to replay
-    const float ik1 = 1.f / hp.k1, ik2 = 1.f / hp.k2;
+    const float ik1 = hp.ik1, ik2 = hp.ik2;
     cdc_f2 W[N / 2], M[N / 2], V[N / 2];
 #pragma unroll
     for (int k = 0; k < N / 2; ++k) {
@@ -234,7 +234,9 @@ __device__ __forceinline__ void adam_replay_wave_scaled(float (&w)[N], float (&m
     if (from < to) {
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) {
-            const cdc_f2 mo = M[k] * hp.k1, vo = V[k] * hp.k2;
+            // k + k_lo = 1 / ik to 2^-48: out and in are inverses of each other, a segment leaves no factor (1 + 6e-8) on the state
+            const cdc_f2 mo = __builtin_elementwise_fma(M[k], (cdc_f2){hp.k1, hp.k1}, M[k] * hp.k1_lo);
+            const cdc_f2 vo = __builtin_elementwise_fma(V[k], (cdc_f2){hp.k2, hp.k2}, V[k] * hp.k2_lo);
             w[2 * k] = W[k].x; w[2 * k + 1] = W[k].y;
             m[2 * k] = mo.x; m[2 * k + 1] = mo.y;
             v[2 * k] = vo.x; v[2 * k + 1] = vo.y;

@@ -37,6 +37,17 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
                                             16 no phase 1, 32 no epilogue 1 */
 #endif
 
+#ifndef PAIR_TRACE
+#define PAIR_TRACE 0                     /* probe builds only (tools/pair_trace.py): thread 0 of workgroup 0 stamps the 100 MHz wall clock at phase boundaries */
+#endif
+#if PAIR_TRACE
+__device__ unsigned long long g_pair_stamps[16];
+#define PAIR_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pair_stamps[(i)] = wall_clock64(); } while (0)
+extern "C" int cdc_debug_pair_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pair_stamps), sizeof(unsigned long long) * 16); }
+#else
+#define PAIR_STAMP(i) do { } while (0)
+#endif
+
 template <int H1, int H2>
 struct PairCfg {
     static constexpr int A_BYTES = PAIR_BM * PAIR_ROWB;
@@ -71,6 +82,7 @@ template <int H1, int H2>
 __global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) k_pair_fwd(const cdc_expert_pair_args a_by_value) {
     CDC_PRIO_MAIN();
     (void)a_by_value;
+    PAIR_STAMP(0);
     const PAIR_KARG cdc_expert_pair_args& a = *(const PAIR_KARG cdc_expert_pair_args*)__builtin_amdgcn_kernarg_segment_ptr();
     typedef PairCfg<H1, H2> Cfg;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -161,6 +173,7 @@ __global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_
     // ring of PAIR_NSTAGE slabs, PAIR_NSTAGE - 1 of them in flight: slab t is waited for with a COUNTED vmcnt (6 direct loads per wave
     // and slab, 7 for the two waves that fetch the side rows), the slab freed by the barrier is refilled right after it
     const int nk1 = (PAIR_PROBE & 16) ? 0 : nk;
+    PAIR_STAMP(1);
 #pragma unroll
     for (int p = 0; p < PAIR_NSTAGE - 1; ++p)
         if (p < nk1) issue(p);
@@ -201,7 +214,9 @@ __global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
         }
     }
+    PAIR_STAMP(2);
     __syncthreads();                                                 // the ring is free
+    PAIR_STAMP(3);
 
     // ---- W2 whole into LDS behind the hidden tile's image: 8 direct loads per wave, in flight under the register epilogue ----
     unsigned char* const Hs = smem;
@@ -262,8 +277,10 @@ __global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_
             }
         }
     }
+    PAIR_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's share of W2
     __syncthreads();
+    PAIR_STAMP(5);
 
     // ---- the hidden tile out to memory, whole rows from LDS (read by grad-weight and as the activation mask of grad-input) ----
     if (Hout && !(PAIR_PROBE & 2)) {
@@ -279,6 +296,7 @@ __global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_
         }
     }
 
+    PAIR_STAMP(6);
     // ---- phase 2: every operand in LDS -----------------------------------------------------------------------------------
     const int wm2 = (wave >> 1) * 32, wn2 = (wave & 1) * (H2 / 2);
     f32x4_t acc2[Cfg::MT2][Cfg::NT2];
@@ -306,6 +324,7 @@ __global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_
         }
     }
 
+    PAIR_STAMP(7);
     if (PAIR_PROBE & 8) { if (acc2[0][0][0] == 123.456f && Y) Y[0] = 1.f; return; }
     // ---- epilogue 2: accumulators -> LDS tile -> whole rows out (gemm2.hip's fast path: 8 columns per thread) -------------------
     __syncthreads();
@@ -318,6 +337,7 @@ __global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_
             for (int r = 0; r < 4; ++r)
                 ct[(wm2 + mt * 16 + (lane >> 4) * 4 + r) * Cfg::CS + wn2 + nt * 16 + (lane & 15)] = acc2[mt][nt][r];
     __syncthreads();
+    PAIR_STAMP(8);
     constexpr int C8 = H2 / 8;
     constexpr int ROWS_PER_PASS = PAIR_THREADS / C8;
     const int c8 = (tid % C8) * 8, lr0 = tid / C8;
@@ -359,6 +379,7 @@ __global__ void __launch_bounds__(PAIR_THREADS) __attribute__((amdgpu_waves_per_
             *reinterpret_cast<bf16x8_t*>(hp + (int64_t)lr * ldyh) = h8;
         }
     }
+    PAIR_STAMP(9);
 }
 
 extern "C" int cdc_expert_pair_fwd(const cdc_expert_pair_args* a, void* stream) {

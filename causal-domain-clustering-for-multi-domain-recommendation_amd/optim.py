@@ -83,12 +83,19 @@ class FusedAdam:
         self._k1 = self._k2 = 0.0
         self.replay_tab = None
         c = float(torch.tensor(2.0 * f32(self.l2_table) + self._wd, dtype=torch.float64).to(torch.float32))
+        self._ik1 = self._ik2 = self._k1_lo = self._k2_lo = 0.0
         if self.fast_replay and c > 0.0:
-            self._k1, self._k2 = f32(self._lerp_w * c), f32(self._omb2 * c * c)
-            if self._k1 > 0.0 and self._k2 > 0.0:
+            k1, k2 = f32(self._lerp_w * c), f32(self._omb2 * c * c)
+            if k1 > 0.0 and k2 > 0.0:
+                # the scales as the kernel applies them: in by the fp32 reciprocals ik, out by K = 1 / ik (as fp32 pair hi + lo), the
+                # per-step constants formed with the same K — in and out are inverses to 2^-48 (cdc_adam_hp)
+                self._ik1, self._ik2 = f32(1.0 / k1), f32(1.0 / k2)
+                K1, K2 = 1.0 / self._ik1, 1.0 / self._ik2
+                self._k1, self._k2 = f32(K1), f32(K2)
+                self._k1_lo, self._k2_lo = f32(K1 - self._k1), f32(K2 - self._k2)
                 t64 = tab.double()
-                A = t64[:, 0] * self._k1 * t64[:, 1] / math.sqrt(self._k2)
-                E = self._eps * t64[:, 1] / math.sqrt(self._k2)
+                A = t64[:, 0] * K1 * t64[:, 1] / math.sqrt(K2)
+                E = self._eps * t64[:, 1] / math.sqrt(K2)
                 A[0] = A[1]                                           # (row 0 = "step 0" is never replayed; keep it finite)
                 rt = torch.stack([-1.0 / A, -E / A], dim=1)           # C1 = -1/A_t, C2 = -E_t/A_t (csrc/common.h adam_scaled_step_pk)
                 self.replay_tab = rt.to(torch.float32).to(dev).contiguous()
@@ -116,6 +123,7 @@ class FusedAdam:
         hp.inv_bc2 = self.inv_bc2.data_ptr()
         hp.replay_tab = None if self.replay_tab is None else self.replay_tab.data_ptr()
         hp.k1, hp.k2 = self._k1, self._k2
+        hp.ik1, hp.ik2, hp.k1_lo, hp.k2_lo = self._ik1, self._ik2, self._k1_lo, self._k2_lo
         return hp
 
     def _stream(self):

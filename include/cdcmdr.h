@@ -127,7 +127,12 @@ typedef struct {
     const float* inv_bc2;           /* fast_replay: device table [n_scalars] of 1/sqrt(1-beta2^t) */
     const float* replay_tab;        /* fast_replay in scaled state (NULL = off): device table [n_scalars][2] of
                                        {A_t = step_size_t * k1 * sqrt(1-beta2^t) / sqrt(k2),  E_t = eps * sqrt(1-beta2^t) / sqrt(k2)} */
-    float k1, k2;                   /* k1 = (1-beta1) * (2*l2 + wd),  k2 = (1-beta2) * (2*l2 + wd)^2  (fp32; both > 0 to enable) */
+    float k1, k2;                   /* the scales of the scaled state, k1 ~ (1-beta1) * (2*l2 + wd),  k2 ~ (1-beta2) * (2*l2 + wd)^2  (both > 0 to
+                                       enable): M = m * ik1, V = v * ik2 on the way in; m = M * (k1 + k1_lo), v = V * (k2 + k2_lo) on the way
+                                       out, where k + k_lo = 1 / ik to 2^-48 — so that a row's state does not pick up the factor
+                                       (ik * k) = 1 + 6e-8 with every replayed segment (round 4: that coherent drift of every row's
+                                       moments doubled the spread of the AUC over row orders) */
+    float ik1, ik2, k1_lo, k2_lo;
 } cdc_adam_hp;
 
 /* Exact dense-Adam semantics for the whole table, in three launches:

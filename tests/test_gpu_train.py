@@ -108,6 +108,51 @@ def test_lazy_fast_replay_and_periodic_flush_stay_on_the_exact_trajectory(cuda):
         assert_close(lazy[2], dense[2], 1e-4, 1e-12, f"v {kw}")
 
 
+def test_fast_replay_in_many_short_segments_does_not_drift(cuda):
+    """The scaled-state replay turns a row's moments into M = m * ik, V = v * ik2 at the start of a segment and back at its end.
+    With the way back as `* k` (k the fp32 scale, ik = fl(1/k)) every segment left the factor ik * k = 1 +- 6e-8 on the state —
+    the SAME factor on every row, every segment: 300 one-step segments moved v by 2e-5 relative to one 300-step segment, and over a
+    training run that coherent drift of all moments doubled the spread of the AUC over row orders (tools/auc_spread_probe.py,
+    DESIGN.md section 7).  Now the way back multiplies by k + k_lo = 1 / ik to 2^-48: 300 one-step segments and one 300-step segment
+    agree to rounding noise (a random walk of half-ulp roundings: ~1e-6), with no common sign."""
+    from cdcmdr_amd.model.ple import PLE
+    from cdcmdr_amd.optim import FusedAdam
+    fd = [50, 3000, 7, 900]
+    K = 300
+    res = {}
+    for segments in ("short", "long"):
+        torch.manual_seed(11)
+        model = PLE(fd, 8, 3, 1, 1, ((16,), (8,)), (8,), dropout=0.0).to(cuda).set_precision("f32")
+        opt = FusedAdam(model, table_mode="lazy", fast_replay=True, flush_every=0)
+        assert opt.replay_tab is not None
+        g = torch.Generator(device="cpu").manual_seed(3)
+        R, D = opt.table.shape
+        with torch.no_grad():
+            opt.table.data.copy_((torch.randn(R, D, generator=g) * 0.01).to(cuda))
+            opt.table_m.copy_((torch.randn(R, D, generator=g) * 1e-3).to(cuda))          # moments at the scale real gradients leave
+            opt.table_v.copy_((torch.rand(R, D, generator=g) * 1e-6 + 1e-8).to(cuda))
+        opt.table_last.zero_()
+        opt.step_dev.zero_()
+        if segments == "short":
+            for _ in range(K):
+                opt.step_dev += 1
+                opt.flush_table()
+        else:
+            opt.step_dev += K
+            opt.flush_table()
+        torch.cuda.synchronize()
+        assert int(opt.table_last.min().item()) == K
+        res[segments] = (opt.table.data.double().cpu(), opt.table_v.double().cpu())
+    dw = (res["short"][0] - res["long"][0]).abs()
+    assert float(dw.max()) < 2e-7, f"w: one-step segments differ from one long segment by {float(dw.max()):.2e}"      # (|w| ~ 1e-2: ulp 1e-9)
+    a, b = res["short"][1], res["long"][1]
+    rel = (a - b) / b.abs().clamp_min(1e-30)
+    # rounding noise: |rel| a few 1e-7 with both signs; the drift this guards against: +-1.8e-5 on every element of v, one sign
+    print(f"v: max |rel| {float(rel.abs().max()):.2e}, mean rel {float(rel.mean()):+.2e}")
+    assert float(rel.abs().max()) < 3e-6, f"v: one-step segments differ from one long segment by {float(rel.abs().max()):.2e} (relative)"
+    assert abs(float(rel.mean())) < 2e-7, f"v: common relative shift {float(rel.mean()):+.2e}"
+
+
 def test_dense_and_lazy_table_modes_are_bit_identical(cuda):
     from cdcmdr_amd.optim import FusedAdam
     from cdcmdr_amd.trainer import TrainStep

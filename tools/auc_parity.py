@@ -171,7 +171,7 @@ def side_oracle(args, fd, sd0, train, ev, bf16=False, perm_seed=None):
     return np.concatenate(out).astype(np.float32)
 
 
-def side_hip(args, fd, model, sd0, train, ev, precision, perm_seed=None):
+def side_hip(args, fd, model, sd0, train, ev, precision, perm_seed=None, fast_replay=True, scaled_replay=True, **step_kw):
     import torch
     from cdcmdr_amd.optim import FusedAdam
     from cdcmdr_amd.trainer import TrainStep
@@ -179,8 +179,10 @@ def side_hip(args, fd, model, sd0, train, ev, precision, perm_seed=None):
     model.load_state_dict(sd0)
     model = model.to(dev).set_precision(precision)
     model.train()
-    opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode="lazy")
-    ts = TrainStep(model, opt, B, mode="multi", use_graph=True)
+    opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode="lazy", fast_replay=fast_replay)
+    if not scaled_replay:
+        opt.replay_tab = None                      # (probe: the hardware rcp / sqrt at the exact recurrence's rounding points, csrc/common.h adam_elem_fast_pk)
+    ts = TrainStep(model, opt, B, mode="multi", use_graph=True, **step_kw)
     Xtr, ytr, gtr = (torch.from_numpy(a).to(dev) for a in train)
     for s in range(args.steps):
         sl = slice(s * B, (s + 1) * B)
