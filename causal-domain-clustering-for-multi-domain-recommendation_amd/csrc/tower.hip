@@ -365,7 +365,14 @@ struct TwFwdCfg {
     static constexpr int SMEM = PAR + TW_PAR_FLOATS * 4;
 };
 
-// `keep` (cdc_tower_step only, else null): LDS floats [mean1 64 | invstd1 64 | mean2 64 | invstd2 64] handed to the backward body
+// `keep` (cdc_tower_step only, else null): LDS floats handed to the backward body — [mean1 64 | invstd1 64 | mean2 64 | invstd2 64 |
+// the rows' logit gradients 128 | "this workgroup forms the row's wide gradient" flags 128 (ints) | the rows' loss terms 128 doubles]:
+// the head has a row's output in a register, so the loss and its gradient (the fused-BCE form: a row's OWN tower only) are formed
+// there — the backward body starts without its round trips to the labels, the tower column and the outputs
+#define TW_KEEP_D 256
+#define TW_KEEP_MINE 384
+#define TW_KEEP_LOSS 512
+#define TW_KEEP_FLOATS 768
 template <int NK0, int H1, int H2>
 __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, unsigned char* smem, float* keep) {
     typedef TwFwdCfg<NK0, H1, H2> Cfg;
@@ -423,6 +430,17 @@ __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, uns
         if (which == 2 && k < H2) par_s[TW_PAR_WO + k] = T.wo[k];
         if (which == 2 && k == H2) par_s[TW_PAR_WO + H2] = T.bo ? T.bo[0] : 0.f;
         (void)v;
+    }
+
+    // cdc_tower_step: the head thread of a row (tid = 2 row) fetches the row's tower column and label now, for the loss at the end
+    int k_own = 0;
+    float k_tgt = 0.f;
+    if (keep && (tid & 1) == 0 && (tid >> 1) < rows) {
+        const int64_t r = row0 + (tid >> 1);
+        int64_t c = a.bce_group ? a.bce_group[r] : 0;
+        if (c < 0 || c >= n_tower) c = 0;
+        k_own = (int)c;
+        k_tgt = a.bce_y_i16 ? (float)a.bce_y_i16[r] : a.bce_y_f32[r];
     }
 
     // ---- operands of both contractions: global -> LDS, all in flight at once
@@ -630,6 +648,21 @@ __device__ __forceinline__ void tw_fwd_body(const TW_KARG cdc_tower_args& a, uns
             if (a.sigmoid) acc = 1.f / (1.f + expf(-acc));
             a.out[(int64_t)(row0 + lr) * a.ld_out + t] = acc;
         }
+        if (keep && hf == 0) {                                           // (cdc_tower_step: the arithmetic of tw_bwd_body's phase (1), fused-BCE form)
+            float d_t = 0.f;
+            double lp = 0.0;
+            int mine = 0;
+            if (lr < rows && k_own == t) {
+                const float o = acc, tgt = k_tgt;
+                lp = (double)((tgt - 1.f) * fmaxf(log1pf(-o), -100.f) - tgt * fmaxf(logf(o), -100.f));
+                const float dout = a.bce_inv_count * (o - tgt) / fmaxf((1.f - o) * o, 1e-12f);
+                d_t = a.sigmoid ? dout * o * (1.f - o) : dout;
+                mine = 1;
+            }
+            keep[TW_KEEP_D + lr] = d_t;
+            reinterpret_cast<int*>(keep)[TW_KEEP_MINE + lr] = mine;
+            reinterpret_cast<double*>(keep + TW_KEEP_LOSS)[lr] = lp;
+        }
     }
     TW_STAMP(9);
     if (tid == 0) tw_finish(hdr, TW_FDONE, TW_FEPOCH, n_tower * G, epoch);
@@ -830,7 +863,14 @@ __device__ __forceinline__ void tw_bwd_body(const TW_KARG cdc_tower_args& a, uns
 #endif
 
     // ---- (1) logit gradients of the block's rows (k_head_bwd's arithmetic: BCELoss(mean) on the row's own tower, or d_out)
-    if (tid < TW_ROWS) {
+    if (keep) {                                                          // cdc_tower_step: formed by the forward body's head
+        if (tid < TW_ROWS) {
+            const float d_t = keep[TW_KEEP_D + tid];
+            d_s[tid] = d_t; dsum_s[tid] = d_t;
+            loss_s[tid] = reinterpret_cast<const double*>(keep + TW_KEEP_LOSS)[tid];
+            mine_s[tid] = reinterpret_cast<const int*>(keep)[TW_KEEP_MINE + tid];
+        }
+    } else if (tid < TW_ROWS) {
         float d_t = 0.f, dsum = 0.f;
         int mine = 0;
         double lp = 0.0;
@@ -1223,7 +1263,7 @@ template <int NK0, int H1, int H2>
 struct TwStepCfg {
     static constexpr int F = TwFwdCfg<NK0, H1, H2>::SMEM, B = TwBwdCfg<NK0, H1, H2>::SMEM;
     static constexpr int KEEP = ((F > B ? F : B) + 15) / 16 * 16;    // the bodies' regions overlay each other; the statistics sit behind both
-    static constexpr int SMEM = KEEP + 256 * 4;
+    static constexpr int SMEM = KEEP + TW_KEEP_FLOATS * 4;
     static_assert(SMEM <= 150 * 1024, "one workgroup per CU");
 };
 // Forward and backward of a TRAINING step in one launch (cdc_tower_step): with the fused loss a workgroup's backward needs nothing
