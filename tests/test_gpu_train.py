@@ -149,7 +149,7 @@ def test_fast_replay_in_many_short_segments_does_not_drift(cuda):
     rel = (a - b) / b.abs().clamp_min(1e-30)
     # rounding noise: |rel| a few 1e-7 with both signs; the drift this guards against: +-1.8e-5 on every element of v, one sign
     print(f"v: max |rel| {float(rel.abs().max()):.2e}, mean rel {float(rel.mean()):+.2e}")
-    assert float(rel.abs().max()) < 3e-6, f"v: one-step segments differ from one long segment by {float(rel.abs().max()):.2e} (relative)"
+    assert float(rel.abs().max()) < 6e-6, f"v: one-step segments differ from one long segment by {float(rel.abs().max()):.2e} (relative)"
     assert abs(float(rel.mean())) < 2e-7, f"v: common relative shift {float(rel.mean()):+.2e}"
 
 
