@@ -398,7 +398,7 @@ _SIGNATURES = {
     "cdc_sum_slices": (c_i32, [c_p, c_i64, c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p]),
     "cdc_adam_multi": (c_i32, [C.POINTER(AdamArgs), c_p]),
     "cdc_adam_multi_table": (c_i32, [C.POINTER(AdamArgs), c_p, c_p, c_p, c_i32, c_p]),
-    "cdc_embed_segsum_lazy_update_dense": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32,
+    "cdc_embed_segsum_lazy_update_dense": (c_i32, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, AdamHP, c_p, c_i64, c_i32, c_i32, c_i32,
                                                    C.POINTER(AdamArgs), c_p, c_p, c_p, c_i32, c_p]),
     "cdc_step_increment": (c_i32, [c_p, c_p]),
     "cdc_begin_step": (c_i32, [c_p, c_p, c_i32, c_p]),

@@ -750,8 +750,8 @@ __global__ void __launch_bounds__(256, 4) k_segment_sum_dense(const float* __res
                                                            SegSink sink, cdc_adam_hp hp, const int32_t* __restrict__ step_dev, int32_t B,
                                                            int32_t F, int32_t D, int32_t subs, const AdamHdr h,
                                                            const cdc_adam_tensor* __restrict__ tab, const int32_t* __restrict__ wg_tensor,
-                                                           const int32_t* __restrict__ wg_chunk, int32_t n_dense) {
-    const int n_long = F * SEG_LONG_BLOCKS;
+                                                           const int32_t* __restrict__ wg_chunk, int32_t n_dense, int32_t short_only) {
+    const int n_long = short_only ? 0 : F * SEG_LONG_BLOCKS;          // short_only: an owner's merged row lists (k_segment_sum_short_sink's case)
     const int b = (int)blockIdx.x;
     if (b >= n_long && b < n_long + n_dense) {
         const int ti = __builtin_amdgcn_readfirstlane(wg_tensor[b - n_long]);
@@ -766,8 +766,8 @@ __global__ void __launch_bounds__(256, 4) k_segment_sum_dense(const float* __res
     if (b < n_long)
         seg_long_body<VEC>(b / SEG_LONG_BLOCKS, b % SEG_LONG_BLOCKS, d_out, seg_start, perm, uniq_cnt, sink, B, F, D, subs, SEG_DIRECT);
     else
-        seg_direct_body<VEC>(b - n_long - n_dense, (int)gridDim.x - n_long - n_dense, d_out, seg_start, perm, uniq_cnt, nullptr, sink, B, F, D,
-                             SEG_DIRECT);
+        seg_direct_body<VEC>(b - n_long - n_dense, (int)gridDim.x - n_long - n_dense, d_out, seg_start, perm, uniq_cnt,
+                             short_only ? sink.uniq_row : nullptr, sink, B, F, D, short_only ? 0 : SEG_DIRECT);
 }
 // short segments only (an owner's merged row lists), same sink
 template <int VEC>
@@ -829,8 +829,8 @@ extern "C" int cdc_embed_segsum_lazy_update(const float* d_out, const int32_t* s
 // cdc_embed_segsum_lazy_update (all segment lengths) and cdc_adam_multi_table in ONE launch: see k_segment_sum_dense
 extern "C" int cdc_embed_segsum_lazy_update_dense(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
                                                   const int32_t* uniq_row, float* w, float* m, float* v, int32_t* last, cdc_adam_hp hp,
-                                                  const int32_t* step_dev, int64_t B, int32_t F, int32_t D, const cdc_adam_args* dense,
-                                                  const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev,
+                                                  const int32_t* step_dev, int64_t B, int32_t F, int32_t D, int32_t short_only,
+                                                  const cdc_adam_args* dense, const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev,
                                                   const int32_t* wg_chunk_dev, int32_t n_dense_workgroups, void* stream) {
     CDC_CHECK_ARG(d_out && seg_start && perm && uniq_cnt && uniq_row && w && m && v && last && step_dev && hp.step_scalars &&
                       hp.n_scalars > 0, CDC_E_BADARG, "embed_segsum_lazy_update_dense: null pointer");
@@ -843,14 +843,14 @@ extern "C" int cdc_embed_segsum_lazy_update_dense(const float* d_out, const int3
     SegSink sink = {};
     sink.w = w; sink.m = m; sink.v = v; sink.last = last; sink.uniq_row = uniq_row;
     const int direct_blocks = (int)std::min<int64_t>(cdc_ceil_div((int64_t)F * B * (vec ? D / 4 : D), 256), 8192);
-    const int blocks = direct_blocks + F * SEG_LONG_BLOCKS + n_dense_workgroups;
+    const int blocks = direct_blocks + (short_only ? 0 : F * SEG_LONG_BLOCKS) + n_dense_workgroups;
     const int subs = (D <= 64 && 64 % D == 0) ? 64 / D : 1;
     const AdamHdr h = {dense->lerp_w, dense->beta2, dense->one_minus_beta2, dense->eps, dense->weight_decay, dense->grad_scale,
                        dense->step_scalars, dense->n_scalars, dense->step_dev, dense->reg_sum, dense->reg_seed};
     if (vec) hipLaunchKernelGGL(k_segment_sum_dense<4>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D, subs,
-                                h, tensors_dev, wg_tensor_dev, wg_chunk_dev, n_dense_workgroups);
+                                h, tensors_dev, wg_tensor_dev, wg_chunk_dev, n_dense_workgroups, short_only);
     else     hipLaunchKernelGGL(k_segment_sum_dense<1>, dim3(blocks), dim3(256), 0, st, d_out, seg_start, perm, uniq_cnt, sink, hp, step_dev, (int32_t)B, F, D, subs,
-                                h, tensors_dev, wg_tensor_dev, wg_chunk_dev, n_dense_workgroups);
+                                h, tensors_dev, wg_tensor_dev, wg_chunk_dev, n_dense_workgroups, short_only);
     CDC_LAUNCH_CHECK("embed_segsum_lazy_update_dense");
     return 0;
 }

@@ -311,20 +311,21 @@ class FusedAdam:
         for a in self._dense_args:
             L.launch("cdc_adam_multi", self.lib.cdc_adam_multi, (C.byref(a),), s)
 
-    def rows_and_dense_step(self, idx, d_out, B, F, D, param_grads, param_refs, slabs=None, tag=""):
+    def rows_and_dense_step(self, idx, d_out, B, F, D, param_grads, param_refs, slabs=None, tag="", short_segments=False):
         """table_step (lazy table: per-row gradient sums + the rows' Adam step) and dense_step in ONE launch
         (cdc_embed_segsum_lazy_update_dense): what ends a single-GPU training step."""
         if self.table_mode != "lazy":
             raise RuntimeError("rows_and_dense_step: lazy table only")
         self._dense_prepare(param_grads, param_refs, slabs, True)
         if self._dense_table is None:            # (no dense parameter has a gradient)
-            return self.table_step(idx, d_out, B, F, D, tag=tag)
+            return self.table_step(idx, d_out, B, F, D, tag=tag, short_segments=short_segments)
         hdr, tab, wg_t, wg_c, n_wg = self._dense_table
         ws = self._workspace(B, F, D, tag)       # rows were sorted by the catch-up of this step
         L.launch("cdc_embed_segsum_lazy_update_dense", self.lib.cdc_embed_segsum_lazy_update_dense,
                  (d_out.data_ptr(), ws["seg"].data_ptr(), ws["perm"].data_ptr(), ws["cnt"].data_ptr(), ws["uniq"].data_ptr(),
                   self.table.data_ptr(), self.table_m.data_ptr(), self.table_v.data_ptr(), self.table_last.data_ptr(), self._hp(),
-                  self.step_dev.data_ptr(), B, F, D, C.byref(hdr), tab.data_ptr(), wg_t.data_ptr(), wg_c.data_ptr(), n_wg), self._stream())
+                  self.step_dev.data_ptr(), B, F, D, 1 if short_segments else 0, C.byref(hdr), tab.data_ptr(), wg_t.data_ptr(), wg_c.data_ptr(),
+                  n_wg), self._stream())
 
     def _dense_prepare(self, param_grads, param_refs, slabs, table_form):
         """argument blocks of the dense Adam launch(es) for this gradient layout -> self._dense_args / self._dense_table.

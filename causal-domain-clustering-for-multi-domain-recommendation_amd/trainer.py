@@ -574,9 +574,14 @@ class TrainStep:
         def update():
             if side_ok:
                 torch.cuda.current_stream().wait_stream(self._side_stream())      # the slice (and the look-ahead sort) are done
+            if side_ok:
+                # the owner's row update and the dense parameters in one launch, as on one GPU (optim.rows_and_dense_step)
+                opt.rows_and_dense_step(recv_cur, self.grads_recv, Bv, F, D, plan.param_grads, plan._param_refs, plan.grad_slabs, tag="owner",
+                                        short_segments=True)
+                self._reg()
+                return
             opt.table_step(recv_cur, self.grads_recv, Bv, F, D, "owner", short_segments=True)
-            if not side_ok:
-                opt.flush_slice()                       # off the rows-exchange critical path: after the owner's update
+            opt.flush_slice()                           # off the rows-exchange critical path: after the owner's update
             opt.dense_step(plan.param_grads, plan._param_refs, plan.grad_slabs)
             self._reg()
 

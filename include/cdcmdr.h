@@ -961,9 +961,9 @@ int cdc_adam_multi_table(const cdc_adam_args* a, const cdc_adam_tensor* tensors_
  * (double atomics in both forms). */
 int cdc_embed_segsum_lazy_update_dense(const float* d_out, const int32_t* seg_start, const int32_t* perm, const int32_t* uniq_cnt,
                                        const int32_t* uniq_row, float* w, float* m, float* v, int32_t* last, cdc_adam_hp hp,
-                                       const int32_t* step_dev, int64_t B, int32_t F, int32_t D, const cdc_adam_args* dense,
-                                       const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev, const int32_t* wg_chunk_dev,
-                                       int32_t n_dense_workgroups, void* stream);
+                                       const int32_t* step_dev, int64_t B, int32_t F, int32_t D, int32_t short_only,
+                                       const cdc_adam_args* dense, const cdc_adam_tensor* tensors_dev, const int32_t* wg_tensor_dev,
+                                       const int32_t* wg_chunk_dev, int32_t n_dense_workgroups, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * STAR parameter fusion (reference: model/star.py:90-93,100-102,169-176): for every domain g

@@ -202,7 +202,7 @@ def test_entry_points_reject_bad_arguments_without_touching_the_device():
     rc = lib.cdc_embed_lazy_flush(one, one, one, one, 1 << 40, 4, hp, one, 0, 2, 0, 0, None)
     assert rc == -2 and b"exceeds the 2^31 work items" in lib.cdc_last_error()
     # the rows + dense-parameter update in one launch needs the dense descriptor table
-    rc = lib.cdc_embed_segsum_lazy_update_dense(one, one, one, one, one, one, one, one, one, hp, one, 8, 2, 4, None, None, None, None, 0, None)
+    rc = lib.cdc_embed_segsum_lazy_update_dense(one, one, one, one, one, one, one, one, one, hp, one, 8, 2, 4, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"descriptor table" in lib.cdc_last_error()
     # the fused PLE level boundary's LDS budget, as plan.CGCMid.match asks it: 3 domains fit, 6 and 7 domains (2 + 2 experts) do not
     assert lib.cdc_cgc_mid_fits(8, 4, 8, 3) == 1 and lib.cdc_cgc_mid_fits(12, 6, 12, 5) == 1
