@@ -352,6 +352,7 @@ _SIGNATURES = {
     "cdc_shadow_bf16": (c_i32, [C.POINTER(ShadowArgs), c_p]),
     "cdc_glinear_bwd_w": (c_i32, [C.POINTER(LinBwdwArgs), c_i32, c_p]),
     "cdc_glinear_bwd_w_pair": (c_i32, [C.POINTER(LinBwdwArgs), C.POINTER(LinBwdwArgs), c_p, c_p]),
+    "cdc_glinear_bwd_w_pair_reduce": (c_i32, [C.POINTER(LinBwdwArgs), C.POINTER(LinBwdwArgs), c_p, c_p]),
     "cdc_gate_pool_fwd": (c_i32, [C.POINTER(PoolFwdArgs), c_p]),
     "cdc_cgc_mid_fwd": (c_i32, [C.POINTER(CgcMidFwdArgs), c_p]),
     "cdc_cgc_mid_bwd": (c_i32, [C.POINTER(CgcMidBwdArgs), c_p]),

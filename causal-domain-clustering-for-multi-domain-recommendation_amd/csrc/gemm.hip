@@ -764,8 +764,10 @@ __global__ void __launch_bounds__(GEMM_THREADS) k_glinear_bwd_w(const cdc_lin_bw
         }
 }
 
-__global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a, int64_t slab_stride, int64_t total) {
-    CDC_PRIO_MAIN();
+// (the body is a device function so that one launch can reduce the slabs of two grad-weight launches: k_bwd_w_reduce_dual below; `a` may
+// live in the kernel argument block or in device memory)
+__device__ __forceinline__ void bwd_w_reduce_body(const cdc_lin_bwdw_args& a, const int64_t slab_stride, const int64_t total, const int bid,
+                                                  const int nblk) {
     // one flat index space over all groups: a slab IS the concatenation [dW_0 | db_0 | dW_1 | db_1 | ...]
     __shared__ int64_t first[CDC_MAX_GROUPS + 1];                      // first flat index of every group (scan by wave 0)
     if (threadIdx.x < 64) {
@@ -791,7 +793,7 @@ __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a,
     }
     if (vec4) {
         const int64_t total4 = (total + 3) / 4;
-        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t q = (int64_t)bid * blockDim.x + threadIdx.x; q < total4; q += (int64_t)nblk * blockDim.x) {
             const int64_t e = q * 4;
             int g = 0;
             while (g + 1 < a.n_groups && e >= first[g + 1]) ++g;
@@ -829,7 +831,7 @@ __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a,
         }
         return;
     }
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < total; e += (int64_t)nblk * blockDim.x) {
         // slabs are added in slice order (deterministic); four loads are in flight per round
         float sum = 0.f;
         int s = 0;
@@ -852,6 +854,18 @@ __global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a,
             *dst = G.accumulate ? *dst + sum : sum;
         }
     }
+}
+__global__ void __launch_bounds__(256) k_bwd_w_reduce(const cdc_lin_bwdw_args a, int64_t slab_stride, int64_t total) {
+    CDC_PRIO_MAIN();
+    bwd_w_reduce_body(a, slab_stride, total, blockIdx.x, gridDim.x);
+}
+// the slabs of the wide and of the narrow class of a step's batched grad-weight contractions (k_g2_tn_dual) summed by ONE launch: workgroups
+// [0, n_first) take tabs[0], the others tabs[1]
+__global__ void __launch_bounds__(256) k_bwd_w_reduce_dual(const cdc_lin_bwdw_args* __restrict__ tabs, int64_t slab0, int64_t total0, int64_t slab1,
+                                                           int64_t total1, int n_first) {
+    CDC_PRIO_MAIN();
+    if ((int)blockIdx.x < n_first) bwd_w_reduce_body(tabs[0], slab0, total0, blockIdx.x, n_first);
+    else bwd_w_reduce_body(tabs[1], slab1, total1, (int)blockIdx.x - n_first, (int)gridDim.x - n_first);
 }
 
 // =================================================================================================
@@ -1158,6 +1172,23 @@ extern "C" int cdc_glinear_bwd_w_pair(const cdc_lin_bwdw_args* wide, const cdc_l
         }
     }
     return g2_launch_bwd_w_dual(wide, narrow, tabs_dev, slab[0], slab[1], (hipStream_t)stream);
+}
+// the same, and the slabs of both classes summed into the gradients by ONE more launch (callers that need the reduced gradient right
+// away: data parallelism all-reduces it; autograd hands it on) — two launches where cdc_glinear_bwd_w twice issues four
+extern "C" int cdc_glinear_bwd_w_pair_reduce(const cdc_lin_bwdw_args* wide, const cdc_lin_bwdw_args* narrow, const cdc_lin_bwdw_args* tabs_dev,
+                                             void* stream) {
+    const int rc = cdc_glinear_bwd_w_pair(wide, narrow, tabs_dev, stream);
+    if (rc) return rc;
+    CDC_CHECK_ARG(wide->split_k > 1 && narrow->split_k > 1, CDC_E_BADARG, "glinear_bwd_w_pair_reduce: both classes must be split (else cdc_glinear_bwd_w_pair)");
+    int64_t slab[2] = {0, 0};
+    for (int w = 0; w < 2; ++w) {
+        const cdc_lin_bwdw_args* a = w ? narrow : wide;
+        for (int g = 0; g < a->n_groups; ++g) slab[w] += (int64_t)a->g[g].N * a->g[g].K + a->g[g].N;
+    }
+    const int b0 = (int)std::min<int64_t>(cdc_ceil_div(slab[0], 1024), 4096), b1 = (int)std::min<int64_t>(cdc_ceil_div(slab[1], 1024), 4096);
+    hipLaunchKernelGGL(k_bwd_w_reduce_dual, dim3(b0 + b1), dim3(256), 0, (hipStream_t)stream, tabs_dev, slab[0], slab[0], slab[1], slab[1], b0);
+    CDC_LAUNCH_CHECK("bwd_w_reduce_dual");
+    return 0;
 }
 
 extern "C" int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void* stream) {

@@ -520,9 +520,17 @@ class Plan:
         # launches that leave the slab reduction to the optimiser get a workspace region of their own behind the shared one
         # (their slabs must survive until the dense Adam launch)
         own, extra = {}, 0
-        if self.defer_dw_reduce:
+        shad = lambda a: all(a.g[i].dzh and a.g[i].xh for i in range(a.n_groups))      # noqa: E731
+        splittable = lambda a: a.split_k > 1 and not any(a.g[i].accumulate for i in range(a.n_groups))     # noqa: E731
+        # the wide and the narrow class of the batched grad-weight contractions as ONE launch (csrc/gemm2.hip k_g2_tn_dual)?
+        two_classes = (len(dw) == 2 and shad(dw[0][0]) and shad(dw[1][0]) and any(dw[0][0].g[i].N > 64 for i in range(dw[0][0].n_groups)) and
+                       all(dw[1][0].g[i].N <= 64 for i in range(dw[1][0].n_groups)))
+        # ... whose slabs the consumer adds up (single GPU: the dense Adam launch) or, where the reduced gradient is needed at once (data
+        # parallelism all-reduces it), ONE more launch (cdc_glinear_bwd_w_pair_reduce): two launches instead of four
+        pair_reduce = (not self.defer_dw_reduce) and two_classes and all(splittable(a) for a, _ in dw)
+        if self.defer_dw_reduce or pair_reduce:
             for a, fl in dw:
-                if a.split_k > 1 and not any(a.g[i].accumulate for i in range(a.n_groups)):
+                if splittable(a):
                     slab = sum(a.g[i].N * a.g[i].K + a.g[i].N for i in range(a.n_groups))
                     own[id(a)] = (extra, slab)
                     extra += (a.split_k * slab + 3) // 4 * 4
@@ -532,11 +540,8 @@ class Plan:
             for a in self._gemm_ws_users:
                 a.workspace = self._gemm_ws.data_ptr()
         pair = None
-        if len(dw) == 2 and all(id(a) in own or a.split_k <= 1 for a, _ in dw) and self.defer_dw_reduce:
-            (aw, _), (an, _) = dw
-            shad = lambda a: all(a.g[i].dzh and a.g[i].xh for i in range(a.n_groups))      # noqa: E731
-            if shad(aw) and shad(an) and any(aw.g[i].N > 64 for i in range(aw.n_groups)) and all(an.g[i].N <= 64 for i in range(an.n_groups)):
-                pair = (aw, an)
+        if two_classes and all(id(a) in own or a.split_k <= 1 for a, _ in dw) and (self.defer_dw_reduce or pair_reduce):
+            pair = (dw[0][0], dw[1][0])
         for a, fl in dw:
             a.workspace = self._gemm_ws.data_ptr()
             if id(a) in own:
@@ -546,9 +551,10 @@ class Plan:
                 pos = 0
                 for i in range(a.n_groups):
                     G = a.g[i]
-                    self.grad_slabs[G.dw] = (a.workspace + 4 * pos, slab, a.split_k)
-                    if G.db:
-                        self.grad_slabs[G.db] = (a.workspace + 4 * (pos + G.N * G.K), slab, a.split_k)
+                    if self.defer_dw_reduce:
+                        self.grad_slabs[G.dw] = (a.workspace + 4 * pos, slab, a.split_k)
+                        if G.db:
+                            self.grad_slabs[G.db] = (a.workspace + 4 * (pos + G.N * G.K), slab, a.split_k)
                     pos += G.N * G.K + G.N
             if pair is not None:
                 continue
@@ -560,8 +566,8 @@ class Plan:
             # two argument blocks travel as a device copy, made now that their workspaces are final
             aw, an = pair
             self._dw_pair_dev = torch.frombuffer(bytearray(bytes(aw) + bytes(an)), dtype=torch.uint8).to(self.device)
-            step = self.call("cdc_glinear_bwd_w_pair", C.byref(aw), C.byref(an), self._dw_pair_dev.data_ptr(), what="cdc_glinear_bwd_w",
-                             flops=sum(fl for _, fl in dw))
+            step = self.call("cdc_glinear_bwd_w_pair_reduce" if pair_reduce else "cdc_glinear_bwd_w_pair", C.byref(aw), C.byref(an),
+                             self._dw_pair_dev.data_ptr(), what="cdc_glinear_bwd_w", flops=sum(fl for _, fl in dw))
             self.bwd_steps.append(step)
             self.deferred_dw_steps.append(step)
         self.bwd_steps[0:0] = self._emit_transposes()

@@ -390,6 +390,10 @@ int cdc_glinear_bwd_w(const cdc_lin_bwdw_args* a, int32_t prec, void* stream);
  * no row_offsets, and either split_k <= 1 or defer_reduce (the slab-adding launch is left to the consumer).  Same arithmetic as two
  * cdc_glinear_bwd_w calls. */
 int cdc_glinear_bwd_w_pair(const cdc_lin_bwdw_args* wide, const cdc_lin_bwdw_args* narrow, const cdc_lin_bwdw_args* tabs_dev, void* stream);
+/* ... and the slabs of both classes added into the gradients by ONE more launch (same sums, same slice order as cdc_glinear_bwd_w's
+ * own reduce launch): for callers that need the reduced gradient at once (data parallelism all-reduces it).  Both classes split. */
+int cdc_glinear_bwd_w_pair_reduce(const cdc_lin_bwdw_args* wide, const cdc_lin_bwdw_args* narrow, const cdc_lin_bwdw_args* tabs_dev,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gate softmax + expert pooling (reference: model/ple.py:89-94,105-123; model/mmoe.py:37-40,58-60)
