@@ -11,17 +11,24 @@
 // grad-weight launches and the next grad-input launch read: bf16 dZ of both expert levels and the gate-logit gradients.
 //
 // Shape of the kernels (what three slower versions taught, profiles/round3/README.md):
-//   * 1024 threads per workgroup: in the row-wise phases wave w IS batch row w (lane = column: two columns of H1 = 128, one of
-//     H2 = 64), in the MFMA phases wave w takes tiles w, w+16, ...  A 256-thread version ran one wave per SIMD and every LDS /
+//   * 1024 threads per workgroup: in the forward's pooling phases wave w IS batch row w (lane = column: two columns of H1 = 128, one
+//     of H2 = 64), in the MFMA phases wave w takes tiles w, w+16, ...  A 256-thread version ran one wave per SIMD and every LDS /
 //     DPP / scalar-load latency of its dependent chains lay bare (30 / 47 us); four waves per SIMD cover each other.
 //   * nothing is unrolled over (gate, expert): a fully unrolled version was 50-85 KB of straight-line code that is executed
 //     once per workgroup, i.e. fetched cold.  Loops are rolled; what they index with run-time values sits in LDS, put there by
 //     direct-to-LDS loads issued at kernel entry (no registers, so the issuing loop is rolled as well).
 //   * every global load that depends on nothing is issued at entry (expert rows, B fragments + bias of the wave's tiles); no
 //     load sits between a value's first use and the previous barrier.
-//   * the argument block is read through the kernarg segment pointer (indexing the by-value struct with run-time values makes
-//     the compiler keep a private copy of all 2.5 KB of it in scratch), and descriptor fields are copied to locals before the
-//     loops that use them: reads through that pointer are not treated as invariant across stores.
+//   * the argument block is copied from the kernarg segment to LDS at entry, every thread one 8-byte piece (round 4): what the entry
+//     reads of it — counts, then the descriptors they index, then what those point to — was a chain of dependent reads of memory
+//     that is cold at every launch, 1-2 us each and most of a 9-10 us entry; now ONE such read.  (Indexing the by-value struct with
+//     run-time values had made the compiler keep a private copy of all 2.5 KB of it in scratch; round 3 read it through the
+//     kernarg segment pointer.)
+//   * round 4, after phase stamps (tools/mid_trace.py, profiles/round4/README.md section 11): with 16 waves on the CU a row-wise
+//     phase is bound by instruction ISSUE as soon as it spends a whole wave on one row — the backward's two pool phases (a 64-lane
+//     reduction per (expert, gate) pair and row: 7.4 us each) now give a row to the 16 lanes of a DPP row, a lane four (two times
+//     four) columns, a wave four rows x every fourth expert; gate softmax and gate-logit gradients take a lane per TERM instead of a
+//     lane per gate (sums in index order out of LDS: the same bits); tables are built from one descriptor read per lane.
 #include "common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -71,18 +78,6 @@ __device__ __forceinline__ void mid_glds16(const void* g, void* l) {
 __device__ __forceinline__ void mid_glds4(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
 }
-// sum over the 64 lanes of a wave, result in every lane: four cross-lane adds in the VALU inside each DPP row of 16 (quad_perm
-// [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then two ds_bpermute steps across the rows
-__device__ __forceinline__ float mid_wave_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
 // sum over the 16 lanes of a DPP row, result in every lane of the row: four cross-lane adds in the VALU (quad_perm [1,0,3,2],
 // quad_perm [2,3,0,1], row_half_mirror, row_mirror) — the pool backwards give a batch row to 16 lanes
 __device__ __forceinline__ float mid_row16_sum(float v) {
@@ -124,33 +119,11 @@ __device__ __forceinline__ void mid_tables_store(signed char (*pos)[MID_E], unsi
         pos[g][e] = (signed char)p;
     }
 }
-template <typename GatePtr>
-__device__ __forceinline__ void mid_fill_tables(signed char (*pos)[MID_E], unsigned char (*sel)[CDC_MAX_SEL], GatePtr gates, int n_gate, int tid) {
-    mid_tables_store(pos, sel, mid_tables_fetch(gates, n_gate, tid), tid);
-}
-static_assert(MID_E == CDC_MAX_SEL, "mid_fill_tables fills both tables with one index");
+static_assert(MID_E == CDC_MAX_SEL, "mid_tables_fetch / _store fill both tables with one index");
 static_assert(2 * MID_E + MID_G <= 64, "k_cgc_mid_bwd: one lane of a wave per grad-input K-step candidate");
 
-// softmax over n_sel <= 16 values exactly as cdc_gate_pool_fwd computes it (max-subtract, expf, sum in index order, one divide)
-__device__ __forceinline__ void mid_softmax(float (&p)[CDC_MAX_SEL], int n_sel) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < CDC_MAX_SEL; ++j) {
-        if (j >= n_sel) p[j] = -INFINITY;
-        mx = fmaxf(mx, p[j]);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < CDC_MAX_SEL; ++j) {
-        p[j] = j < n_sel ? expf(p[j] - mx) : 0.f;
-        sum += p[j];
-    }
-    const float inv = 1.f / sum;
-#pragma unroll
-    for (int j = 0; j < CDC_MAX_SEL; ++j) p[j] *= inv;
-}
-
-// the same softmax with ONE gate's logits spread over the 16 lanes of a DPP row (lane j holds logit j): the maximum is order-free,
+// softmax over n_sel <= 16 values exactly as cdc_gate_pool_fwd computes it (max-subtract, expf, sum in index order, one divide),
+// with ONE gate's logits spread over the 16 lanes of a DPP row (lane j holds logit j): the maximum is order-free,
 // every lane takes one expf instead of one lane sixteen, and the sum is formed in index order out of the LDS slot the probabilities
 // go to anyway (by every lane of the row: no broadcast) — the bits of mid_softmax.  active: the row's gate exists (its slot may be
 // written); valid: j < n_sel.  Returns the lane's probability.
