@@ -201,6 +201,7 @@ def test_entry_points_reject_bad_arguments_without_touching_the_device():
     hp.step_scalars, hp.n_scalars = 16, 4
     rc = lib.cdc_embed_lazy_flush(one, one, one, one, 1 << 40, 4, hp, one, 0, 2, 0, 0, None)
     assert rc == -2 and b"exceeds the 2^31 work items" in lib.cdc_last_error()
+    assert lib.cdc_glinear_bwd_w_pair_reduce(None, None, None, None) == -1 and b"null argument" in lib.cdc_last_error()
     # the rows + dense-parameter update in one launch needs the dense descriptor table
     rc = lib.cdc_embed_segsum_lazy_update_dense(one, one, one, one, one, one, one, one, one, hp, one, 8, 2, 4, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"descriptor table" in lib.cdc_last_error()
