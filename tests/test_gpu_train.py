@@ -294,8 +294,9 @@ def test_row_sort_one_batch_ahead_trains_bit_identically(cuda, monkeypatch, use_
         assert torch.equal(res["0"][2][k][0], res["1"][2][k][0]) and torch.equal(res["0"][2][k][1], res["1"][2][k][1]), k
 
 
-@pytest.mark.parametrize("use_graph,sort_ahead,precision", [(False, True, "f32"), (True, True, "bf16"), (False, False, "bf16")])
-def test_rows_and_dense_parameters_updated_by_one_launch_train_bit_identically(cuda, use_graph, sort_ahead, precision):
+@pytest.mark.parametrize("use_graph,sort_ahead,precision,emb_dim", [(False, True, "f32", 16), (True, True, "bf16", 16), (False, False, "bf16", 16),
+                                                                     (False, True, "f32", 6)])
+def test_rows_and_dense_parameters_updated_by_one_launch_train_bit_identically(cuda, use_graph, sort_ahead, precision, emb_dim):
     """cdc_embed_segsum_lazy_update_dense (the step's table rows and the dense parameters' Adam in ONE launch, TrainStep's default on
     one GPU with the lazy table) against cdc_adam_multi followed by cdc_embed_segsum_lazy_update: per element the same arithmetic,
     the split-K slabs added in the same order — weights, moments and the BCE losses held to BIT equality, the regularisation figure
@@ -312,7 +313,8 @@ def test_rows_and_dense_parameters_updated_by_one_launch_train_bit_identically(c
     res = {}
     for one in (False, True):
         torch.manual_seed(4)
-        model = PLE(fd, 16, 3, 2, 2, ((64, 32), (16,)), (8, 4), dropout=0.2).to(cuda).set_precision(precision)
+        # (emb_dim 6: rows without whole 16-byte pieces — the scalar forms of both update bodies)
+        model = PLE(fd, emb_dim, 3, 2, 2, ((64, 32), (16,)), (8, 4), dropout=0.2).to(cuda).set_precision(precision)
         model.seed = 5
         opt = FusedAdam(model, table_mode="lazy", flush_every=4)
         ts = TrainStep(model, opt, B, use_graph=use_graph, sort_ahead=sort_ahead, rows_dense_one_launch=one)
