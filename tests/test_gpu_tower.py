@@ -195,9 +195,10 @@ def test_training_steps_with_the_fused_towers_follow_the_unfused_trajectory(cuda
             assert float(d.mean()) < 2e-4, f"{k}: mean |d| {float(d.mean()):.3e}"
 
 
-@pytest.mark.parametrize("B,n_tower,table_mode,use_graph", [(1024, 3, "lazy", True), (130, 3, "dense", False), (2, 3, "dense", False),
-                                                          (300, 4, "dense", False)])
-def test_both_directions_in_one_launch_equal_the_two_launches(cuda, B, n_tower, table_mode, use_graph):
+@pytest.mark.parametrize("B,n_tower,table_mode,use_graph,kind", [(1024, 3, "lazy", True, "ple"), (130, 3, "dense", False, "ple"),
+                                                               (2, 3, "dense", False, "ple"), (300, 4, "dense", False, "ple"),
+                                                               (1000, 3, "lazy", False, "mmoe")])
+def test_both_directions_in_one_launch_equal_the_two_launches(cuda, B, n_tower, table_mode, use_graph, kind):
     """cdc_tower_step (TrainStep's default with the fused loss on one GPU) against cdc_tower_fwd + cdc_tower_bwd: the same arithmetic
     in the same order (the backward body reads what the forward body of the same workgroup wrote; the batch statistics travel in
     LDS instead of through save_mean / save_invstd) — losses and every parameter after four steps held to BIT equality."""
@@ -212,7 +213,7 @@ def test_both_directions_in_one_launch_equal_the_two_launches(cuda, B, n_tower, 
     y = [torch.from_numpy(rng.integers(0, 2, B).astype(np.int16)).to(cuda) for _ in range(steps)]
     res = {}
     for both in (False, True):
-        m = _model(cuda, n_tower, 0.2, True)
+        m = _model(cuda, n_tower, 0.2, True, kind=kind)                # (MMoE: the towers read the 128-wide expert mixture, H0 = 128)
         m.train()
         opt = FusedAdam(m, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-8, table_mode=table_mode)
         ts = TrainStep(m, opt, B, mode="multi", use_graph=use_graph, tower_one_launch=both)
